@@ -1,0 +1,158 @@
+/*
+ * surya_amd.h -- C ABI of libsurya_amd.so, the MI355X (gfx950) implementation of surya's batched model-inference
+ * hot path. Plain pointers and sizes only; no torch types. All device pointers are HIP device memory owned by the
+ * caller (PyTorch-ROCm caching allocator on the Python side); the library owns only what it allocates in
+ * *_create(): KV-cache slots, activation workspaces and small pinned staging buffers, freed by *_destroy().
+ *
+ * Nothing like this exists in the reference (it has no native code at all): each entry point
+ * cites the reference Python interface it replaces. The reference-side binding a maintainer would add is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = SA_ERR_* (caller error), >0 = hipError_t passthrough.
+ *     Nothing throws across the ABI.
+ *   - all work is enqueued on the hipStream_t passed in (as void*); functions do not synchronise unless
+ *     documented ("sync"). A handle is re-entrant but not thread-safe: one host thread per handle, like the
+ *     reference's single-threaded device path (surya/settings.py:179-183).
+ *   - dtype: 0 = fp32 ("reference mode": exact-f32 MFMA, used for bit-exact token tests), 1 = bf16.
+ */
+#ifndef SURYA_AMD_H
+#define SURYA_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_OK 0
+#define SA_ERR_ARG (-1)
+#define SA_ERR_SHAPE (-2)
+#define SA_ERR_UNSUPPORTED (-3)
+#define SA_ERR_STATE (-4)
+#define SA_ERR_NOMEM (-5)
+
+#define SA_DTYPE_F32 0
+#define SA_DTYPE_BF16 1
+
+/* Library / build info: returns a static string "surya_amd <version> gfx950". */
+const char* surya_amd_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Recognition model: vision encoder + decoder + heads.
+ * Replaces SuryaModel.forward (surya/common/surya/__init__.py:274-338), process_outputs / decode / prefill
+ * (surya/recognition/__init__.py:294-471) and ContinuousBatchingCache (surya/recognition/cache.py:7-109).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct surya_rec_config {
+    /* vision encoder (surya/common/surya/encoder/config.py:18-53) */
+    int32_t enc_depth, enc_hidden, enc_inter, enc_inter_pad, enc_heads;
+    int32_t patch_dim, patch_dim_pad;    /* 588 and its K padding (multiple of 64) */
+    int32_t merge;                       /* spatial_merge_size */
+    int32_t window_tokens;               /* window_size / merge / patch_size (merged tokens per window side) */
+    int32_t enc_out_hidden;
+    uint32_t fullatt_mask;               /* bit i set: block i attends over the whole image */
+    float enc_eps;
+    /* decoder (surya/common/surya/decoder/config.py:28-85) */
+    int32_t vocab, dec_hidden, dec_inter, dec_layers, dec_heads, dec_kv_heads, dec_head_dim;
+    float dec_eps;
+    /* model (surya/common/surya/config.py:12-71) */
+    int32_t bbox_size, embed_multiplier;
+    int32_t image_token_id, pad_token_id, eos_token_id;
+    /* capacities */
+    int32_t max_slots;            /* continuous-batching slots (RecognitionPredictor batch size) */
+    int32_t max_kv_len;           /* prompt + generated tokens per slot */
+    int32_t max_patches;          /* encoder chunk capacity in patches (reference: encoder_chunk_size) */
+    int32_t max_prefill_tokens;   /* packed prompt tokens per prefill call */
+    int32_t dtype;
+} surya_rec_config;
+
+/* Weight table: device pointers in the compute dtype (inv_freq tables are fp32), kernel layout:
+ *   Linear weights [out, in_padded] row-major; gate|up fused and row-interleaved (g0,u0,g1,u1,...), q|k|v fused.
+ * Index = SA_RW_* for globals, SA_RW_ENC(l, k), SA_RW_DEC(l, k) for layers. The Python loader
+ * (surya_amd/recognition/weights.py) builds it from the reference's state-dict names. */
+enum {
+    SA_RW_PATCH = 0, SA_RW_MERGER_LN, SA_RW_FC1_W, SA_RW_FC1_B, SA_RW_FC2_W, SA_RW_FC2_B, SA_RW_IMG_H, SA_RW_IMG_W,
+    SA_RW_DEC_NORM, SA_RW_TOK_EMBED, SA_RW_LM_W, SA_RW_LM_B, SA_RW_BBOX_W, SA_RW_BBOX_B, SA_RW_ENC_INVFREQ,
+    SA_RW_DEC_INVFREQ, SA_RW_GLOBALS
+};
+enum { SA_RE_NORM1 = 0, SA_RE_QKV_W, SA_RE_QKV_B, SA_RE_PROJ_W, SA_RE_PROJ_B, SA_RE_NORM2, SA_RE_GU_W, SA_RE_GU_B,
+       SA_RE_DOWN_W, SA_RE_DOWN_B, SA_RE_COUNT };
+enum { SA_RD_LN1 = 0, SA_RD_QKV_W, SA_RD_QKV_B, SA_RD_O_W, SA_RD_LN2, SA_RD_GU_W, SA_RD_DOWN_W, SA_RD_COUNT };
+#define SA_RW_ENC(l, k) (SA_RW_GLOBALS + (l) * SA_RE_COUNT + (k))
+#define SA_RW_DEC(cfg_enc_depth, l, k) (SA_RW_GLOBALS + (cfg_enc_depth) * SA_RE_COUNT + (l) * SA_RD_COUNT + (k))
+#define SA_RW_TOTAL(enc_depth, dec_layers) (SA_RW_GLOBALS + (enc_depth) * SA_RE_COUNT + (dec_layers) * SA_RD_COUNT)
+
+typedef struct surya_rec surya_rec;
+
+/* Bytes of device memory *_create will allocate for this config (KV cache + workspaces). */
+size_t surya_rec_workspace_bytes(const surya_rec_config* cfg);
+
+/* Create a model instance. `weights` has SA_RW_TOTAL entries; the caller keeps the tensors alive. */
+int surya_rec_create(const surya_rec_config* cfg, const void* const* weights, int n_weights, surya_rec** out);
+int surya_rec_destroy(surya_rec* h);
+
+/* Host-only planning of the vision encoder's index math for one packed batch of images: window order
+ * (get_window_index, encoder/__init__.py:552-597), rotary position ids (rot_pos_emb, :523-550), window / image
+ * segment boundaries (:615-646). Runs without a GPU; exposed for tests.
+ *   grid_hw      [n_images*2]  patch-grid (h, w) per image (both even)
+ *   src_row      [P]           window-ordered row r reads original tile row src_row[r]
+ *   pos_hw       [P*2]         (h, w) patch coordinates in window order
+ *   cu_window    [*n_windows+1] patch offsets of the (non-empty) windows, capacity P/4 + n_images + 1
+ *   merged_src   [P/merge^2]   window-ordered merged token g came from original merged token merged_src[g]
+ */
+int surya_rec_plan_encoder(const surya_rec_config* cfg, const int32_t* grid_hw, int n_images, int32_t* src_row,
+                           int32_t* pos_hw, int32_t* cu_window, int32_t* n_windows, int32_t* merged_src);
+
+/* Prefill n sequences into KV slots (replaces RecognitionPredictor.prefill's model call + cache merge,
+ * recognition/__init__.py:354-471 and cache.py:57-105).
+ *   tiles        device fp32 [P, patch_dim], merge-block-major rows as produced by the processor
+ *                (processor/__init__.py:214-228), images concatenated in sequence order
+ *   grid_hw      host [n_images*2]
+ *   input_ids    host, packed prompt tokens of all sequences (no padding)
+ *   seq_offsets  host [n_seqs+1]
+ *   slot_ids     host [n_seqs] destination slots (distinct, < max_slots)
+ * Image features are scattered to the positions where input_ids == image_token_id, in order
+ * (common/surya/__init__.py:214-225). Afterwards each slot holds its first generated token as next input and
+ * outputs(step 0) hold token / score / bbox for the slots given. Enqueue only. */
+int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, const int32_t* input_ids,
+                      const int32_t* seq_offsets, const int32_t* slot_ids, int n_seqs, void* stream);
+
+/* Set the list of slots that take part in decode steps (host bookkeeping of batch_prompt_mapping,
+ * recognition/__init__.py:125-136). */
+int surya_rec_set_active(surya_rec* h, const int32_t* slots, int n_active, void* stream);
+
+/* Run `n_steps` greedy decode steps for the active slots without host round trips (replaces
+ * RecognitionPredictor.decode + process_outputs, recognition/__init__.py:294-352). Step s writes
+ * outputs(step s). n_steps <= SA_MAX_STEPS. Enqueue only. */
+#define SA_MAX_STEPS 16
+int surya_rec_decode(surya_rec* h, int n_steps, void* stream);
+
+/* Sync the stream and copy the outputs of steps [0, n_steps) to host arrays indexed [step][slot]:
+ *   tokens int32 [n_steps*max_slots], scores fp32 [n_steps*max_slots], bboxes int32 [n_steps*max_slots*6]. */
+int surya_rec_read_outputs(surya_rec* h, int n_steps, int32_t* tokens, float* scores, int32_t* bboxes, void* stream);
+
+/* Test hooks (tolerance tests of intermediate tensors):
+ *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in
+ *                ORIGINAL token order (= get_image_embeddings, common/surya/__init__.py:130-195) to `out`
+ *                (device, compute dtype).
+ *   copy_last_logits: async D2D copy of the fp32 logits [rows, vocab] of the last prefill/decode call into
+ *                `dst` (device, capacity max_rows rows); row r = r-th sequence of the prefill / r-th active slot. */
+int surya_rec_encode_only(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* out, void* stream);
+int surya_rec_copy_last_logits(surya_rec* h, float* dst, int max_rows, int* rows, void* stream);
+/* Force the token fed to the next decode step (teacher forcing in parity tests). */
+int surya_rec_set_next_tokens(surya_rec* h, const int32_t* slots, const int32_t* tokens, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Op-level entry points (unit tests of the kernels through the same library; row-major, compute dtype).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* C[M,N] = X[M,K] W[N,K]^T + bias, epilogue: 0 none/bias, 1 +residual R, 2 gelu, 3 swiglu (W rows interleaved,
+ * C is [M,N/2]), 4 hardswish, 5 relu. out_f32 != 0: C (and R) are fp32 regardless of dtype. */
+int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, const void* W, long ldw, void* C, long ldc,
+                  const void* bias, const void* R, long ldr, int M, int N, int K, void* stream);
+int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURYA_AMD_H */

@@ -1,0 +1,40 @@
+"""Test infrastructure only: makes /root/reference's *model* modules importable in the build container.
+
+Used by oracle/make_golden.py and the optional cross-check tests to run the real reference
+(VikParuchuri/surya @ v0.14.6) on CPU with seeded synthetic weights.  Nothing here is product code and
+nothing here exists on the GPU box (tests that need it skip when /root/reference is absent).
+
+Recipe follows SURVEY.md Appendix A:
+  * stub modules for imports missing from this image (dotenv, pydantic_settings, cv2, filetype, pypdfium2);
+  * transformers 5.x removed ROPE_INIT_FUNCTIONS["default"] (used at surya/common/surya/decoder/__init__.py:333);
+  * SuryaDecoderConfig needs pad_token_id passed explicitly (read at decoder/__init__.py:401);
+  * lm_head/token_embed tying is done by hand by the caller when wanted (common/surya/__init__.py:111-116).
+"""
+import os
+import sys
+
+REFERENCE_ROOT = os.environ.get("SURYA_REFERENCE_ROOT", "/root/reference")
+_STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "surya"))
+
+
+def install():
+    """Put stubs + the reference on sys.path and patch transformers for the reference's needs."""
+    if not available():
+        raise RuntimeError(f"reference not present at {REFERENCE_ROOT}")
+    for p in (REFERENCE_ROOT, _STUBS):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    from transformers import modeling_rope_utils as mru
+
+    def _default_rope(config, device=None, **kw):
+        d = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        inv = 1.0 / (config.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+        return inv, 1.0
+
+    mru.ROPE_INIT_FUNCTIONS.setdefault("default", _default_rope)
+    return True

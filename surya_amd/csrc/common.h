@@ -1,0 +1,98 @@
+// Common device/host helpers for the gfx950 (CDNA4, wave64) kernels of the surya hot path.
+// Written for MI355X only: no CUDA / multi-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/surya_amd.h"
+
+namespace sa {
+
+typedef unsigned short bf16_t;   // storage type for bf16 (bit pattern)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// Status codes (SA_OK, SA_ERR_*) come from the C-ABI header: negative = caller error, positive = hipError_t.
+
+#define SA_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            fprintf(stderr, "[surya_amd] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return (int)_e;                                                                            \
+        }                                                                                              \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;   // v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Ty;
+template <> struct Ty<float> {
+    static constexpr int KE = 32;            // elements per 128-byte K chunk row
+    static constexpr int V16 = 4;            // elements per 16 bytes
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float rnd(float v) { return v; }   // round through storage type
+};
+template <> struct Ty<bf16_t> {
+    static constexpr int KE = 64;
+    static constexpr int V16 = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+// Unpack a 16-byte register chunk into floats (4 for f32, 8 for bf16).
+__device__ __forceinline__ void unpack16(const uint4& v, float (&o)[4], float*) {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+__device__ __forceinline__ void unpack16(const uint4& v, float (&o)[8], bf16_t*) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// Store 4 consecutive outputs.
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2(a, b), pack2(c, d));
+}
+__device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void store2(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack2(a, b); }
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+}  // namespace sa

@@ -1,0 +1,466 @@
+// Non-GEMM kernels of the recognition path (gfx950, wave64). All are HBM/latency-bound:
+// 16-byte vector accesses, wave-shuffle reductions, LDS staging of K/V. Templated on the storage type
+// T (bf16_t or float); arithmetic is fp32.
+#pragma once
+#include "common.h"
+
+namespace sa {
+
+// ---------------------------------------------------------------------------------------------------
+// Patch tiles fp32 [P, kin] -> T [P, kout] (zero padded), rows gathered by src_row (window order), so the
+// reference's `hidden_states[window_index]` gather (encoder/__init__.py:622-627) costs nothing extra.
+template <typename T>
+__global__ void convert_tiles_kernel(const float* __restrict__ in, T* __restrict__ out, const int* __restrict__ src_row,
+                                     int P, int kin, int kout) {
+    const int row = blockIdx.x;
+    const float* src = in + (long)src_row[row] * kin;
+    T* dst = out + (long)row * kout;
+    for (int c = threadIdx.x * 4; c < kout; c += blockDim.x * 4) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (c + r < kin) ? src[c + r] : 0.f;
+        store4(dst + c, v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RMSNorm, Qwen2RMSNorm semantics (encoder/__init__.py:99-104): y = w * T(x * rsqrt(mean(x^2) + eps)).
+// One wave per row; optional row gather (src_row) for "last token only" use.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ w,
+                                                      T* __restrict__ y, long ldy, const int* __restrict__ src_row,
+                                                      int rows, int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* xr = x + (long)(src_row ? src_row[row] : row) * ldx;
+    constexpr int V = Ty<T>::V16;
+    float ss = 0.f;
+    for (int c = lane * V; c < C; c += 64 * V) {
+        float v[V];
+        unpack16(*reinterpret_cast<const uint4*>(xr + c), v, (T*)nullptr);
+#pragma unroll
+        for (int i = 0; i < V; ++i) ss += v[i] * v[i];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    T* yr = y + (long)row * ldy;
+    for (int c = lane * V; c < C; c += 64 * V) {
+        float v[V], g[V];
+        unpack16(*reinterpret_cast<const uint4*>(xr + c), v, (T*)nullptr);
+        unpack16(*reinterpret_cast<const uint4*>(w + c), g, (T*)nullptr);
+#pragma unroll
+        for (int i = 0; i < V; i += 4)
+            store4(yr + c + i, g[i] * Ty<T>::rnd(v[i] * rstd), g[i + 1] * Ty<T>::rnd(v[i + 1] * rstd),
+                   g[i + 2] * Ty<T>::rnd(v[i + 2] * rstd), g[i + 3] * Ty<T>::rnd(v[i + 3] * rstd));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Vision 2-D RoPE in place on the q and k parts of qkv [P, 3*H] (apply_rotary_pos_emb_vision,
+// encoder/__init__.py:188-199). Per patch the angle vector (length D/2) is [pos_h*f | pos_w*f], f = inv_freq[D/4],
+// duplicated to D (:633); rotate_half pairs element i with i + D/2. fp32 math.
+template <typename T>
+__global__ void rope_vision_kernel(T* __restrict__ qkv, const int* __restrict__ pos_hw, const float* __restrict__ inv_freq,
+                                   int P, int H, int heads, int D) {
+    const int p = blockIdx.x;
+    const int half = D / 2, quarter = D / 4;
+    const float ph = (float)pos_hw[2 * p], pw = (float)pos_hw[2 * p + 1];
+    T* base = qkv + (long)p * 3 * H;
+    __shared__ float cs_t[128], sn_t[128];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float ang = (i < quarter) ? ph * inv_freq[i] : pw * inv_freq[i - quarter];
+        sincosf(ang, &sn_t[i], &cs_t[i]);
+    }
+    __syncthreads();
+    // items: (q|k, head, i < half)
+    for (int it = threadIdx.x; it < 2 * heads * half; it += blockDim.x) {
+        const int i = it % half, hh = (it / half) % heads, which = it / (half * heads);
+        const float sn = sn_t[i], cs = cs_t[i];
+        T* v = base + (long)which * H + hh * D;
+        const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
+        Ty<T>::st(v + i, x1 * cs - x2 * sn);
+        Ty<T>::st(v + i + half, x2 * cs + x1 * sn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Segment attention on the vector ALU (first correct version; the score/PV products are ~1 % of the
+// encoder FLOPs). One 256-thread workgroup = 64 queries of one (segment, head); 4 lanes share a query, each
+// owning D/4 of the head dim. K/V stream through LDS in 64-key chunks; online softmax in fp32.
+//   non-causal varlen (vision windows / whole images, encoder/__init__.py:238-261)
+//   causal GQA over the slot KV cache (decoder prefill, decoder/__init__.py:101-128)
+struct AttnSegs {
+    const int* tile_seg;     // [n_tiles] segment of each 64-query tile
+    const int* tile_q0;      // [n_tiles] first query (segment-local) of the tile
+    const int* seg_len;      // [n_seg]
+    const long* q_off;       // [n_seg] element offset of the segment's first query row
+    const long* k_off;       // [n_seg] element offset of the segment's first key row (head 0)
+    const long* v_off;       // [n_seg]
+    const long* o_off;       // [n_seg]
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        T* __restrict__ out, AttnSegs sg, long q_row, long q_head, long k_row,
+                                                        long k_head, long o_row, long o_head, int group, int causal, float scale) {
+    constexpr int DS = D / 4;                 // elements of the head dim per lane
+    constexpr int V = Ty<T>::V16;
+    constexpr int CPR = D / V;                // 16-byte chunks per K/V row
+    constexpr int KC = (D * sizeof(T) >= 512) ? 32 : 64;   // keys per LDS chunk (<= 32 KiB for K+V)
+    __shared__ __attribute__((aligned(16))) T ks[KC * D];
+    __shared__ __attribute__((aligned(16))) T vs[KC * D];
+    const int tile = blockIdx.x, head = blockIdx.y, kvh = head / group;
+    const int seg = sg.tile_seg[tile], q0 = sg.tile_q0[tile], L = sg.seg_len[seg];
+    const int tid = threadIdx.x, ql = tid >> 2, sl = tid & 3;
+    const int qi = q0 + ql;
+    const bool valid = qi < L;
+    float qr[DS], acc[DS];
+    {
+        const T* qp = q + sg.q_off[seg] + (long)min(qi, L - 1) * q_row + (long)head * q_head + sl * DS;
+#pragma unroll
+        for (int i = 0; i < DS; i += 4) {
+            float t4[4];
+            load4(qp + i, t4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qr[i + r] = t4[r] * scale;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DS; ++i) acc[i] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int kend = causal ? min(L, q0 + 64) : L;
+    const T* kbase = k + sg.k_off[seg] + (long)kvh * k_head;
+    const T* vbase = v + sg.v_off[seg] + (long)kvh * k_head;
+    for (int kc = 0; kc < kend; kc += KC) {
+        const int nk = min(KC, kend - kc);
+        for (int c = tid; c < nk * CPR; c += 256) {
+            const int r = c / CPR, cc = c % CPR;
+            *reinterpret_cast<uint4*>(ks + r * D + cc * V) = *reinterpret_cast<const uint4*>(kbase + (long)(kc + r) * k_row + cc * V);
+            *reinterpret_cast<uint4*>(vs + r * D + cc * V) = *reinterpret_cast<const uint4*>(vbase + (long)(kc + r) * k_row + cc * V);
+        }
+        __syncthreads();
+        for (int jb = 0; jb < nk; jb += 16) {
+            float s[16];
+            float bm = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = jb + jj;
+                float d = 0.f;
+                if (j < nk) {
+                    const T* kr = ks + j * D + sl * DS;
+#pragma unroll
+                    for (int i = 0; i < DS; i += 4) {
+                        float t4[4];
+                        load4(kr + i, t4);
+                        d += qr[i] * t4[0] + qr[i + 1] * t4[1] + qr[i + 2] * t4[2] + qr[i + 3] * t4[3];
+                    }
+                }
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                const bool ok = (j < nk) && (!causal || (kc + j) <= qi);
+                s[jj] = ok ? d : -INFINITY;
+                bm = fmaxf(bm, s[jj]);
+            }
+            if (bm == -INFINITY) continue;     // uniform within the 4 lanes of a query; shuffles are above
+            const float mnew = fmaxf(mrun, bm);
+            const float alpha = __expf(mrun - mnew);
+            lrun *= alpha;
+#pragma unroll
+            for (int i = 0; i < DS; ++i) acc[i] *= alpha;
+            mrun = mnew;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = jb + jj;
+                if (j < nk) {                  // wave-uniform bound
+                    const float pj = __expf(s[jj] - mnew);   // exp(-inf) = 0 for masked keys
+                    lrun += pj;
+                    const T* vr = vs + j * D + sl * DS;
+#pragma unroll
+                    for (int i = 0; i < DS; i += 4) {
+                        float t4[4];
+                        load4(vr + i, t4);
+                        acc[i] += pj * t4[0]; acc[i + 1] += pj * t4[1]; acc[i + 2] += pj * t4[2]; acc[i + 3] += pj * t4[3];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        const float inv = 1.0f / lrun;
+        T* op = out + sg.o_off[seg] + (long)qi * o_row + (long)head * o_head + sl * DS;
+#pragma unroll
+        for (int i = 0; i < DS; i += 4) store4(op + i, acc[i] * inv, acc[i + 1] * inv, acc[i + 2] * inv, acc[i + 3] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Merged image tokens (window order) -> decoder input embeddings:
+//   embeds[dst_row[r]] = merged[r] + img_h_embed[hidx[r]] + img_w_embed[widx[r]]
+// = inverse window permutation (encoder/__init__.py:669-670) + 2-D learned position embedding
+// (common/surya/__init__.py:233-272,193) + masked_scatter into the <IMAGE> positions (:214-225).
+// Rounding follows the reference: (h + w) -> T, feature + that -> T.
+template <typename T>
+__global__ void scatter_image_kernel(const T* __restrict__ merged, const T* __restrict__ hemb, const T* __restrict__ wemb,
+                                     const int* __restrict__ dst_row, const int* __restrict__ hidx, const int* __restrict__ widx,
+                                     T* __restrict__ embeds, int H) {
+    const int r = blockIdx.x;
+    const T* src = merged + (long)r * H;
+    const T* he = hemb + (long)hidx[r] * H;
+    const T* we = wemb + (long)widx[r] * H;
+    T* dst = embeds + (long)dst_row[r] * H;
+    for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+        float a[4], b[4], d[4];
+        load4(src + c, a); load4(he + c, b); load4(we + c, d);
+        store4(dst + c, a[0] + Ty<T>::rnd(b[0] + d[0]), a[1] + Ty<T>::rnd(b[1] + d[1]), a[2] + Ty<T>::rnd(b[2] + d[2]),
+               a[3] + Ty<T>::rnd(b[3] + d[3]));
+    }
+}
+
+// Token embedding gather: x[t] = table[ids[t]] (rows with ids[t] < 0 are left untouched: image positions).
+template <typename T>
+__global__ void embed_tokens_kernel(const T* __restrict__ table, const int* __restrict__ ids, T* __restrict__ x, int H) {
+    const int t = blockIdx.x;
+    const int id = ids[t];
+    if (id < 0) return;
+    const uint4* src = reinterpret_cast<const uint4*>(table + (long)id * H);
+    uint4* dst = reinterpret_cast<uint4*>(x + (long)t * H);
+    for (int c = threadIdx.x; c < H / Ty<T>::V16; c += blockDim.x) dst[c] = src[c];
+}
+
+// Decode-step embedding: x[a] = table[next_token[active_slots[a]]].
+template <typename T>
+__global__ void embed_slots_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
+                                   const int* __restrict__ active_slots, T* __restrict__ x, int H) {
+    const int a = blockIdx.x;
+    const int id = next_token[active_slots[a]];
+    const uint4* src = reinterpret_cast<const uint4*>(table + (long)id * H);
+    uint4* dst = reinterpret_cast<uint4*>(x + (long)a * H);
+    for (int c = threadIdx.x; c < H / Ty<T>::V16; c += blockDim.x) dst[c] = src[c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decoder prefill: RoPE on q (in place) and k, append k/v to the slot KV cache.
+// qkv [Ttot, (nq + 2 nkv) * D]; cache layout [slot][kv_head][T_max][D]; cos/sin are rounded to T before use
+// (decoder/__init__.py:361), rotate_half pairing (:53-84).
+template <typename T>
+__global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict__ tok_slot, const int* __restrict__ tok_pos,
+                                      const float* __restrict__ inv_freq, T* __restrict__ kc, T* __restrict__ vc,
+                                      int nq, int nkv, int D, int Tmax) {
+    const int t = blockIdx.x;
+    const int slot = tok_slot[t], pos = tok_pos[t];
+    const int half = D / 2;
+    T* row = qkv + (long)t * (nq + 2 * nkv) * D;
+    const float fpos = (float)pos;
+    for (int it = threadIdx.x; it < (nq + nkv) * half; it += blockDim.x) {
+        const int i = it % half, hh = it / half;           // hh < nq: q head, else k head
+        float sn, cs;
+        sincosf(fpos * inv_freq[i], &sn, &cs);
+        cs = Ty<T>::rnd(cs); sn = Ty<T>::rnd(sn);
+        T* v = row + (long)hh * D;
+        const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
+        const float y1 = x1 * cs - x2 * sn, y2 = x2 * cs + x1 * sn;
+        if (hh < nq) {
+            Ty<T>::st(v + i, y1); Ty<T>::st(v + i + half, y2);
+        } else {
+            T* dst = kc + (((long)slot * nkv + (hh - nq)) * Tmax + pos) * D;
+            Ty<T>::st(dst + i, y1); Ty<T>::st(dst + i + half, y2);
+        }
+    }
+    const T* vsrc = row + (long)(nq + nkv) * D;
+    for (int it = threadIdx.x; it < nkv * D; it += blockDim.x) {
+        const int hh = it / D, i = it % D;
+        vc[(((long)slot * nkv + hh) * Tmax + pos) * D + i] = vsrc[it];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decode step attention, one workgroup per (active slot, kv head): RoPE of the new q/k, KV append and
+// single-query GQA attention over the slot's cache in one launch. 16 lanes share a key (16-byte slices of the
+// head dim, coalesced 256-byte rows for D=128 bf16), 16 keys in flight per workgroup, partial softmax states
+// merged through LDS. Replaces cache concat + 4-D mask + SDPA (decoder/__init__.py:193-234, cache.py:57-105).
+template <typename T, int D, int MAXG>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ kc,
+                                                          T* __restrict__ vc, const int* __restrict__ active_slots,
+                                                          const int* __restrict__ kv_len, const float* __restrict__ inv_freq,
+                                                          int nq, int nkv, int Tmax, float scale) {
+    constexpr int EPL = D / 16;                 // head-dim elements per lane
+    const int G = nq / nkv;
+    const int a = blockIdx.x, kvh = blockIdx.y;
+    const int slot = active_slots[a];
+    const int len = kv_len[slot];               // cached tokens before this step == RoPE position of the new token
+    const int tid = threadIdx.x, kg = tid >> 4, e = tid & 15;
+    __shared__ float qs[MAXG * D];
+    __shared__ float knew[D], vnew[D];
+    __shared__ float mg[4 * MAXG], lg[4 * MAXG];
+    __shared__ float accs[4 * MAXG * D];
+    const T* row = qkv + (long)a * (nq + 2 * nkv) * D;
+    const int half = D / 2;
+    const float fpos = (float)len;
+    for (int it = tid; it < (G + 1) * half; it += 256) {
+        const int i = it % half, hh = it / half;            // hh < G: q head of this group, hh == G: the k head
+        float sn, cs;
+        sincosf(fpos * inv_freq[i], &sn, &cs);
+        cs = Ty<T>::rnd(cs); sn = Ty<T>::rnd(sn);
+        const T* v = (hh < G) ? row + (long)(kvh * G + hh) * D : row + (long)(nq + kvh) * D;
+        const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
+        const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
+        if (hh < G) {
+            qs[hh * D + i] = y1 * scale; qs[hh * D + i + half] = y2 * scale;
+        } else {
+            knew[i] = y1; knew[i + half] = y2;
+            T* dst = kc + (((long)slot * nkv + kvh) * Tmax + len) * D;
+            Ty<T>::st(dst + i, y1); Ty<T>::st(dst + i + half, y2);
+        }
+    }
+    for (int i = tid; i < D; i += 256) {
+        const T val = row[(long)(nq + nkv + kvh) * D + i];
+        vnew[i] = Ty<T>::ld(&val);
+        vc[(((long)slot * nkv + kvh) * Tmax + len) * D + i] = val;
+    }
+    __syncthreads();
+    float qreg[MAXG][EPL], acc[MAXG][EPL], m[MAXG], l[MAXG];
+#pragma unroll
+    for (int h = 0; h < MAXG; ++h) {
+        m[h] = -INFINITY; l[h] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) { acc[h][i] = 0.f; qreg[h][i] = (h < G) ? qs[h * D + e * EPL + i] : 0.f; }
+    }
+    const T* kb = kc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
+    const T* vb = vc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
+    // keys 0..len-1 from the cache, key `len` (the new token) from LDS, handled by the group it falls to
+    for (int j = kg; j <= len; j += 16) {
+        float kf[EPL], vf[EPL];
+        if (j < len) {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) { kf[i] = Ty<T>::ld(kb + (long)j * D + i); vf[i] = Ty<T>::ld(vb + (long)j * D + i); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) { kf[i] = knew[e * EPL + i]; vf[i] = vnew[e * EPL + i]; }
+        }
+#pragma unroll
+        for (int h = 0; h < MAXG; ++h) {
+            if (h < G) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[i];
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                const float mn = fmaxf(m[h], d);
+                const float al = __expf(m[h] - mn), pj = __expf(d - mn);
+                l[h] = l[h] * al + pj;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[i];
+                m[h] = mn;
+            }
+        }
+    }
+    // merge the 4 key groups of each wave with shuffles, then the 4 waves through LDS
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int h = 0; h < MAXG; ++h) {
+        if (h < G) {
+            float mw = fmaxf(m[h], __shfl_xor(m[h], 16, 64));
+            mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+            const float w = (m[h] == -INFINITY) ? 0.f : __expf(m[h] - mw);
+            float lw = l[h] * w;
+            lw += __shfl_xor(lw, 16, 64); lw += __shfl_xor(lw, 32, 64);
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+                float av = acc[h][i] * w;
+                av += __shfl_xor(av, 16, 64); av += __shfl_xor(av, 32, 64);
+                if ((tid & 48) == 0) accs[(wave * MAXG + h) * D + e * EPL + i] = av;
+            }
+            if ((tid & 63) == 0) { mg[wave * MAXG + h] = mw; lg[wave * MAXG + h] = lw; }
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < G * D; it += 256) {
+        const int h = it / D, dd = it % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) M = fmaxf(M, mg[g * MAXG + h]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float mgv = mg[g * MAXG + h];
+            const float w = (mgv == -INFINITY) ? 0.f : __expf(mgv - M);   // waves that saw no key
+            num += w * accs[(g * MAXG + h) * D + dd];
+            den += w * lg[g * MAXG + h];
+        }
+        Ty<T>::st(out + (long)a * nq * D + (long)(kvh * G + h) * D + dd, num / den);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Greedy head (process_outputs, recognition/__init__.py:294-324) on fp32 logits [rows, V]:
+// pred = argmax (first max), score = max softmax prob = 1 / sum(exp(x - max)), done = pred in {eos, pad};
+// bbox = trunc(sigmoid(W_b h + b) * bbox_size) (common/surya/__init__.py:329); updates the slot state for
+// the next step (next input token = pad if done, kv_len += 1).
+template <typename T>
+__global__ __launch_bounds__(256) void greedy_head_kernel(const float* __restrict__ logits, long ldl, int V,
+                                                          const T* __restrict__ hidden, int H, const T* __restrict__ wb,
+                                                          const T* __restrict__ bb, const int* __restrict__ row_slot,
+                                                          int eos_id, int pad_id, float bbox_size, int* __restrict__ out_token,
+                                                          float* __restrict__ out_score, int* __restrict__ out_bbox,
+                                                          int* __restrict__ next_token, int* __restrict__ kv_len, int len_inc) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lr = logits + (long)r * ldl;
+    __shared__ float smax[4], ssum[4];
+    __shared__ int sidx[4];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid * 4; c < V; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(lr + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c + i < V && vv[i] > best) { best = vv[i]; bi = c + i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { smax[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    best = smax[0]; bi = sidx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
+    float se = 0.f;
+    for (int c = tid * 4; c < V; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(lr + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c + i < V) se += expf(vv[i] - best);
+    }
+    se = wave_sum(se);
+    if (lane == 0) ssum[wave] = se;
+    __syncthreads();
+    const int slot = row_slot[r];
+    if (tid == 0) {
+        const float tot = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+        const bool done = (bi == eos_id) || (bi == pad_id);
+        out_token[slot] = bi;
+        out_score[slot] = done ? 0.f : 1.0f / tot;
+        next_token[slot] = done ? pad_id : bi;
+        kv_len[slot] += len_inc;
+    }
+    // bbox head: 6 dot products of length H, one wave each (waves 0..3 take outputs 0..3, then 4..5)
+    const T* hr = hidden + (long)r * H;
+    for (int o = wave; o < 6; o += 4) {
+        float d = 0.f;
+        for (int c = lane; c < H; c += 64) d += Ty<T>::ld(hr + c) * Ty<T>::ld(wb + (long)o * H + c);
+        d = wave_sum(d);
+        if (lane == 0) {
+            const float lin = Ty<T>::rnd(d + Ty<T>::ld(bb + o));
+            const float sg = Ty<T>::rnd(1.0f / (1.0f + expf(-lin)));
+            out_bbox[slot * 6 + o] = (int)(sg * bbox_size);
+        }
+    }
+}
+
+}  // namespace sa

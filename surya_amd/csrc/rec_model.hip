@@ -1,0 +1,689 @@
+// Recognition model on MI355X: host-side planning (window order, segments, slot bookkeeping) + kernel
+// sequencing behind the C ABI of include/surya_amd.h.
+//
+// Design (vs the reference's PyTorch path):
+//   * the packed patch sequence is permuted into window order while it is converted to the compute dtype, so
+//     `hidden_states[window_index]` (encoder/__init__.py:626) never runs as a separate gather;
+//   * prompts are PACKED (no left padding): positions come from per-token (slot, pos), not from a 2-D mask;
+//   * the KV cache is slot based, [layer][slot][kv_head][T_max][d], with a per-slot length on the device:
+//     ContinuousBatchingCache.merge / pad_left / trim_left (recognition/cache.py:8-105) have no equivalent data
+//     movement -- admitting a prompt writes its K/V rows straight into a free slot;
+//   * the greedy head keeps next-token / length state on the device, so n decode steps need no host round trip.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/surya_amd.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------------- staging
+struct Stager {   // pinned host arena mirrored by a device arena; one H2D copy per plan
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t cap = 0, off = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int init(size_t bytes) {
+        cap = bytes;
+        SA_HIP(hipHostMalloc((void**)&host, cap, hipHostMallocDefault));
+        SA_HIP(hipMalloc((void**)&dev, cap));
+        SA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return SA_OK;
+    }
+    void destroy() {
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        if (ev) (void)hipEventDestroy(ev);
+        host = dev = nullptr; ev = nullptr;
+    }
+    void begin() {
+        if (pending) { (void)hipEventSynchronize(ev); pending = false; }
+        off = 0;
+    }
+    template <typename U> U* put(const U* src, size_t n) {   // returns the DEVICE address
+        size_t bytes = n * sizeof(U);
+        size_t o = (off + 255) & ~(size_t)255;
+        if (o + bytes > cap) return nullptr;
+        if (bytes) memcpy(host + o, src, bytes);
+        off = o + bytes;
+        return reinterpret_cast<U*>(dev + o);
+    }
+    template <typename U> U* put(const std::vector<U>& v) { return put(v.data(), v.size()); }
+    int flush(hipStream_t s) {
+        if (off) {
+            SA_HIP(hipMemcpyAsync(dev, host, off, hipMemcpyHostToDevice, s));
+            SA_HIP(hipEventRecord(ev, s));
+            pending = true;
+        }
+        return SA_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------- encoder plan
+struct EncPlan {
+    int P = 0;
+    std::vector<int> src_row, pos_hw, merged_src, hidx, widx;
+    std::vector<int> win_cu, img_cu;            // segment boundaries in patches
+};
+
+// Index math of get_window_index / rot_pos_emb / get_2d_learned_embeddings for images [0, n) of grid_hw.
+static int plan_encoder(const surya_rec_config& c, const int32_t* grid_hw, int n, EncPlan& pl) {
+    const int mg = c.merge, unit = mg * mg, vw = c.window_tokens;
+    pl = EncPlan();
+    pl.win_cu.push_back(0);
+    pl.img_cu.push_back(0);
+    int tok_base = 0;
+    for (int im = 0; im < n; ++im) {
+        const int h = grid_hw[2 * im], w = grid_hw[2 * im + 1];
+        if (h <= 0 || w <= 0 || h % mg || w % mg) return SA_ERR_SHAPE;
+        const int lh = h / mg, lw = w / mg;
+        const int pad_h = vw - lh % vw, pad_w = vw - lw % vw;      // == vw when divisible: one empty window row
+        const int nh = (lh + pad_h) / vw, nw = (lw + pad_w) / vw;
+        for (int wy = 0; wy < nh; ++wy)
+            for (int wx = 0; wx < nw; ++wx) {
+                int cnt = 0;
+                for (int dy = 0; dy < vw; ++dy)
+                    for (int dx = 0; dx < vw; ++dx) {
+                        const int y = wy * vw + dy, x = wx * vw + dx;
+                        if (y >= lh || x >= lw) continue;
+                        const int tok = y * lw + x;
+                        pl.merged_src.push_back(tok_base + tok);
+                        // get_2d_learned_embeddings: (arange(n) / max(1, n-1) * mult).long() in fp32
+                        pl.hidx.push_back((int)(((float)y / (float)std::max(1, lh - 1)) * (float)c.embed_multiplier));
+                        pl.widx.push_back((int)(((float)x / (float)std::max(1, lw - 1)) * (float)c.embed_multiplier));
+                        for (int u = 0; u < unit; ++u) {
+                            pl.src_row.push_back((tok_base + tok) * unit + u);
+                            pl.pos_hw.push_back(y * mg + u / mg);
+                            pl.pos_hw.push_back(x * mg + u % mg);
+                        }
+                        ++cnt;
+                    }
+                if (cnt) pl.win_cu.push_back(pl.win_cu.back() + cnt * unit);   // unique_consecutive drops empties
+            }
+        tok_base += lh * lw;
+        pl.img_cu.push_back(pl.img_cu.back() + h * w);
+    }
+    pl.P = pl.img_cu.back();
+    return SA_OK;
+}
+
+struct SegLists {   // host side of AttnSegs
+    std::vector<int> tile_seg, tile_q0, seg_len;
+    std::vector<long> q_off, k_off, v_off, o_off;
+    void add_tiles(int seg, int L) {
+        for (int q0 = 0; q0 < L; q0 += 64) { tile_seg.push_back(seg); tile_q0.push_back(q0); }
+    }
+};
+
+static AttnSegs stage_segs(Stager& st, const SegLists& s) {
+    AttnSegs a;
+    a.tile_seg = st.put(s.tile_seg); a.tile_q0 = st.put(s.tile_q0); a.seg_len = st.put(s.seg_len);
+    a.q_off = st.put(s.q_off); a.k_off = st.put(s.k_off); a.v_off = st.put(s.v_off); a.o_off = st.put(s.o_off);
+    return a;
+}
+
+__global__ void set_slot_state_kernel(const int* slots, const int* lens, int* kv_len, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) kv_len[slots[i]] = lens[i];
+}
+__global__ void set_next_tokens_kernel(const int* slots, const int* toks, int* next_token, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) next_token[slots[i]] = toks[i];
+}
+
+// --------------------------------------------------------------------------------------------------- model
+struct RecBase {
+    virtual ~RecBase() {}
+    virtual int prefill(const float*, const int32_t*, int, const int32_t*, const int32_t*, const int32_t*, int, hipStream_t) = 0;
+    virtual int set_active(const int32_t*, int, hipStream_t) = 0;
+    virtual int decode(int, hipStream_t) = 0;
+    virtual int read_outputs(int, int32_t*, float*, int32_t*, hipStream_t) = 0;
+    virtual int encode_only(const float*, const int32_t*, int, void*, hipStream_t) = 0;
+    virtual int copy_last_logits(float*, int, int*, hipStream_t) = 0;
+    virtual int set_next_tokens(const int32_t*, const int32_t*, int, hipStream_t) = 0;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+template <typename T>
+struct RecModel : RecBase {
+    surya_rec_config c;
+    std::vector<const void*> w;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    Stager st, st_small;
+    // encoder workspaces
+    T *tiles_t, *ex, *eh, *eqkv, *emlp, *emh, *emerged;
+    // decoder workspaces
+    T *dx, *dh, *dqkv, *dattn, *dmlp, *dlast;
+    float* logits;
+    T *kcache, *vcache;
+    int *kv_len, *next_token, *active_dev;
+    int* out_token; float* out_score; int* out_bbox;     // [SA_MAX_STEPS][max_slots] (bbox x6)
+    char* out_host = nullptr;                            // pinned mirror of the three output arrays
+    size_t out_bytes = 0;
+    int n_active = 0;
+    int last_rows = 0;
+
+    const T* W(int idx) const { return reinterpret_cast<const T*>(w[idx]); }
+    const T* WE(int l, int k) const { return W(SA_RW_ENC(l, k)); }
+    const T* WD(int l, int k) const { return W(SA_RW_DEC(c.enc_depth, l, k)); }
+
+    static size_t layout(const surya_rec_config& c, RecModel* m) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+        const size_t Pm = c.max_patches, Tm = std::max(c.max_prefill_tokens, c.max_slots), S = c.max_slots;
+        const int unit = c.merge * c.merge;
+        const size_t qkv_d = (size_t)(c.dec_heads + 2 * c.dec_kv_heads) * c.dec_head_dim;
+        size_t o_tiles = take(Pm * c.patch_dim_pad * sizeof(T));
+        size_t o_ex = take(Pm * c.enc_hidden * sizeof(T));
+        size_t o_eh = take(Pm * c.enc_hidden * sizeof(T));
+        size_t o_eqkv = take(Pm * 3 * c.enc_hidden * sizeof(T));
+        size_t o_emlp = take(Pm * c.enc_inter_pad * sizeof(T));
+        size_t o_emh = take(Pm * c.enc_hidden * sizeof(T));                 // [P/unit, unit*He]
+        size_t o_emerged = take(Pm / unit * c.enc_out_hidden * sizeof(T));
+        size_t o_dx = take(Tm * c.dec_hidden * sizeof(T));
+        size_t o_dh = take(Tm * c.dec_hidden * sizeof(T));
+        size_t o_dqkv = take(Tm * qkv_d * sizeof(T));
+        size_t o_dattn = take(Tm * c.dec_heads * c.dec_head_dim * sizeof(T));
+        size_t o_dmlp = take(Tm * c.dec_inter * sizeof(T));
+        size_t o_dlast = take(S * c.dec_hidden * sizeof(T));
+        size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
+        const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
+        size_t o_k = take(kv_elems * sizeof(T));
+        size_t o_v = take(kv_elems * sizeof(T));
+        size_t o_kvlen = take(S * sizeof(int));
+        size_t o_next = take(S * sizeof(int));
+        size_t o_active = take(S * sizeof(int));
+        size_t o_out = take((size_t)SA_MAX_STEPS * S * 8 * sizeof(int));
+        if (m) {
+            char* b = m->arena;
+            m->tiles_t = (T*)(b + o_tiles); m->ex = (T*)(b + o_ex); m->eh = (T*)(b + o_eh); m->eqkv = (T*)(b + o_eqkv);
+            m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
+            m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
+            m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits);
+            m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
+            m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active);
+            m->out_token = (int*)(b + o_out);
+            m->out_score = (float*)(m->out_token + (size_t)SA_MAX_STEPS * S);
+            m->out_bbox = (int*)(m->out_score + (size_t)SA_MAX_STEPS * S);
+            m->out_bytes = (size_t)SA_MAX_STEPS * S * 8 * sizeof(int);
+        }
+        return off;
+    }
+
+    int init(const surya_rec_config& cfg, const void* const* weights, int n) {
+        c = cfg;
+        w.assign(weights, weights + n);
+        arena_bytes = layout(c, nullptr);
+        SA_HIP(hipMalloc((void**)&arena, arena_bytes));
+        layout(c, this);
+        SA_HIP(hipMemset(kv_len, 0, c.max_slots * sizeof(int)));
+        SA_HIP(hipMemset(next_token, 0, c.max_slots * sizeof(int)));
+        SA_HIP(hipMemset(out_token, 0, out_bytes));
+        SA_HIP(hipHostMalloc((void**)&out_host, out_bytes, hipHostMallocDefault));
+        const size_t Pm = c.max_patches, Tm = std::max(c.max_prefill_tokens, c.max_slots);
+        int rc = st.init((Pm * 8 + Tm * 8 + (size_t)c.max_slots * 64) * sizeof(int) + (1 << 20));
+        if (rc) return rc;
+        rc = st_small.init((size_t)c.max_slots * 4 * sizeof(int) + 4096);
+        if (rc) return rc;
+        SA_HIP(hipDeviceSynchronize());
+        return SA_OK;
+    }
+    ~RecModel() override {
+        st.destroy(); st_small.destroy();
+        if (arena) (void)hipFree(arena);
+        if (out_host) (void)hipHostFree(out_host);
+    }
+
+    // ------------------------------------------------------------------------------------------ helpers
+    template <int EPI>
+    int gemm(const T* X, long ldx, const T* Wt, long ldw, T* C, long ldc, const T* bias, const T* R, long ldr, int M, int N,
+             int K, hipStream_t s) {
+        GemmArgs<T, T> a{X, ldx, Wt, ldw, C, ldc, bias, R, ldr, M, N, K};
+        return launch_gemm<T, T, EPI>(a, s);
+    }
+    int rmsnorm(const T* x, long ldx, const T* wt, T* y, long ldy, const int* src_row, int rows, int C, float eps, hipStream_t s) {
+        if (rows <= 0) return SA_OK;
+        hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, wt, y, ldy, src_row, rows, C, eps);
+        return (int)hipGetLastError();
+    }
+    int attention(int D, const T* q, const T* k, const T* v, T* o, const AttnSegs& sg, int n_tiles, int heads, long q_row,
+                  long q_head, long k_row, long k_head, long o_row, long o_head, int group, int causal, float scale,
+                  hipStream_t s) {
+        if (n_tiles <= 0) return SA_OK;
+        dim3 grid(n_tiles, heads), block(256);
+#define SA_ATTN(DD)                                                                                                    \
+    hipLaunchKernelGGL((attn_valu_kernel<T, DD>), grid, block, 0, s, q, k, v, o, sg, q_row, q_head, k_row, k_head, o_row, \
+                       o_head, group, causal, scale)
+        switch (D) {
+            case 32: SA_ATTN(32); break;
+            case 64: SA_ATTN(64); break;
+            case 80: SA_ATTN(80); break;
+            case 128: SA_ATTN(128); break;
+            default: return SA_ERR_UNSUPPORTED;
+        }
+#undef SA_ATTN
+        return (int)hipGetLastError();
+    }
+
+    // Vision encoder for images [0, n) whose tiles start at `tiles`; merged tokens (original order index g)
+    // are written to dst + dst_rows[g] * dec_hidden. Chunks on image boundaries when P exceeds max_patches.
+    int encode(const float* tiles, const int32_t* grid_hw, int n, const std::vector<int>& dst_rows, T* dst, hipStream_t s) {
+        const int unit = c.merge * c.merge, He = c.enc_hidden, D = He / c.enc_heads;
+        int i0 = 0;
+        long patch_base = 0, tok_base = 0;
+        while (i0 < n) {
+            int i1 = i0;
+            long P = 0;
+            while (i1 < n) {
+                const long p = (long)grid_hw[2 * i1] * grid_hw[2 * i1 + 1];
+                if (p > c.max_patches) return SA_ERR_SHAPE;
+                if (P + p > c.max_patches) break;
+                P += p; ++i1;
+            }
+            EncPlan pl;
+            int rc = plan_encoder(c, grid_hw + 2 * i0, i1 - i0, pl);
+            if (rc) return rc;
+            SegLists win, full;
+            for (size_t sgi = 0; sgi + 1 < pl.win_cu.size(); ++sgi) {
+                const int a = pl.win_cu[sgi], L = pl.win_cu[sgi + 1] - a;
+                win.seg_len.push_back(L);
+                win.q_off.push_back((long)a * 3 * He); win.k_off.push_back((long)a * 3 * He + He);
+                win.v_off.push_back((long)a * 3 * He + 2 * He); win.o_off.push_back((long)a * He);
+                win.add_tiles((int)sgi, L);
+            }
+            for (size_t sgi = 0; sgi + 1 < pl.img_cu.size(); ++sgi) {
+                const int a = pl.img_cu[sgi], L = pl.img_cu[sgi + 1] - a;
+                full.seg_len.push_back(L);
+                full.q_off.push_back((long)a * 3 * He); full.k_off.push_back((long)a * 3 * He + He);
+                full.v_off.push_back((long)a * 3 * He + 2 * He); full.o_off.push_back((long)a * He);
+                full.add_tiles((int)sgi, L);
+            }
+            std::vector<int> dst_row(pl.merged_src.size());
+            for (size_t g = 0; g < dst_row.size(); ++g) dst_row[g] = dst_rows[tok_base + pl.merged_src[g]];
+            st.begin();
+            const int* d_src_row = st.put(pl.src_row);
+            const int* d_pos = st.put(pl.pos_hw);
+            const int* d_dst = st.put(dst_row);
+            const int* d_hidx = st.put(pl.hidx);
+            const int* d_widx = st.put(pl.widx);
+            AttnSegs d_win = stage_segs(st, win), d_full = stage_segs(st, full);
+            if (!d_full.o_off) return SA_ERR_NOMEM;
+            rc = st.flush(s);
+            if (rc) return rc;
+
+            const int Pi = (int)P;
+            hipLaunchKernelGGL(convert_tiles_kernel<T>, dim3(Pi), dim3(64), 0, s, tiles + patch_base * c.patch_dim, tiles_t,
+                               d_src_row, Pi, c.patch_dim, c.patch_dim_pad);
+            if ((rc = gemm<EPI_BIAS>(tiles_t, c.patch_dim_pad, W(SA_RW_PATCH), c.patch_dim_pad, ex, He, nullptr, nullptr, 0, Pi,
+                                     He, c.patch_dim_pad, s))) return rc;
+            const float scale = 1.0f / sqrtf((float)D);
+            for (int l = 0; l < c.enc_depth; ++l) {
+                if ((rc = rmsnorm(ex, He, WE(l, SA_RE_NORM1), eh, He, nullptr, Pi, He, c.enc_eps, s))) return rc;
+                if ((rc = gemm<EPI_BIAS>(eh, He, WE(l, SA_RE_QKV_W), He, eqkv, 3 * He, WE(l, SA_RE_QKV_B), nullptr, 0, Pi,
+                                         3 * He, He, s))) return rc;
+                hipLaunchKernelGGL(rope_vision_kernel<T>, dim3(Pi), dim3(256), 0, s, eqkv, d_pos,
+                                   reinterpret_cast<const float*>(w[SA_RW_ENC_INVFREQ]), Pi, He, c.enc_heads, D);
+                const bool fullatt = (c.fullatt_mask >> l) & 1u;
+                const AttnSegs& sg = fullatt ? d_full : d_win;
+                const int nt = (int)(fullatt ? full.tile_seg.size() : win.tile_seg.size());
+                if ((rc = attention(D, eqkv, eqkv, eqkv, eh, sg, nt, c.enc_heads, 3 * He, D, 3 * He, D, He, D, 1, 0, scale, s)))
+                    return rc;
+                if ((rc = gemm<EPI_RESIDUAL>(eh, He, WE(l, SA_RE_PROJ_W), He, ex, He, WE(l, SA_RE_PROJ_B), ex, He, Pi, He, He, s)))
+                    return rc;
+                if ((rc = rmsnorm(ex, He, WE(l, SA_RE_NORM2), eh, He, nullptr, Pi, He, c.enc_eps, s))) return rc;
+                if ((rc = gemm<EPI_SWIGLU>(eh, He, WE(l, SA_RE_GU_W), He, emlp, c.enc_inter_pad, WE(l, SA_RE_GU_B), nullptr, 0,
+                                           Pi, 2 * c.enc_inter_pad, He, s))) return rc;
+                if ((rc = gemm<EPI_RESIDUAL>(emlp, c.enc_inter_pad, WE(l, SA_RE_DOWN_W), c.enc_inter_pad, ex, He,
+                                             WE(l, SA_RE_DOWN_B), ex, He, Pi, He, c.enc_inter_pad, s))) return rc;
+            }
+            // merger: ln_q eps is fixed 1e-6 in the reference (encoder/__init__.py:114)
+            if ((rc = rmsnorm(ex, He, W(SA_RW_MERGER_LN), eh, He, nullptr, Pi, He, 1e-6f, s))) return rc;
+            const int Mg = Pi / unit, Hm = He * unit;
+            if ((rc = gemm<EPI_GELU>(eh, Hm, W(SA_RW_FC1_W), Hm, emh, Hm, W(SA_RW_FC1_B), nullptr, 0, Mg, Hm, Hm, s))) return rc;
+            if ((rc = gemm<EPI_BIAS>(emh, Hm, W(SA_RW_FC2_W), Hm, emerged, c.enc_out_hidden, W(SA_RW_FC2_B), nullptr, 0, Mg,
+                                     c.enc_out_hidden, Hm, s))) return rc;
+            hipLaunchKernelGGL(scatter_image_kernel<T>, dim3(Mg), dim3(128), 0, s, emerged, W(SA_RW_IMG_H), W(SA_RW_IMG_W), d_dst,
+                               d_hidx, d_widx, dst, c.dec_hidden);
+            if ((rc = (int)hipGetLastError())) return rc;
+            patch_base += P;
+            tok_base += P / unit;
+            i0 = i1;
+        }
+        return SA_OK;
+    }
+
+    int encode_only(const float* tiles, const int32_t* grid_hw, int n, void* out, hipStream_t s) override {
+        if (c.enc_out_hidden != c.dec_hidden) return SA_ERR_SHAPE;
+        long ntok = 0;
+        for (int i = 0; i < n; ++i) ntok += (long)grid_hw[2 * i] * grid_hw[2 * i + 1] / (c.merge * c.merge);
+        std::vector<int> ident(ntok);
+        for (long i = 0; i < ntok; ++i) ident[i] = (int)i;
+        return encode(tiles, grid_hw, n, ident, reinterpret_cast<T*>(out), s);
+    }
+
+    // ------------------------------------------------------------------------------------------ decoder
+    int decoder_layers(int M, bool is_prefill, const int* d_tok_slot, const int* d_tok_pos, const AttnSegs* sg, int n_tiles,
+                       hipStream_t s) {
+        const int Hd = c.dec_hidden, nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim, I = c.dec_inter;
+        const int qkv_d = (nq + 2 * nkv) * d;
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t layer_kv = (size_t)c.max_slots * nkv * c.max_kv_len * d;
+        const float* inv_freq = reinterpret_cast<const float*>(w[SA_RW_DEC_INVFREQ]);
+        int rc;
+        for (int l = 0; l < c.dec_layers; ++l) {
+            T* kc = kcache + l * layer_kv;
+            T* vc = vcache + l * layer_kv;
+            if ((rc = rmsnorm(dx, Hd, WD(l, SA_RD_LN1), dh, Hd, nullptr, M, Hd, c.dec_eps, s))) return rc;
+            if ((rc = gemm<EPI_BIAS>(dh, Hd, WD(l, SA_RD_QKV_W), Hd, dqkv, qkv_d, WD(l, SA_RD_QKV_B), nullptr, 0, M, qkv_d, Hd, s)))
+                return rc;
+            if (is_prefill) {
+                hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, inv_freq, kc,
+                                   vc, nq, nkv, d, c.max_kv_len);
+                if ((rc = attention(d, dqkv, kc, vc, dattn, *sg, n_tiles, nq, qkv_d, d, d, (long)c.max_kv_len * d, (long)nq * d,
+                                    d, nq / nkv, 1, scale, s))) return rc;
+            } else {
+                dim3 grid(M, nkv), block(256);
+#define SA_DEC(DD)                                                                                                      \
+    hipLaunchKernelGGL((decode_attn_kernel<T, DD, 8>), grid, block, 0, s, dqkv, dattn, kc, vc, active_dev, kv_len, inv_freq, \
+                       nq, nkv, c.max_kv_len, scale)
+                switch (d) {
+                    case 32: SA_DEC(32); break;
+                    case 64: SA_DEC(64); break;
+                    case 128: SA_DEC(128); break;
+                    default: return SA_ERR_UNSUPPORTED;
+                }
+#undef SA_DEC
+                if ((rc = (int)hipGetLastError())) return rc;
+            }
+            if ((rc = gemm<EPI_RESIDUAL>(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, dx, Hd, nullptr, dx, Hd, M, Hd, nq * d,
+                                         s))) return rc;
+            if ((rc = rmsnorm(dx, Hd, WD(l, SA_RD_LN2), dh, Hd, nullptr, M, Hd, c.dec_eps, s))) return rc;
+            if ((rc = gemm<EPI_SWIGLU>(dh, Hd, WD(l, SA_RD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
+            if ((rc = gemm<EPI_RESIDUAL>(dmlp, I, WD(l, SA_RD_DOWN_W), I, dx, Hd, nullptr, dx, Hd, M, Hd, I, s))) return rc;
+        }
+        return SA_OK;
+    }
+
+    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, hipStream_t s) {
+        const int Hd = c.dec_hidden;
+        int rc;
+        if ((rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), dlast, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
+        GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
+        if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
+        const size_t so = (size_t)step * c.max_slots;
+        hipLaunchKernelGGL(greedy_head_kernel<T>, dim3(rows), dim3(256), 0, s, logits, (long)c.vocab, c.vocab, dlast, Hd,
+                           W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id, c.pad_token_id, (float)c.bbox_size,
+                           out_token + so, out_score + so, out_bbox + so * 6, next_token, kv_len, len_inc);
+        last_rows = rows;
+        return (int)hipGetLastError();
+    }
+
+    int prefill(const float* tiles, const int32_t* grid_hw, int n_images, const int32_t* input_ids, const int32_t* seq_offsets,
+                const int32_t* slot_ids, int n_seqs, hipStream_t s) override {
+        if (n_seqs <= 0) return SA_OK;
+        if (n_seqs > c.max_slots) return SA_ERR_ARG;
+        const int Ttot = seq_offsets[n_seqs];
+        if (Ttot > c.max_prefill_tokens) return SA_ERR_SHAPE;
+        const int nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim;
+        std::vector<int> ids(Ttot), tok_slot(Ttot), tok_pos(Ttot), lens(n_seqs), last_row(n_seqs), img_pos;
+        SegLists sg;
+        for (int i = 0; i < n_seqs; ++i) {
+            const int a = seq_offsets[i], L = seq_offsets[i + 1] - a;
+            if (L <= 0 || L >= c.max_kv_len || slot_ids[i] < 0 || slot_ids[i] >= c.max_slots) return SA_ERR_ARG;
+            lens[i] = L; last_row[i] = a + L - 1;
+            for (int t = 0; t < L; ++t) {
+                const int id = input_ids[a + t];
+                if (id < 0 || id >= c.vocab) return SA_ERR_ARG;
+                const bool img = (id == c.image_token_id);
+                ids[a + t] = img ? -1 : id;
+                if (img) img_pos.push_back(a + t);
+                tok_slot[a + t] = slot_ids[i]; tok_pos[a + t] = t;
+            }
+            sg.seg_len.push_back(L);
+            sg.q_off.push_back((long)a * (nq + 2 * nkv) * d);
+            sg.k_off.push_back((long)slot_ids[i] * nkv * c.max_kv_len * d);
+            sg.v_off.push_back((long)slot_ids[i] * nkv * c.max_kv_len * d);
+            sg.o_off.push_back((long)a * nq * d);
+            sg.add_tiles(i, L);
+        }
+        long ntok = 0;
+        for (int i = 0; i < n_images; ++i) ntok += (long)grid_hw[2 * i] * grid_hw[2 * i + 1] / (c.merge * c.merge);
+        if ((long)img_pos.size() != ntok) return SA_ERR_SHAPE;   // reference only warns (common/surya/__init__.py:216-221)
+        int rc;
+        // small plan first (its own stager: the encoder re-stages per chunk)
+        st_small.begin();
+        const int* d_slots = st_small.put(slot_ids, n_seqs);
+        const int* d_lens = st_small.put(lens);
+        const int* d_last = st_small.put(last_row);
+        if (!d_last) return SA_ERR_NOMEM;
+        if ((rc = st_small.flush(s))) return rc;
+        // token embeddings for non-image positions
+        {
+            st.begin();
+            const int* d_ids = st.put(ids);
+            if (!d_ids) return SA_ERR_NOMEM;
+            if ((rc = st.flush(s))) return rc;
+            hipLaunchKernelGGL(embed_tokens_kernel<T>, dim3(Ttot), dim3(128), 0, s, W(SA_RW_TOK_EMBED), d_ids, dx, c.dec_hidden);
+        }
+        if (n_images > 0 && (rc = encode(tiles, grid_hw, n_images, img_pos, dx, s))) return rc;
+        st.begin();
+        const int* d_tok_slot = st.put(tok_slot);
+        const int* d_tok_pos = st.put(tok_pos);
+        AttnSegs d_sg = stage_segs(st, sg);
+        if (!d_sg.o_off) return SA_ERR_NOMEM;
+        if ((rc = st.flush(s))) return rc;
+        hipLaunchKernelGGL(set_slot_state_kernel, dim3(cdiv(n_seqs, 256)), dim3(256), 0, s, d_slots, d_lens, kv_len, n_seqs);
+        if ((rc = decoder_layers(Ttot, true, d_tok_slot, d_tok_pos, &d_sg, (int)sg.tile_seg.size(), s))) return rc;
+        return heads(n_seqs, d_last, d_slots, 0, 0, s);
+    }
+
+    int set_active(const int32_t* slots, int n, hipStream_t s) override {
+        if (n < 0 || n > c.max_slots) return SA_ERR_ARG;
+        n_active = n;
+        if (n == 0) return SA_OK;
+        st_small.begin();
+        const int* d = st_small.put(slots, n);
+        if (!d) return SA_ERR_NOMEM;
+        int rc = st_small.flush(s);
+        if (rc) return rc;
+        SA_HIP(hipMemcpyAsync(active_dev, d, n * sizeof(int), hipMemcpyDeviceToDevice, s));
+        return SA_OK;
+    }
+
+    int decode(int n_steps, hipStream_t s) override {
+        if (n_steps < 0 || n_steps > SA_MAX_STEPS) return SA_ERR_ARG;
+        const int M = n_active;
+        if (M == 0) return SA_OK;
+        int rc;
+        for (int step = 0; step < n_steps; ++step) {
+            hipLaunchKernelGGL(embed_slots_kernel<T>, dim3(M), dim3(128), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, dx,
+                               c.dec_hidden);
+            if ((rc = decoder_layers(M, false, nullptr, nullptr, nullptr, 0, s))) return rc;
+            if ((rc = heads(M, nullptr, active_dev, step, 1, s))) return rc;
+        }
+        return SA_OK;
+    }
+
+    int read_outputs(int n_steps, int32_t* tokens, float* scores, int32_t* bboxes, hipStream_t s) override {
+        if (n_steps <= 0 || n_steps > SA_MAX_STEPS) return SA_ERR_ARG;
+        const size_t S = c.max_slots, full = (size_t)SA_MAX_STEPS * S;
+        const size_t nt = (size_t)n_steps * S;
+        SA_HIP(hipMemcpyAsync(out_host, out_token, nt * sizeof(int), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(out_host + full * 4, out_score, nt * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(out_host + full * 8, out_bbox, nt * 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipStreamSynchronize(s));
+        memcpy(tokens, out_host, nt * sizeof(int));
+        memcpy(scores, out_host + full * 4, nt * sizeof(float));
+        memcpy(bboxes, out_host + full * 8, nt * 6 * sizeof(int));
+        return SA_OK;
+    }
+
+    int copy_last_logits(float* dst, int max_rows, int* rows, hipStream_t s) override {
+        const int r = std::min(max_rows, last_rows);
+        *rows = r;
+        if (r > 0) SA_HIP(hipMemcpyAsync(dst, logits, (size_t)r * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return SA_OK;
+    }
+
+    int set_next_tokens(const int32_t* slots, const int32_t* toks, int n, hipStream_t s) override {
+        if (n <= 0) return SA_OK;
+        st_small.begin();
+        const int* ds = st_small.put(slots, n);
+        const int* dt = st_small.put(toks, n);
+        if (!dt) return SA_ERR_NOMEM;
+        int rc = st_small.flush(s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(set_next_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ds, dt, next_token, n);
+        return (int)hipGetLastError();
+    }
+};
+
+static int check_cfg(const surya_rec_config* c) {
+    if (!c) return SA_ERR_ARG;
+    if (c->dtype != SA_DTYPE_F32 && c->dtype != SA_DTYPE_BF16) return SA_ERR_UNSUPPORTED;
+    if (c->enc_hidden % 64 || c->enc_inter_pad % 64 || c->patch_dim_pad % 64 || c->dec_hidden % 64 || c->dec_inter % 64 ||
+        (c->dec_heads * c->dec_head_dim) % 64 || c->vocab % 4)
+        return SA_ERR_SHAPE;
+    if (c->enc_hidden % c->enc_heads || c->dec_heads % c->dec_kv_heads || c->dec_heads / c->dec_kv_heads > 8) return SA_ERR_SHAPE;
+    if (c->merge != 2 || c->window_tokens <= 0 || c->enc_depth > 32) return SA_ERR_UNSUPPORTED;
+    if (c->max_slots <= 0 || c->max_kv_len <= 0 || c->max_patches < 4 || c->max_prefill_tokens <= 0) return SA_ERR_ARG;
+    return SA_OK;
+}
+
+}  // namespace sa
+
+using namespace sa;
+struct surya_rec { std::unique_ptr<RecBase> impl; surya_rec_config cfg; };
+
+// ------------------------------------------------------------------------------------------------ op level
+template <typename TI, typename TO>
+static int op_gemm_t(int epi, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, const void* bias, const void* R,
+                     long ldr, int M, int N, int K, hipStream_t s) {
+    GemmArgs<TI, TO> a{(const TI*)X, ldx, (const TI*)W, ldw, (TO*)C, ldc, (const TI*)bias, (const TO*)R, ldr, M, N, K};
+    switch (epi) {
+        case EPI_BIAS: return launch_gemm<TI, TO, EPI_BIAS>(a, s);
+        case EPI_RESIDUAL: return R ? launch_gemm<TI, TO, EPI_RESIDUAL>(a, s) : SA_ERR_ARG;
+        case EPI_GELU: return launch_gemm<TI, TO, EPI_GELU>(a, s);
+        case EPI_SWIGLU: return launch_gemm<TI, TO, EPI_SWIGLU>(a, s);
+        case EPI_HARDSWISH: return launch_gemm<TI, TO, EPI_HARDSWISH>(a, s);
+        case EPI_RELU: return launch_gemm<TI, TO, EPI_RELU>(a, s);
+    }
+    return SA_ERR_ARG;
+}
+
+
+extern "C" {
+
+const char* surya_amd_version(void) { return "surya_amd 0.1.0 gfx950"; }
+
+size_t surya_rec_workspace_bytes(const surya_rec_config* cfg) {
+    if (check_cfg(cfg)) return 0;
+    return cfg->dtype == SA_DTYPE_F32 ? RecModel<float>::layout(*cfg, nullptr) : RecModel<bf16_t>::layout(*cfg, nullptr);
+}
+
+int surya_rec_create(const surya_rec_config* cfg, const void* const* weights, int n_weights, surya_rec** out) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!weights || !out || n_weights != SA_RW_TOTAL(cfg->enc_depth, cfg->dec_layers)) return SA_ERR_ARG;
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) return SA_ERR_ARG;
+    auto* h = new surya_rec();
+    h->cfg = *cfg;
+    if (cfg->dtype == SA_DTYPE_F32) {
+        auto m = std::make_unique<RecModel<float>>();
+        rc = m->init(*cfg, weights, n_weights);
+        h->impl = std::move(m);
+    } else {
+        auto m = std::make_unique<RecModel<bf16_t>>();
+        rc = m->init(*cfg, weights, n_weights);
+        h->impl = std::move(m);
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return SA_OK;
+}
+
+int surya_rec_destroy(surya_rec* h) {
+    if (!h) return SA_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    delete h;
+    return SA_OK;
+}
+
+int surya_rec_plan_encoder(const surya_rec_config* cfg, const int32_t* grid_hw, int n_images, int32_t* src_row, int32_t* pos_hw,
+                           int32_t* cu_window, int32_t* n_windows, int32_t* merged_src) {
+    if (!cfg || !grid_hw || n_images <= 0) return SA_ERR_ARG;
+    EncPlan pl;
+    int rc = plan_encoder(*cfg, grid_hw, n_images, pl);
+    if (rc) return rc;
+    if (src_row) memcpy(src_row, pl.src_row.data(), pl.src_row.size() * sizeof(int));
+    if (pos_hw) memcpy(pos_hw, pl.pos_hw.data(), pl.pos_hw.size() * sizeof(int));
+    if (cu_window) memcpy(cu_window, pl.win_cu.data(), pl.win_cu.size() * sizeof(int));
+    if (n_windows) *n_windows = (int)pl.win_cu.size() - 1;
+    if (merged_src) memcpy(merged_src, pl.merged_src.data(), pl.merged_src.size() * sizeof(int));
+    return SA_OK;
+}
+
+int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, const int32_t* input_ids,
+                      const int32_t* seq_offsets, const int32_t* slot_ids, int n_seqs, void* stream) {
+    if (!h || !input_ids || !seq_offsets || !slot_ids || (n_images > 0 && (!tiles || !grid_hw))) return SA_ERR_ARG;
+    return h->impl->prefill(tiles, grid_hw, n_images, input_ids, seq_offsets, slot_ids, n_seqs, (hipStream_t)stream);
+}
+int surya_rec_set_active(surya_rec* h, const int32_t* slots, int n_active, void* stream) {
+    if (!h || (n_active > 0 && !slots)) return SA_ERR_ARG;
+    return h->impl->set_active(slots, n_active, (hipStream_t)stream);
+}
+int surya_rec_decode(surya_rec* h, int n_steps, void* stream) {
+    if (!h) return SA_ERR_ARG;
+    return h->impl->decode(n_steps, (hipStream_t)stream);
+}
+int surya_rec_read_outputs(surya_rec* h, int n_steps, int32_t* tokens, float* scores, int32_t* bboxes, void* stream) {
+    if (!h || !tokens || !scores || !bboxes) return SA_ERR_ARG;
+    return h->impl->read_outputs(n_steps, tokens, scores, bboxes, (hipStream_t)stream);
+}
+int surya_rec_encode_only(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* out, void* stream) {
+    if (!h || !tiles || !grid_hw || !out || n_images <= 0) return SA_ERR_ARG;
+    return h->impl->encode_only(tiles, grid_hw, n_images, out, (hipStream_t)stream);
+}
+int surya_rec_copy_last_logits(surya_rec* h, float* dst, int max_rows, int* rows, void* stream) {
+    if (!h || !dst || !rows || max_rows <= 0) return SA_ERR_ARG;
+    return h->impl->copy_last_logits(dst, max_rows, rows, (hipStream_t)stream);
+}
+int surya_rec_set_next_tokens(surya_rec* h, const int32_t* slots, const int32_t* tokens, int n, void* stream) {
+    if (!h || !slots || !tokens) return SA_ERR_ARG;
+    return h->impl->set_next_tokens(slots, tokens, n, (hipStream_t)stream);
+}
+
+int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, const void* W, long ldw, void* C, long ldc,
+                  const void* bias, const void* R, long ldr, int M, int N, int K, void* stream) {
+    if (!X || !W || !C) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SA_DTYPE_F32) return op_gemm_t<float, float>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s);
+    if (dtype == SA_DTYPE_BF16)
+        return out_f32 ? op_gemm_t<bf16_t, float>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s)
+                       : op_gemm_t<bf16_t, bf16_t>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s);
+    return SA_ERR_UNSUPPORTED;
+}
+
+int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
+                     void* stream) {
+    if (!x || !w || !y || rows <= 0) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SA_DTYPE_F32)
+        hipLaunchKernelGGL(rmsnorm_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const float*)x, ldx, (const float*)w,
+                           (float*)y, ldy, (const int*)nullptr, rows, C, eps);
+    else if (dtype == SA_DTYPE_BF16)
+        hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)w,
+                           (bf16_t*)y, ldy, (const int*)nullptr, rows, C, eps);
+    else
+        return SA_ERR_UNSUPPORTED;
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+"""Seeded synthetic weights and inputs (no checkpoints or datasets exist offline).
+
+State-dict keys are the reference's own parameter names (``SuryaModel.state_dict()`` /
+``EfficientViTForSemanticSegmentation.state_dict()``) so a real safetensors checkpoint can be dropped in.
+
+Init recipes are the probe-verified ones from SURVEY.md 8(d): HF-style N(0, 0.02) makes the tied-embedding
+recogniser repeat its last token and the detector emit a constant 0.5 map, so neither would exercise parity.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .config import RecConfig, DetConfig
+
+
+def _normal(gen, shape, std):
+    return torch.randn(shape, generator=gen, dtype=torch.float32) * std
+
+
+def make_rec_weights(cfg: RecConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """fp32 CPU state dict for SuryaModel (surya/common/surya/__init__.py:71-109 lists the sub-modules)."""
+    g = torch.Generator().manual_seed(seed)
+    e, d = cfg.encoder, cfg.decoder
+    sd: Dict[str, torch.Tensor] = {}
+    He, Hd = e.hidden_size, d.hidden_size
+    se, sdd = 1.7 / math.sqrt(He), 1.7 / math.sqrt(Hd)
+    sd["vision_encoder.patch_embed.proj.weight"] = _normal(
+        g, (He, e.in_channels, e.temporal_patch_size, e.patch_size, e.patch_size), 1.7 / math.sqrt(e.patch_dim))
+    for i in range(e.depth):
+        p = f"vision_encoder.blocks.{i}."
+        sd[p + "norm1.weight"] = torch.ones(He)
+        sd[p + "norm2.weight"] = torch.ones(He)
+        sd[p + "attn.qkv.weight"] = _normal(g, (3 * He, He), se)
+        sd[p + "attn.qkv.bias"] = _normal(g, (3 * He,), 0.02)
+        sd[p + "attn.proj.weight"] = _normal(g, (He, He), se)
+        sd[p + "attn.proj.bias"] = _normal(g, (He,), 0.02)
+        for nm, shp in (("gate_proj", (e.intermediate_size, He)), ("up_proj", (e.intermediate_size, He)),
+                        ("down_proj", (He, e.intermediate_size))):
+            sd[p + f"mlp.{nm}.weight"] = _normal(g, shp, 1.7 / math.sqrt(shp[1]))
+            sd[p + f"mlp.{nm}.bias"] = _normal(g, (shp[0],), 0.02)
+    m = e.spatial_merge_size ** 2
+    sd["vision_encoder.merger.ln_q.weight"] = torch.ones(He)
+    sd["vision_encoder.merger.mlp.0.weight"] = _normal(g, (He * m, He * m), 1.7 / math.sqrt(He * m))
+    sd["vision_encoder.merger.mlp.0.bias"] = _normal(g, (He * m,), 0.02)
+    sd["vision_encoder.merger.mlp.2.weight"] = _normal(g, (e.out_hidden_size, He * m), 1.7 / math.sqrt(He * m))
+    sd["vision_encoder.merger.mlp.2.bias"] = _normal(g, (e.out_hidden_size,), 0.02)
+    qd, kvd = d.num_attention_heads * d.head_dim, d.num_key_value_heads * d.head_dim
+    for i in range(d.num_hidden_layers):
+        p = f"decoder.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = _normal(g, (qd, Hd), sdd)
+        sd[p + "self_attn.q_proj.bias"] = _normal(g, (qd,), 0.02)
+        sd[p + "self_attn.k_proj.weight"] = _normal(g, (kvd, Hd), sdd)
+        sd[p + "self_attn.k_proj.bias"] = _normal(g, (kvd,), 0.02)
+        sd[p + "self_attn.v_proj.weight"] = _normal(g, (kvd, Hd), sdd)
+        sd[p + "self_attn.v_proj.bias"] = _normal(g, (kvd,), 0.02)
+        sd[p + "self_attn.o_proj.weight"] = _normal(g, (Hd, qd), 1.7 / math.sqrt(qd))
+        sd[p + "mlp.gate_proj.weight"] = _normal(g, (d.intermediate_size, Hd), sdd)
+        sd[p + "mlp.up_proj.weight"] = _normal(g, (d.intermediate_size, Hd), sdd)
+        sd[p + "mlp.down_proj.weight"] = _normal(g, (Hd, d.intermediate_size), 1.7 / math.sqrt(d.intermediate_size))
+        sd[p + "input_layernorm.weight"] = torch.ones(Hd)
+        sd[p + "post_attention_layernorm.weight"] = torch.ones(Hd)
+    sd["decoder.norm.weight"] = torch.ones(Hd)
+    sd["embedder.token_embed.weight"] = _normal(g, (d.vocab_size, Hd), 0.02)
+    sd["img_w_embed.weight"] = _normal(g, (cfg.image_embed_encoding_size, Hd), 0.02)
+    sd["img_h_embed.weight"] = _normal(g, (cfg.image_embed_encoding_size, Hd), 0.02)
+    sd["bbox_head.weight"] = _normal(g, (6, Hd), sdd)
+    sd["bbox_head.bias"] = _normal(g, (6,), 0.02)
+    # untied, separately seeded head: with a tied random embedding the model only repeats its input
+    sd["lm_head.weight"] = _normal(g, (d.vocab_size, Hd), 0.2)
+    sd["lm_head.bias"] = _normal(g, (d.vocab_size,), 0.6)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------- detector
+def det_param_specs(cfg: DetConfig) -> List[Tuple[str, str, tuple]]:
+    """(name, kind, shape) for every parameter/buffer of EfficientViTForSemanticSegmentation in module order
+    (surya/detection/model/encoderdecoder.py:484-630 backbone, :673-722 head). kind in {conv, bias, bn}."""
+    specs: List[Tuple[str, str, tuple]] = []
+    w = cfg.widths
+
+    def conv(prefix, cout, cin_per_group, k, bias, bn):
+        specs.append((prefix + ".conv.weight", "conv", (cout, cin_per_group, k, k)))
+        if bias:
+            specs.append((prefix + ".conv.bias", "bias", (cout,)))
+        if bn:
+            specs.append((prefix + ".norm", "bn", (cout,)))
+
+    conv("vit.stem.in_conv", w[0], cfg.num_channels, 3, False, True)
+    for r in range(cfg.depths[0]):
+        conv(f"vit.stem.res{r}.main.conv1", w[0], w[0], 3, False, True)
+        conv(f"vit.stem.res{r}.main.conv2", w[0], w[0], 3, False, True)
+    cin = w[0]
+    for si, (cout, depth) in enumerate(zip(w[1:], cfg.depths[1:])):
+        vit_stage, fewer = si >= 3, si >= 2
+        blk = f"vit.stages.{si}.blocks.0.main"
+        exp = 24 if vit_stage else 16
+        mid = round(cin * exp)
+        if fewer:  # MBConv, bias+no-norm on first two convs
+            conv(blk + ".inverted_conv", mid, cin, 1, True, False)
+            conv(blk + ".depth_conv", mid, 1, 3, True, False)
+            conv(blk + ".point_conv", cout, mid, 1, False, True)
+        else:      # FusedMBConv
+            conv(blk + ".spatial_conv", mid, cin, 3, False, True)
+            conv(blk + ".point_conv", cout, mid, 1, False, True)
+        for bi in range(1, depth + 1):
+            if vit_stage:
+                ctx = f"vit.stages.{si}.blocks.{bi}.context_module.main"
+                td = cout  # heads*dim == in_channels (heads_ratio 1)
+                heads = cout // cfg.head_dim
+                conv(ctx + ".qkv", 3 * td, cout, 1, False, False)
+                specs.append((ctx + ".aggreg.0.0.weight", "conv", (3 * td, 1, 5, 5)))
+                specs.append((ctx + ".aggreg.0.1.weight", "conv", (3 * td, cfg.head_dim, 1, 1)))
+                conv(ctx + ".proj", cout, 2 * td, 1, False, True)
+                loc = f"vit.stages.{si}.blocks.{bi}.local_module.main"
+                mid = cout * 6
+                conv(loc + ".inverted_conv", mid, cout, 1, True, False)
+                conv(loc + ".depth_conv", mid, 1, 3, True, False)
+                conv(loc + ".point_conv", cout, mid, 1, False, True)
+            else:
+                blk = f"vit.stages.{si}.blocks.{bi}.main"
+                mid = cout * 4
+                if fewer:
+                    conv(blk + ".inverted_conv", mid, cout, 1, True, False)
+                    conv(blk + ".depth_conv", mid, 1, 3, True, False)
+                    conv(blk + ".point_conv", cout, mid, 1, False, True)
+                else:
+                    conv(blk + ".spatial_conv", mid, cout, 3, False, True)
+                    conv(blk + ".point_conv", cout, mid, 1, False, True)
+        cin = cout
+    for i, width in enumerate(w[1:]):
+        specs.append((f"decode_head.linear_c.{i}.proj.weight", "conv", (cfg.decoder_layer_hidden_size, width)))
+        specs.append((f"decode_head.linear_c.{i}.proj.bias", "bias", (cfg.decoder_layer_hidden_size,)))
+    nst = len(w) - 1
+    specs.append(("decode_head.linear_fuse.weight", "conv",
+                  (cfg.decoder_hidden_size, cfg.decoder_layer_hidden_size * nst, 1, 1)))
+    specs.append(("decode_head.batch_norm", "bn", (cfg.decoder_hidden_size,)))
+    specs.append(("decode_head.classifier.weight", "conv", (cfg.num_labels, cfg.decoder_hidden_size, 1, 1)))
+    specs.append(("decode_head.classifier.bias", "bias", (cfg.num_labels,)))
+    return specs
+
+
+def make_det_weights(cfg: DetConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, kind, shape in det_param_specs(cfg):
+        if kind == "conv":
+            fan_in = int(np.prod(shape[1:]))
+            sd[name] = _normal(g, shape, 1.0 / math.sqrt(fan_in))
+        elif kind == "bias":
+            sd[name] = _normal(g, shape, 0.1)
+        else:  # bn: gamma U(0.8,1.2), beta N(0,0.1), running mean N(0,0.1), running var U(0.5,1.5)
+            sd[name + ".weight"] = 0.8 + 0.4 * torch.rand(shape, generator=g)
+            sd[name + ".bias"] = _normal(g, shape, 0.1)
+            sd[name + ".running_mean"] = _normal(g, shape, 0.1)
+            sd[name + ".running_var"] = 0.5 + torch.rand(shape, generator=g)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------- inputs
+def make_line_crops(n: int, height: int = 64, width_range=(128, 512), seed: int = 1234, fixed_width=None):
+    """uint8 RGB line crops: white background with dark random-width bars."""
+    rng = np.random.default_rng(seed)
+    crops = []
+    for _ in range(n):
+        w = int(fixed_width) if fixed_width else int(rng.integers(width_range[0], width_range[1] + 1))
+        img = np.full((height, w, 3), 255, np.uint8)
+        x = int(rng.integers(2, 8))
+        while x < w - 4:
+            bw = int(rng.integers(2, 12))
+            y0 = int(rng.integers(4, height // 3))
+            y1 = int(rng.integers(2 * height // 3, height - 4))
+            img[y0:y1, x:min(w, x + bw)] = rng.integers(0, 96, size=3, dtype=np.uint8)
+            x += bw + int(rng.integers(2, 10))
+        crops.append(img)
+    return crops
+
+
+def make_pages(n: int, size: int = 1024, seed: int = 1234):
+    """uint8 RGB pages: white with dark text-like rectangles in rows."""
+    rng = np.random.default_rng(seed)
+    pages = []
+    for _ in range(n):
+        img = np.full((size, size, 3), 255, np.uint8)
+        y = int(rng.integers(20, 60))
+        while y < size - 40:
+            lh = int(rng.integers(14, 28))
+            x = int(rng.integers(30, 90))
+            xe = size - int(rng.integers(30, 300))
+            while x < xe:
+                ww = int(rng.integers(10, 70))
+                img[y:y + lh, x:min(xe, x + ww)] = rng.integers(0, 80, size=3, dtype=np.uint8)
+                x += ww + int(rng.integers(6, 16))
+            y += lh + int(rng.integers(12, 36))
+        pages.append(img)
+    return pages
