@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the recognition hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of RecognitionPredictor's device loop (prefill + continuous-batching greedy decode until every
+line stopped) over a batch of 256 synthetic ragged line crops per GPU (BASELINE.json configs[1]): REC-FULL synthetic
+weights (no checkpoints offline), bf16, crops 64 x {128..512}, tiles already resident in HBM when the clock starts.
+Weak scaling: every rank processes its own 256 lines; no data-path collective (lines are independent); the token
+all-gather of surya_amd.dist runs once after the timed region to check all ranks finished the same amount of work.
+
+Prints ONE JSON line on rank 0 with the metric, plus
+  roofline      event-timed GEMM launches of one extra (untimed) pass, dominant tile configuration
+  cpu_baseline  the CPU oracle (oracle/rec_oracle.py, a port of the reference's torch path) on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="REC-FULL")
+    ap.add_argument("--lines", type=int, default=256, help="line crops per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="continuous-batching slots (RECOGNITION_BATCH_SIZE)")
+    ap.add_argument("--max-tokens", type=int, default=48)
+    ap.add_argument("--steps-per-sync", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lines", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, prep, n_lines, max_tokens):
+    """The CPU oracle on the first n_lines of the same workload (fp32, all host threads): lines/s."""
+    from oracle import rec_oracle as ro
+    ids_list = prep["prompt_ids"][:n_lines]
+    offs = prep["tile_offs"]
+    tiles = prep["tiles"][: int(offs[n_lines])].float().cpu()
+    grids = [(1, h, w) for h, w in prep["grids"][:n_lines]]
+    S = max(len(s) for s in ids_list)
+    pad = cfg.pad_token_id
+    ids = torch.tensor([[pad] * (S - len(s)) + list(s) for s in ids_list], dtype=torch.long)
+    am = ids.ne(pad).long()
+    pos = am.cumsum(-1) - 1
+    pos[pos < 0] = 0
+    pos = am * pos
+    om = ro.OracleRecModel(cfg, sd, cfg.image_token_id)
+    t0 = time.perf_counter()
+    toks, _, _, _ = ro.generate(om, ids, tiles, grids, am, pos, max_tokens, cfg.eos_token_id, cfg.pad_token_id, cfg.nop_token_id)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_lines / dt, 4), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_lines} of the same crops, max_tokens={max_tokens}, fp32 oracle incl. encoder+prefill+decode, "
+                      f"{sum(len(t) for t in toks)} tokens in {dt:.1f}s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
+    if args.steps_per_sync:
+        os.environ["RECOGNITION_STEPS_PER_SYNC"] = str(args.steps_per_sync)
+
+    from surya_amd import _lib as L
+    from surya_amd.config import rec_config
+    from surya_amd.settings import settings
+    from surya_amd.synth import make_line_crops, make_rec_weights
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    from surya_amd.recognition.schema import TaskNames
+    settings.reload()
+
+    cfg = rec_config(args.config)
+    sd = make_rec_weights(cfg, 0)
+    # capacities: prompt <= 63 tokens for these crops; +16 slack for device-resident multi-step decode
+    RecognitionPredictor.batch_size = args.batch
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype=None, **caps):
+            return super().model(f"cuda:{local_rank}", dtype, max_slots=args.batch, max_kv_len=64 + args.max_tokens + 32,
+                                 max_patches=65536, max_prefill_tokens=args.batch * 72)
+
+    RecognitionPredictor.model_loader_cls = Loader
+    pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
+    crops = make_line_crops(args.lines, seed=1234 + rank)
+    crops.sort(key=lambda c: -c.shape[1])                       # the predictor's widest-first ordering
+    flat = {"slices": [c.astype(np.float32) for c in crops], "input_text": [None] * len(crops),
+            "task_names": [TaskNames.ocr_with_boxes] * len(crops)}
+    prep = pred.prepare_lines(flat, math_mode=True)             # host pre-processing + H2D: outside the timed region
+    n_patches = int(prep["tile_offs"][-1])
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    total_tokens = 0
+    for _ in range(args.warmup):
+        toks, _, _ = pred.generate(prep, args.batch)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks, _, _ = pred.generate(prep, args.batch)
+        total_tokens += sum(len(t) for t in toks)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tk = torch.tensor([total_tokens], device="cuda", dtype=torch.int64)
+        dist.all_reduce(tk)
+        total_tokens = int(tk.item())
+
+    # ---- roofline: one more pass with every GEMM launch bracketed by HIP events on its stream
+    roof = None
+    lib = L.lib()
+    if rank == 0:
+        lib.surya_prof_enable(1)
+        pred.generate(prep, args.batch)
+        n = 4
+        launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
+        L.check(lib.surya_prof_read(n, launches, ms, fl, by), "surya_prof_read")
+        lib.surya_prof_enable(0)
+        names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt 64x64 (decode-step GEMMs)", "gemm_nt 32x64", "other"]
+        cats = [{"kernel": names[i], "launches": launches[i], "ms": ms[i], "tflops": (fl[i] / ms[i] / 1e9) if ms[i] else 0.0,
+                 "gbs": (by[i] / ms[i] / 1e6) if ms[i] else 0.0} for i in range(n) if launches[i]]
+        dom = max(cats, key=lambda c: c["ms"])
+        mfma_bound = dom["kernel"].startswith("gemm_nt 128")
+        ach, peak, unit = (dom["tflops"], PEAK_BF16_TFLOPS, "TFLOP/s") if mfma_bound else (dom["gbs"], PEAK_HBM_GBS, "GB/s")
+        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
+                "unit": unit, "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                "launches_per_step": dom["launches"],
+                "all_gemm_configs": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in cats]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, prep, min(args.cpu_lines, args.lines), args.max_tokens)
+
+    if rank == 0:
+        lines_total = args.lines * world * args.steps
+        out = {
+            "metric": "text-lines/sec recognised (whole node)", "value": round(lines_total / dt, 2), "unit": "lines/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"RecognitionPredictor device loop, {args.lines} ragged 64x{{128..512}} crops/GPU, batch {args.batch}, "
+                                   f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
+                       "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
+                       "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

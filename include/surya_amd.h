@@ -152,6 +152,15 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement support (bench.py `roofline`): when enabled every GEMM launch is bracketed by hipEvents on its own
+ * stream. surya_prof_read syncs the device and returns, per tile configuration (0: 128x128, 1: 64x64, 2: 32x64),
+ * the number of launches, the summed event time (ms) and the summed ALGORITHMIC flops / bytes
+ * (2MNK; X + W + C (+R) once each). Arrays need >= 4 entries. Not for use inside timed regions.
+ * ---------------------------------------------------------------------------------------------------------- */
+int surya_prof_enable(int on);
+int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,7 @@ def process_outputs(lm_logits, bbox_logits, eos_id: int, pad_id: int, bbox_size:
     scores = torch.max(F.softmax(logits[:, -1], dim=-1), dim=-1).values
     scores = scores.masked_fill(done, 0).unsqueeze(1)
     boxes = (bl * bbox_size).to(torch.long)
+    process_outputs.last_raw_boxes = bl * bbox_size      # un-truncated values, for boundary-aware test asserts
     return next_ids, preds, boxes, done, scores
 
 
@@ -319,6 +320,7 @@ def generate(model: OracleRecModel, input_ids, tiles, grid_thw, attention_mask, 
     tokens: List[List[int]] = [[] for _ in range(B)]
     scores: List[List[float]] = [[] for _ in range(B)]
     boxes: List[List[List[int]]] = [[] for _ in range(B)]
+    raw_boxes: List[List[List[float]]] = [[] for _ in range(B)]
     logits_log = [] if record_logits else None
     active = [True] * B
     lm, bb = model.prefill(input_ids, tiles, grid_thw, attention_mask, position_ids)
@@ -328,6 +330,7 @@ def generate(model: OracleRecModel, input_ids, tiles, grid_thw, attention_mask, 
     for b in range(B):
         t = int(preds[b, 0])
         tokens[b].append(t); scores[b].append(float(sc[b, 0])); boxes[b].append(bx[b, 0].tolist())
+        raw_boxes[b].append(process_outputs.last_raw_boxes[b, 0].tolist())
         if t in (eos_id, nop_id):                                          # prefill stop rule :559-563
             active[b] = False
     attention_mask = F.pad(attention_mask, (0, 1), value=1)
@@ -342,9 +345,29 @@ def generate(model: OracleRecModel, input_ids, tiles, grid_thw, attention_mask, 
                 continue
             t = int(preds[b, 0])
             tokens[b].append(t); scores[b].append(float(sc[b, 0])); boxes[b].append(bx[b, 0].tolist())
+            raw_boxes[b].append(process_outputs.last_raw_boxes[b, 0].tolist())
             rep = len(tokens[b]) >= max_tokens or detect_repeat_token(tokens[b])   # :583-595
             if t in (eos_id, pad_id) or rep:
                 active[b] = False
         attention_mask = F.pad(attention_mask, (0, 1), value=1)
         position_ids = position_ids[:, -1:] + 1
+    generate.last_raw_boxes = raw_boxes
     return tokens, boxes, scores, logits_log
+
+
+@torch.inference_mode()
+def teacher_forced_logits(model: OracleRecModel, input_ids, tiles, grid_thw, attention_mask, position_ids,
+                          forced: List[List[int]], pad_id: int):
+    """Logits of every step when the given token streams are fed back (lines shorter than the longest are fed pad).
+    Used to compare reduced-precision runs position by position without error feedback through argmax."""
+    out = []
+    lm, _ = model.prefill(input_ids, tiles, grid_thw, attention_mask, position_ids)
+    out.append(lm[:, -1].float().clone())
+    steps = max(len(f) for f in forced)
+    for s in range(steps - 1):
+        nxt = torch.tensor([[f[s] if s < len(f) else pad_id] for f in forced], dtype=torch.long)
+        attention_mask = F.pad(attention_mask, (0, 1), value=1)
+        position_ids = position_ids[:, -1:] + 1
+        lm, _ = model.decode(nxt, attention_mask, position_ids)
+        out.append(lm[:, -1].float().clone())
+    return out

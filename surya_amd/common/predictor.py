@@ -1,0 +1,52 @@
+"""Plugin seam of the predictors (behaviour of surya/common/predictor.py:9-57 and surya/common/load.py:8-24)."""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+from ..settings import settings
+
+
+class ModelLoader:
+    def __init__(self, checkpoint: Optional[str] = None):
+        self.checkpoint = checkpoint
+
+    def model(self, device=None, dtype=None) -> Any:
+        raise NotImplementedError()
+
+    def processor(self, device=None, dtype=None) -> Any:
+        raise NotImplementedError()
+
+
+class BasePredictor:
+    model_loader_cls = ModelLoader
+    batch_size: Optional[int] = None
+    default_batch_sizes = {"cpu": 1, "mps": 1, "cuda": 1}
+    disable_tqdm: bool = settings.DISABLE_TQDM
+    torch_dtype = None
+
+    def __init__(self, checkpoint: Optional[str] = None, device=None, dtype=None):
+        if device is None:
+            device = settings.TORCH_DEVICE_MODEL
+        if dtype is None:
+            dtype = self.torch_dtype
+        self.model = None
+        self.processor = None
+        loader = self.model_loader_cls(checkpoint)
+        self.model = loader.model(device, dtype)
+        self.processor = loader.processor()
+
+    def to(self, device_dtype=None):
+        if not self.model:
+            raise ValueError("Model not loaded")
+        self.model.to(device_dtype)
+
+    def get_batch_size(self):
+        bs = self.batch_size
+        if bs is None:
+            bs = self.default_batch_sizes["cpu"]
+            if settings.TORCH_DEVICE_MODEL in self.default_batch_sizes:
+                bs = self.default_batch_sizes[settings.TORCH_DEVICE_MODEL]
+        return bs
+
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError()

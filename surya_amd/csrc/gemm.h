@@ -180,6 +180,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     }
 }
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's `roofline` object): one record per
+// tile configuration, accumulating launches, algorithmic FLOPs / bytes and event-measured milliseconds.
+struct GemmProfiler {
+    static constexpr int NCFG = 4, POOL = 8192;
+    bool enabled = false;
+    hipEvent_t ev[2 * POOL];
+    bool have_events = false;
+    int n = 0;
+    int cfg_of[POOL];
+    double flops_of[POOL], bytes_of[POOL];
+    void start() {
+        if (!have_events) {
+            for (int i = 0; i < 2 * POOL; ++i) (void)hipEventCreate(&ev[i]);
+            have_events = true;
+        }
+        n = 0; enabled = true;
+    }
+};
+inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+inline int gemm_cfg_id(int BM, int BN) { return BM == 128 ? 0 : (BM == 64 ? 1 : (BM == 32 ? 2 : 3)); }
+
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -190,7 +211,19 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    GemmProfiler& pf = gemm_profiler();
+    const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
+    if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, a);
+    if (prof) {
+        (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
+        pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
+        pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
+        const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : a.N;
+        pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
+                            (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
+        ++pf.n;
+    }
     return (int)hipGetLastError();
 }
 

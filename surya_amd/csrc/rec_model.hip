@@ -671,6 +671,27 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
     return SA_ERR_UNSUPPORTED;
 }
 
+int surya_prof_enable(int on) {
+    GemmProfiler& pf = gemm_profiler();
+    if (on) pf.start(); else pf.enabled = false;
+    return SA_OK;
+}
+
+int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes) {
+    GemmProfiler& pf = gemm_profiler();
+    if (!launches || !ms || !flops || !bytes || max_cfg < GemmProfiler::NCFG) return SA_ERR_ARG;
+    SA_HIP(hipDeviceSynchronize());
+    for (int c = 0; c < GemmProfiler::NCFG; ++c) { launches[c] = 0; ms[c] = flops[c] = bytes[c] = 0.0; }
+    for (int i = 0; i < pf.n; ++i) {
+        float t = 0.f;
+        SA_HIP(hipEventElapsedTime(&t, pf.ev[2 * i], pf.ev[2 * i + 1]));
+        const int c = pf.cfg_of[i];
+        launches[c]++; ms[c] += t; flops[c] += pf.flops_of[i]; bytes[c] += pf.bytes_of[i];
+    }
+    pf.n = 0;
+    return SA_OK;
+}
+
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream) {
     if (!x || !w || !y || rows <= 0) return SA_ERR_ARG;

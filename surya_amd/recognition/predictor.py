@@ -1,0 +1,480 @@
+"""RecognitionPredictor: drop-in for surya.recognition.RecognitionPredictor on MI355X.
+
+Same call signature, class attributes and output schema as the reference
+(surya/recognition/__init__.py:77-102, 773-942). What changes is below the plugin seam:
+  * `self.model` is a HipRecModel (libsurya_amd.so); prefill / decode / process_outputs and the KV-cache merge
+    (reference :294-471, cache.py) are single library calls on a slot-based cache;
+  * prompts are pre-processed once up front (thread pool) and their tiles stay resident in HBM;
+  * the continuous-batching policy is the reference's (:539-599: prefill when more than `min_prefill_ratio` of the
+    slots are empty, same stop rules), but decode runs `RECOGNITION_STEPS_PER_SYNC` device-resident steps per host
+    round trip. Per-line outputs do not depend on batch composition, so the emitted tokens are the same.
+There is no CPU fallback: without the HIP library and a GPU, construction raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..common.geometry import PolygonBox
+from ..common.imageops import fill_poly_mask
+from ..common.predictor import BasePredictor, ModelLoader
+from ..config import RecConfig, rec_config
+from ..settings import settings
+from .model import HipRecModel
+from .postprocess import (clean_close_polygons, clean_math_tags, detect_repeat_token, fix_unbalanced_tags,
+                          prediction_to_polygon_batch, sort_text_lines, unwrap_math, words_from_chars)
+from .processor import NOMATH_TOKEN, SuryaOCRProcessor
+from .schema import OCRResult, TaskNames, TextChar, TextLine
+from .tokenizer import ByteMathTokenizer, OCRTokenizer
+
+
+# ------------------------------------------------------------------------------------------------ input slicing
+def convert_if_not_rgb(images: List[Image.Image]) -> List[Image.Image]:
+    return [im if im.mode == "RGB" else im.convert("RGB") for im in images]
+
+
+def slice_bboxes_from_image(image: np.ndarray, bboxes) -> List[np.ndarray]:
+    """Axis-aligned crops, boxes clipped into the page (surya/input/processing.py:35-54)."""
+    lines = []
+    for bbox in bboxes:
+        b = np.clip(np.array(bbox, dtype=np.int32), 0, None)
+        if b[3] <= b[1]:
+            b[3] = b[1] + 1
+        if b[2] <= b[0]:
+            b[2] = b[0] + 1
+        b[2] = min(b[2], image.shape[1])
+        b[3] = min(b[3], image.shape[0])
+        lines.append(image[b[1]: b[3], b[0]: b[2]].copy())
+    return lines
+
+
+def slice_and_pad_poly(image: np.ndarray, coordinates) -> np.ndarray:
+    """Crop the polygon's bounding box and paint everything outside the polygon with the pad value
+    (surya/input/processing.py:64-101; fillPoly replaced by common.imageops.fill_poly_mask)."""
+    pts = [(int(c[0]), int(c[1])) for c in coordinates]
+    x0, y0 = min(p[0] for p in pts), min(p[1] for p in pts)
+    x1, y1 = max(p[0] for p in pts), max(p[1] for p in pts)
+    crop = image[y0:y1, x0:x1].copy()
+    h, w = crop.shape[:2]
+    if y1 <= y0 or x1 <= x0 or len(pts) < 3 or h == 0 or w == 0:
+        return crop
+    mask = fill_poly_mask(h, w, [(x - x0, y - y0) for x, y in pts])
+    crop[mask == 0] = settings.RECOGNITION_PAD_VALUE
+    return crop
+
+
+def slice_polys_from_image(image: np.ndarray, polys) -> List[np.ndarray]:
+    return [slice_and_pad_poly(image, p) for p in polys]
+
+
+# ------------------------------------------------------------------------------------------------------ loader
+class RecognitionModelLoader(ModelLoader):
+    """`checkpoint` may be None (synthetic config named by SURYA_AMD_REC_CONFIG), a dict
+    {"config": RecConfig, "state_dict": {...}}, or a directory holding the reference's HF-format files
+    (config.json + *.safetensors; recognition/loader.py:25-82)."""
+
+    def __init__(self, checkpoint=None):
+        super().__init__(checkpoint)
+        self._cfg: Optional[RecConfig] = None
+        self._sd = None
+        self._special_tokens = None
+
+    def _resolve(self):
+        if self._cfg is not None:
+            return
+        ck = self.checkpoint
+        if isinstance(ck, dict):
+            self._cfg, self._sd = ck["config"], ck["state_dict"]
+            self._special_tokens = ck.get("special_tokens")
+        elif isinstance(ck, str) and os.path.isdir(ck):
+            from safetensors.torch import load_file
+            with open(os.path.join(ck, "config.json")) as f:
+                raw = json.load(f)
+            self._cfg = rec_config_from_reference_json(raw)
+            self._special_tokens = raw.get("special_ocr_tokens")
+            self._sd = {}
+            for fn in sorted(os.listdir(ck)):
+                if fn.endswith(".safetensors"):
+                    self._sd.update(load_file(os.path.join(ck, fn)))
+        else:
+            from ..synth import make_rec_weights
+            self._cfg = rec_config(ck if isinstance(ck, str) else settings.SURYA_AMD_REC_CONFIG)
+            self._sd = make_rec_weights(self._cfg, 0)
+
+    def tokenizer(self) -> OCRTokenizer:
+        self._resolve()
+        math_tok = None
+        if isinstance(self.checkpoint, str) and os.path.isdir(self.checkpoint):
+            try:
+                from transformers import Qwen2Tokenizer
+                math_tok = Qwen2Tokenizer.from_pretrained(self.checkpoint)
+            except Exception:
+                math_tok = None
+        if math_tok is None:
+            math_tok = ByteMathTokenizer(self._cfg.qwen_offset)
+        return OCRTokenizer(self._special_tokens, math_tok, reserve_special=self._cfg.num_special_tokens)
+
+    def model(self, device=None, dtype=None, **caps) -> HipRecModel:
+        self._resolve()
+        if device is None:
+            device = settings.TORCH_DEVICE_MODEL
+        if device == "cuda":
+            device = "cuda:0"
+        if dtype is None:
+            dtype = torch.bfloat16          # recognition/loader.py:35-38 picks bf16 on GPUs with native bf16
+        tok = self.tokenizer()
+        sysm = tok.system_tokens
+        caps.setdefault("max_slots", settings.RECOGNITION_BATCH_SIZE or RecognitionPredictor.default_batch_sizes["cuda"])
+        caps.setdefault("max_kv_len", 1536 + 32)
+        return HipRecModel(self._cfg, self._sd, image_token_id=sysm["<IMAGE>"], pad_token_id=sysm["<PAD>"],
+                           eos_token_id=sysm["</S>"], dtype=dtype, device=device, **caps)
+
+    def processor(self, device=None, dtype=None) -> SuryaOCRProcessor:
+        self._resolve()
+        e = self._cfg.encoder
+        return SuryaOCRProcessor(self.tokenizer(), self._cfg.num_register_tokens, e.patch_size, e.spatial_merge_size)
+
+
+def rec_config_from_reference_json(raw: dict) -> RecConfig:
+    """Map a SuryaModelConfig config.json (surya/common/surya/config.py) onto RecConfig."""
+    from ..config import DecoderConfig, EncoderConfig
+    ve, de = raw.get("vision_encoder", {}), raw.get("decoder", {})
+    enc = EncoderConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in ve.items()
+                           if k in EncoderConfig.__dataclass_fields__})
+    dkw = {k: v for k, v in de.items() if k in DecoderConfig.__dataclass_fields__}
+    if "head_dim" not in dkw and "hidden_size" in dkw and "num_attention_heads" in dkw:
+        dkw["head_dim"] = dkw["hidden_size"] // dkw["num_attention_heads"]
+    dec = DecoderConfig(**dkw)
+    return RecConfig(name="checkpoint", encoder=enc, decoder=dec, bbox_size=raw.get("bbox_size", 1025),
+                     image_embed_encoding_size=raw.get("image_embed_encoding_size", 1024),
+                     image_embed_encoding_multiplier=raw.get("image_embed_encoding_multiplier", 256),
+                     num_register_tokens=raw.get("num_register_tokens", 4))
+
+
+@dataclass
+class RecognitionPrompt:
+    id: int
+    task_name: str
+    image: np.ndarray
+    text: Optional[str]
+    math_mode: bool
+
+
+class RecognitionPredictor(BasePredictor):
+    model_loader_cls = RecognitionModelLoader
+    batch_size = settings.RECOGNITION_BATCH_SIZE
+    torch_dtype = None
+    default_batch_sizes = {"cpu": 32, "mps": 64, "cuda": 256, "xla": 128}
+    encoder_chunk_size: int = 4096
+    encoder_chunk_sizes = {"cpu": 4096, "mps": 4096, "cuda": 32768, "xla": 32768}
+    min_prefill_ratio: float = 0.2
+    min_trim_length: int = 50        # kept for API compatibility; the slot cache has no left padding to trim
+    tasks = {
+        TaskNames.ocr_with_boxes: {"needs_bboxes": True, "img_size": (1024, 256), "max_tokens": 224},
+        TaskNames.ocr_without_boxes: {"needs_bboxes": False, "img_size": (1024, 256), "max_tokens": 224},
+        TaskNames.block_without_boxes: {"needs_bboxes": False, "img_size": (1024, 512), "max_tokens": 768},
+    }
+
+    def __init__(self, checkpoint=None, device=None, dtype=None):
+        super().__init__(checkpoint, device, dtype)
+        self.prompt_queue = deque()
+        self.batch_prompt_mapping = None
+        self.preprocess_workers = min(8, os.cpu_count() or 1)
+
+    # ------------------------------------------------------------------------------------------ bookkeeping
+    def setup_cache(self, batch_size: int):
+        self.prompt_queue.clear()
+        self.batch_prompt_mapping = {i: None for i in range(batch_size)}
+
+    @property
+    def num_empty_slots(self):
+        return sum(v is None for v in self.batch_prompt_mapping.values())
+
+    @property
+    def num_active_slots(self):
+        return len(self.batch_prompt_mapping) - self.num_empty_slots
+
+    # --------------------------------------------------------------------------------------------- slicing
+    def detect_and_slice_bboxes(self, images, task_names, det_predictor, detection_batch_size=None, highres_images=None):
+        det_predictions = det_predictor(images, batch_size=detection_batch_size)
+        flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
+        for det_pred, image, highres, task in zip(det_predictions, images, highres_images, task_names):
+            polygons = [p.polygon for p in det_pred.bboxes]
+            if highres:
+                ws, hs = highres.size[0] / image.size[0], highres.size[1] / image.size[1]
+                scaled = [[[int(p[0] * ws), int(p[1] * hs)] for p in poly] for poly in polygons]
+                slices = slice_polys_from_image(self.processor.image_processor(highres), scaled)
+                scales = [(ws, hs)] * len(slices)
+            else:
+                slices = slice_polys_from_image(self.processor.image_processor(image), polygons)
+                scales = [(1, 1)] * len(slices)
+            flat["slice_map"].append(len(slices))
+            flat["slices"].extend(slices)
+            flat["polygons"].extend(polygons)
+            flat["task_names"].extend([task] * len(slices))
+            flat["res_scales"].extend(scales)
+        flat["input_text"] = [None] * len(flat["slices"])
+        return flat
+
+    def slice_bboxes(self, images, task_names, bboxes=None, polygons=None, input_text=None) -> dict:
+        assert bboxes is not None or polygons is not None
+        flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
+        for idx, image in enumerate(images):
+            arr = self.processor.image_processor(image)
+            if polygons is not None:
+                polys = polygons[idx]
+                slices = slice_polys_from_image(arr, polys)
+            else:
+                slices = slice_bboxes_from_image(arr, bboxes[idx])
+                polys = [[[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]] for b in bboxes[idx]]
+            flat["slice_map"].append(len(slices))
+            flat["slices"].extend(slices)
+            flat["polygons"].extend(polys)
+            flat["task_names"].extend([task_names[idx]] * len(slices))
+            flat["input_text"].extend([None] * len(slices) if input_text is None else input_text[idx])
+        n = len(flat["slices"])
+        assert n == sum(flat["slice_map"]) == len(flat["polygons"]) == len(flat["input_text"]) == len(flat["task_names"])
+        flat["res_scales"] = [(1, 1)] * n
+        return flat
+
+    def prepare_input(self, task_names, images, input_text, math_modes):
+        """Area clamp + prompt assembly per crop (reference :259-292)."""
+        batch = []
+        for image, text, task, math_mode in zip(images, input_text, task_names, math_modes):
+            size = self.tasks[task]["img_size"]
+            if image.size == 0:     # the reference catches cv2.error here and substitutes a blank crop (:272-278)
+                image = np.zeros((size[1], size[0], 3), dtype=np.float32)
+            else:
+                image = self.processor.scale_to_fit(image, size)
+            text = text or ""
+            if len(text) > self.tasks[task]["max_tokens"]:
+                text = ""
+            batch.append({"task": task, "inputs": [{"type": "image", "image": image, "rotated": False},
+                                                   {"type": "text", "text": text.strip(), "math": math_mode}]})
+        return batch
+
+    def preprocess_prompts(self, prompts: List[RecognitionPrompt]):
+        """All prompts -> (device tiles [sum P, 588], per-prompt tile offsets, grids, prompt ids)."""
+        def one(p):
+            b = self.prepare_input([p.task_name], [p.image], [p.text], [p.math_mode])
+            return self.processor(b)
+
+        if len(prompts) > 4 and self.preprocess_workers > 1:
+            with ThreadPoolExecutor(self.preprocess_workers) as ex:
+                outs = list(ex.map(one, prompts))
+        else:
+            outs = [one(p) for p in prompts]
+        counts = [o["image_tiles"].shape[0] for o in outs]
+        offs = np.zeros(len(outs) + 1, np.int64)
+        offs[1:] = np.cumsum(counts)
+        host = torch.from_numpy(np.concatenate([o["image_tiles"] for o in outs], 0))
+        tiles = host.pin_memory().to(self.model.device, non_blocking=True) if host.numel() else host.to(self.model.device)
+        grids = [tuple(int(x) for x in o["grid_hw"][0]) for o in outs]
+        ids = [o["input_ids"][0] for o in outs]
+        return tiles, offs, grids, ids
+
+    # ------------------------------------------------------------------------------------------- hot loop
+    def prepare_lines(self, flat: dict, math_mode: bool = True) -> dict:
+        """Host half of the loop: build prompts, pre-process every crop, upload the tiles (they stay in HBM)."""
+        prompts, max_tokens = [], {}
+        for idx, (img, txt, task) in enumerate(zip(flat["slices"], flat["input_text"], flat["task_names"])):
+            prompts.append(RecognitionPrompt(id=idx, task_name=task, text=txt, image=img, math_mode=math_mode))
+            max_tokens[idx] = settings.RECOGNITION_MAX_TOKENS or self.tasks[task]["max_tokens"]
+        tiles, tile_offs, grids, prompt_ids = self.preprocess_prompts(prompts)
+        return {"prompts": prompts, "max_tokens": max_tokens, "tiles": tiles, "tile_offs": tile_offs, "grids": grids,
+                "prompt_ids": prompt_ids}
+
+    def generate(self, prep: dict, recognition_batch_size: int | None = None) -> tuple:
+        """Device half: continuous batching over KV slots until every line stopped (reference :501-607)."""
+        prompts, batch_max_tokens = prep["prompts"], prep["max_tokens"]
+        tiles, tile_offs, grids, prompt_ids = prep["tiles"], prep["tile_offs"], prep["grids"], prep["prompt_ids"]
+        n = len(prompts)
+        predicted_tokens = [[] for _ in range(n)]
+        scores = [[] for _ in range(n)]
+        if recognition_batch_size is None:
+            recognition_batch_size = self.get_batch_size()
+        recognition_batch_size = min(recognition_batch_size, self.model.max_slots)
+        self.setup_cache(recognition_batch_size)
+        self.prompt_queue.extend(prompts)
+        overall_max_tokens = max(batch_max_tokens.values())
+        batch_bboxes = np.zeros((n, overall_max_tokens, 6), np.float32)
+        batch_pos = [0] * n
+        eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
+        steps_per_sync = max(1, min(settings.RECOGNITION_STEPS_PER_SYNC, 16))
+        max_prefill = self.model.c.max_prefill_tokens
+
+        def record(p_idx, tok, score, bbox):
+            predicted_tokens[p_idx].append(int(tok))
+            if batch_pos[p_idx] < overall_max_tokens:
+                batch_bboxes[p_idx, batch_pos[p_idx]] = bbox
+            batch_pos[p_idx] += 1
+            scores[p_idx].append(float(score))
+
+        while self.prompt_queue or self.num_active_slots > 0:
+            if (self.num_empty_slots / recognition_batch_size) > self.min_prefill_ratio and self.prompt_queue:
+                empty = [k for k, v in self.batch_prompt_mapping.items() if v is None]
+                take, ntok = [], 0
+                while self.prompt_queue and len(take) < len(empty):
+                    L_ = len(prompt_ids[self.prompt_queue[0].id])
+                    if take and ntok + L_ > max_prefill:
+                        break
+                    take.append(self.prompt_queue.popleft())
+                    ntok += L_
+                slots = empty[: len(take)]
+                a, b = int(tile_offs[take[0].id]), int(tile_offs[take[-1].id + 1])   # queue order == id order
+                self.model.prefill(tiles[a:b], [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
+                tok, sc, bb = self.model.read_outputs(1)
+                for p, s in zip(take, slots):
+                    record(p.id, tok[0, s], sc[0, s], bb[0, s])
+                    if predicted_tokens[p.id][-1] not in (eos, nop):       # prefill stop rule (reference :559-563)
+                        self.batch_prompt_mapping[s] = p.id
+                self.model.set_active([k for k, v in self.batch_prompt_mapping.items() if v is not None])
+            else:
+                k = steps_per_sync
+                self.model.decode(k)
+                tok, sc, bb = self.model.read_outputs(k)
+                changed = False
+                for step in range(k):
+                    for s, p_idx in self.batch_prompt_mapping.items():
+                        if p_idx is None:
+                            continue
+                        record(p_idx, tok[step, s], sc[step, s], bb[step, s])
+                        toks = predicted_tokens[p_idx]
+                        stop = len(toks) >= batch_max_tokens[p_idx] or detect_repeat_token(toks)   # reference :583-595
+                        if toks[-1] in (eos, pad) or stop:
+                            self.batch_prompt_mapping[s] = None
+                            changed = True
+                if changed:
+                    self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
+        return predicted_tokens, torch.from_numpy(batch_bboxes), scores
+
+    def prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:
+        return self.generate(self.prepare_lines(flat, math_mode), recognition_batch_size)
+
+    # ------------------------------------------------------------------------------------- output assembly
+    def get_bboxes_text(self, flat, predicted_tokens, scores, predicted_polygons, drop_repeated_text=False) -> list:
+        """Token stream -> TextChar list per line (reference :609-771): the stream is cut into runs of math-BPE ids,
+        single special tags, and UTF-16 ids; only the last kind carries per-character boxes."""
+        tk = self.processor.ocr_tokenizer
+        blank = [[0, 0], [0, 1], [1, 1], [1, 0]]
+        out = []
+        for tokens, polys, sc in zip(predicted_tokens, predicted_polygons, scores):
+            if self.processor.no_output_token in tokens:
+                out.append(None)
+                continue
+            if drop_repeated_text and detect_repeat_token(tokens):
+                out.append([TextChar(text="", polygon=blank, confidence=0, bbox_valid=False)])
+                continue
+            polys = np.asarray(polys[: len(tokens)]).tolist()
+            runs, cur, cur_kind = [], [], None
+            for bbox, tid, s in zip(polys, tokens, sc):
+                if tid in (self.processor.eos_token_id, self.processor.pad_token_id):
+                    break
+                kind = "qwen" if tid < tk.qwen_offset else ("special" if tid < tk.special_token_offset else "ocr")
+                if cur and (kind != cur_kind or kind == "special"):
+                    runs.append((cur_kind, cur))
+                    cur = []
+                cur.append((tid, s, bbox))
+                cur_kind = kind
+            if cur:
+                runs.append((cur_kind, cur))
+            chars = []
+            for kind, items in runs:
+                ids = [i[0] for i in items]
+                confs = [i[1] for i in items]
+                if kind == "ocr":
+                    text = tk.decode(ids, task=TaskNames.ocr_with_boxes)
+                    boxes = clean_close_polygons([i[2] for i in items])
+                    bi = 0
+                    for ch in text:
+                        chars.append(TextChar(text=ch, polygon=boxes[bi], confidence=confs[bi], bbox_valid=True))
+                        if bi < len(boxes) - 1:
+                            bi += 1
+                elif kind == "special":
+                    text = tk.decode(ids, task=TaskNames.ocr_without_boxes)
+                    if text == NOMATH_TOKEN or re.match(r"<SCRIPT-\w+>", text):
+                        continue
+                    chars.append(TextChar(text=text, polygon=blank, confidence=confs[0], bbox_valid=False))
+                else:
+                    text = tk.decode(ids, task=TaskNames.block_without_boxes)
+                    chars.append(TextChar(text=text, polygon=blank, confidence=confs[0], bbox_valid=False))
+            out.append(chars)
+        return out
+
+    def __call__(self, images: List[Image.Image], task_names: List[str] | None = None, det_predictor=None,
+                 detection_batch_size: int | None = None, recognition_batch_size: int | None = None,
+                 highres_images: List[Image.Image] | None = None, bboxes: List[List[List[int]]] | None = None,
+                 polygons: List[List[List[List[int]]]] | None = None, input_text: List[List[str | None]] | None = None,
+                 sort_lines: bool = False, math_mode: bool = True, return_words: bool = False,
+                 drop_repeated_text: bool = False) -> List[OCRResult]:
+        allowed = self.tasks.keys()
+        if task_names is None:
+            task_names = [TaskNames.ocr_with_boxes] * len(images)
+        assert all(t in allowed for t in task_names), (
+            f"One or more tasks in {task_names} is not supported. Supported tasks are {allowed}")
+        assert len(images) == len(task_names), "You need to pass in one task name for each image"
+        images = convert_if_not_rgb(images)
+        if highres_images is not None:
+            assert len(images) == len(highres_images), "You need to pass in one highres image for each image"
+        highres_images = convert_if_not_rgb(highres_images) if highres_images is not None else [None] * len(images)
+
+        if bboxes is None and polygons is None:
+            assert det_predictor is not None, (
+                "You need to pass in a detection predictor if you don't provide bboxes or polygons")
+            flat = self.detect_and_slice_bboxes(images, task_names, det_predictor, detection_batch_size, highres_images)
+        else:
+            if bboxes is not None:
+                assert len(images) == len(bboxes), "You need to pass in one list of bboxes for each image"
+            if polygons is not None:
+                assert len(images) == len(polygons), "You need to pass in one list of polygons for each image"
+            flat = self.slice_bboxes(images, bboxes=bboxes, polygons=polygons, input_text=input_text, task_names=task_names)
+        if len(flat["slices"]) == 0:
+            return []
+
+        # widest first: the length bucketing that keeps prefill batches homogeneous (reference :847-854)
+        order = sorted(range(len(flat["slices"])), key=lambda i: -flat["slices"][i].shape[1])
+        for key in ("slices", "input_text", "task_names"):
+            flat[key] = [flat[key][i] for i in order]
+
+        predicted_tokens, batch_bboxes, scores = self.prediction_loop(flat, recognition_batch_size, math_mode)
+        bbox_size = self.model.cfg.bbox_size
+        sizes = [img.shape for img in flat["slices"]]
+        polys = prediction_to_polygon_batch(batch_bboxes.numpy(), sizes, bbox_size, bbox_size // 2)
+        char_predictions = self.get_bboxes_text(flat, predicted_tokens, scores, polys, drop_repeated_text)
+        restored = [None] * len(order)
+        for sorted_pos, orig in enumerate(order):
+            restored[orig] = char_predictions[sorted_pos]
+
+        results, start = [], 0
+        for idx, image in enumerate(images):
+            end = start + flat["slice_map"][idx]
+            lines = []
+            for chars, polygon, res_scale in zip(restored[start:end], flat["polygons"][start:end],
+                                                 flat["res_scales"][start:end]):
+                if not chars:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
+                    lines.append(TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True))
+                    continue
+                confidence = float(np.mean([c.confidence for c in chars]))
+                box = PolygonBox(polygon=polygon)
+                for c in chars:
+                    c.rescale(res_scale, (1, 1))
+                    c.shift(box.bbox[0], box.bbox[1])
+                    c.clamp(box.bbox)
+                chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
+                text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
+                lines.append(TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
+                                      words=words_from_chars(chars, box) if return_words else []))
+            start = end
+            if sort_lines:
+                lines = sort_text_lines(lines)
+            results.append(OCRResult(text_lines=lines, image_bbox=[0, 0, image.size[0], image.size[1]]))
+        return results

@@ -1,0 +1,58 @@
+"""Environment-driven settings with the reference's variable names (surya/settings.py:12-190).
+
+pydantic_settings / dotenv are not in the image, so this is a small env reader; only the knobs the hot path
+reads are kept (the reference's S3 / font / dataset settings are out of scope).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+
+def _env(name, cast, default):
+    v = os.environ.get(name)
+    if v is None or v == "":
+        return default
+    if cast is bool:
+        return v.lower() in ("1", "true", "yes", "on")
+    return cast(v)
+
+
+class Settings:
+    def __init__(self):
+        self.reload()
+
+    def reload(self):
+        self.TORCH_DEVICE: Optional[str] = _env("TORCH_DEVICE", str, None)
+        self.DISABLE_TQDM: bool = _env("DISABLE_TQDM", bool, False)
+        self.LOGLEVEL: str = _env("LOGLEVEL", str, "INFO")
+        self.MODEL_CACHE_DIR: Optional[str] = _env("MODEL_CACHE_DIR", str, None)
+        # detection (settings.py:54-73)
+        self.DETECTOR_BATCH_SIZE: Optional[int] = _env("DETECTOR_BATCH_SIZE", int, None)
+        self.DETECTOR_IMAGE_CHUNK_HEIGHT: int = _env("DETECTOR_IMAGE_CHUNK_HEIGHT", int, 1400)
+        self.DETECTOR_TEXT_THRESHOLD: float = _env("DETECTOR_TEXT_THRESHOLD", float, 0.6)
+        self.DETECTOR_BLANK_THRESHOLD: float = _env("DETECTOR_BLANK_THRESHOLD", float, 0.35)
+        self.DETECTOR_POSTPROCESSING_CPU_WORKERS: int = _env("DETECTOR_POSTPROCESSING_CPU_WORKERS", int,
+                                                            min(8, os.cpu_count() or 1))
+        self.DETECTOR_MIN_PARALLEL_THRESH: int = _env("DETECTOR_MIN_PARALLEL_THRESH", int, 3)
+        self.DETECTOR_BOX_Y_EXPAND_MARGIN: float = _env("DETECTOR_BOX_Y_EXPAND_MARGIN", float, 0.05)
+        # recognition (settings.py:77-94)
+        self.RECOGNITION_MAX_TOKENS: Optional[int] = _env("RECOGNITION_MAX_TOKENS", int, None)
+        self.RECOGNITION_BATCH_SIZE: Optional[int] = _env("RECOGNITION_BATCH_SIZE", int, None)
+        self.RECOGNITION_CHUNK_SIZE: Optional[int] = _env("RECOGNITION_CHUNK_SIZE", int, None)
+        self.RECOGNITION_PAD_VALUE: int = _env("RECOGNITION_PAD_VALUE", int, 255)
+        # this implementation only
+        self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
+        self.SURYA_AMD_REC_CONFIG: str = _env("SURYA_AMD_REC_CONFIG", str, "REC-FULL")
+        self.SURYA_AMD_DET_CONFIG: str = _env("SURYA_AMD_DET_CONFIG", str, "DET-DEFAULT")
+
+    @property
+    def TORCH_DEVICE_MODEL(self) -> str:
+        """settings.py:32-52 -- explicit TORCH_DEVICE wins, else cuda (= ROCm/HIP here) if visible, else cpu."""
+        if self.TORCH_DEVICE is not None:
+            return self.TORCH_DEVICE
+        import torch
+        return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+settings = Settings()

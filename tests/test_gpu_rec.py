@@ -1,8 +1,11 @@
 """GPU: recognition hot path through the C ABI vs the CPU oracle (oracle/rec_oracle.py) on seeded inputs.
 
 Tolerances (stated per SURVEY 8(d)):
-  fp32 "reference mode": image embeddings / logits within 2e-4 x max|ref|; greedy token ids, bbox ints bit-exact.
-  bf16: logits within 6e-2 x max|ref| teacher-forced; argmax equal wherever the oracle top-2 margin > 4 x that.
+  fp32 "reference mode": image embeddings / logits within 2e-4 x max|ref|; greedy token ids bit-exact; bbox ints
+       bit-exact except where the oracle's un-truncated value lies within 2e-3 of an integer (trunc boundary), there +-1.
+  bf16: teacher-forced logits vs the fp32 oracle within 2 x (the oracle's OWN bf16-vs-fp32 deviation on the same
+       inputs, i.e. the reference's rounding model) + 1e-2 x max|ref|; argmax equal wherever the oracle top-2 margin
+       exceeds 4 x that tolerance (count reported).
 """
 import numpy as np
 import pytest
@@ -90,7 +93,12 @@ def test_generate_fp32_bit_exact_tokens(hip_lib, cfg_name):
     for i in range(n):
         L_ = len(toks_ref[i])                        # oracle stops lines at eos / repeat; compare the common prefix
         assert got[i][:L_] == toks_ref[i], (i, got[i][:L_], toks_ref[i])
-        assert got_boxes[i][:L_] == boxes_ref[i]
+        raw = ro.generate.last_raw_boxes[i]
+        for t in range(L_):
+            for k in range(6):
+                if got_boxes[i][t][k] != boxes_ref[i][t][k]:
+                    near = abs(raw[t][k] - round(raw[t][k])) < 2e-3
+                    assert near and abs(got_boxes[i][t][k] - boxes_ref[i][t][k]) == 1, (i, t, k, raw[t][k], got_boxes[i][t][k])
         assert np.allclose(got_scores[i][:L_], scores_ref[i], rtol=2e-3, atol=1e-6)
 
 
@@ -159,30 +167,34 @@ def test_slot_reuse_and_partial_active(hip_lib):
 def test_bf16_teacher_forced(hip_lib, cfg_name):
     cfg, sd, m = build(cfg_name, torch.bfloat16)
     tiles, seqs = make_prompts(cfg, GRIDS)
-    T = 16
+    T = 12
     toks_ref, _, _, logits_ref = _oracle_run(cfg, sd, tiles, seqs, T)
+    # the reference's own rounding model: same oracle, bf16 weights/activations, same forced tokens
+    ids, am, pos = left_pad_batch(cfg, seqs)
+    grids = [(1, h, w) for h, w in GRIDS]
+    ob = ro.OracleRecModel(cfg, {k: v.bfloat16() for k, v in sd.items()}, cfg.image_token_id)
+    logits_b16 = ro.teacher_forced_logits(ob, ids, tiles, grids, am, pos, toks_ref, cfg.pad_token_id)
     slots = list(range(len(seqs)))
     m.prefill(tiles.cuda(), GRIDS, seqs, slots)
     m.set_active(slots)
-    worst, mism, checked = 0.0, 0, 0
-    for step in range(T):
+    worst, worst_ref, mism, checked = 0.0, 0.0, 0, 0
+    for step in range(min(T, len(logits_ref))):
         lg = m.last_logits().cpu()
-        ref = logits_ref[step] if step < len(logits_ref) else None
-        if ref is None:
-            break
+        ref = logits_ref[step]
         live = [i for i in range(len(seqs)) if step < len(toks_ref[i])]
         scale = ref[live].abs().max().item()
-        tol = 6e-2 * scale
+        ref_dev = (logits_b16[step][live] - ref[live]).abs().max().item()
+        tol = 2 * ref_dev + 1e-2 * scale
         err = (lg[live] - ref[live]).abs().max().item()
-        worst = max(worst, err / scale)
+        worst, worst_ref = max(worst, err / scale), max(worst_ref, ref_dev / scale)
         top2 = ref.topk(2, dim=-1).values
         for i in live:
             if (top2[i, 0] - top2[i, 1]).item() > 4 * tol:
                 checked += 1
                 mism += int(lg[i].argmax().item() != ref[i].argmax().item())
-        assert err <= tol, (step, err, scale)
-        # teacher forcing: feed the oracle's token
+        assert err <= tol, (step, err, ref_dev, scale)
         m.set_next_tokens(slots, [toks_ref[i][step] if step < len(toks_ref[i]) else cfg.pad_token_id for i in slots])
         m.decode(1)
     assert mism == 0, (mism, checked)
-    print(f"bf16 teacher-forced {cfg_name}: worst rel logit err {worst:.4f}, argmax checked {checked}, mismatches {mism}")
+    print(f"bf16 teacher-forced {cfg_name}: worst rel logit err {worst:.4f} (reference bf16 path {worst_ref:.4f}), "
+          f"argmax checked {checked}, mismatches {mism}")

@@ -1,0 +1,136 @@
+"""CPU: host-side logic of the recognition boundary (tokenizer, processor, post-processing, geometry, ABI surface)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from surya_amd.common.geometry import PolygonBox
+from surya_amd.common import imageops
+from surya_amd.recognition import postprocess as pp
+from surya_amd.recognition.processor import SuryaOCRProcessor
+from surya_amd.recognition.schema import TextChar, TextLine, TaskNames
+from surya_amd.recognition.tokenizer import OCRTokenizer, ByteMathTokenizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "surya_amd.h")).read()
+    names = set(re.findall(r"\b(surya_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/surya_amd.h but not exported"
+
+
+def test_create_rejects_bad_config(hip_lib):
+    from surya_amd import _lib as L
+    cfg = L.RecConfigC(dtype=7)
+    h = C.c_void_p()
+    assert hip_lib.surya_rec_create(C.byref(cfg), None, 0, C.byref(h)) == -3        # SA_ERR_UNSUPPORTED
+    assert hip_lib.surya_rec_workspace_bytes(C.byref(cfg)) == 0
+
+
+def test_tokenizer_roundtrip_three_ranges():
+    tk = OCRTokenizer(None, ByteMathTokenizer(256), reserve_special=64)
+    text = 'Hi <b>x</b> <math display="inline">a^2</math> \U0001F600'
+    ids = tk(text, TaskNames.ocr_with_boxes)["input_ids"][0]
+    assert any(i < tk.qwen_offset for i in ids)                                   # math bytes
+    assert any(tk.qwen_offset <= i < tk.special_token_offset for i in ids)        # tags
+    assert sum(i >= tk.special_token_offset for i in ids) >= 7                    # UTF-16 units (emoji = 2)
+    assert tk.decode(ids, task=TaskNames.ocr_with_boxes) == text
+    assert tk.vocab_size == tk.special_token_offset + 65536
+    with pytest.raises(ValueError):
+        tk.decode([tk.special_token_offset - 1], task=TaskNames.ocr_with_boxes)  # reserved, unmapped tag id
+
+
+def test_processor_tile_order_and_prompt():
+    tk = OCRTokenizer(None, ByteMathTokenizer(256), reserve_special=64)
+    proc = SuryaOCRProcessor(tk)
+    # index image: pixel value = patch row-major index; 56 x 84 -> grid 4 x 6 (no resize needed)
+    gh, gw = 4, 6
+    img = np.zeros((gh * 14, gw * 14, 3), np.float32)
+    for r in range(gh):
+        for c in range(gw):
+            img[r * 14:(r + 1) * 14, c * 14:(c + 1) * 14] = r * gw + c
+    tiles, grid = proc.process_and_tile(img)
+    assert grid == (gh, gw) and tiles.shape == (24, 588)
+    raw = np.rint((tiles[:, 0] * 0.229 + 0.485) * 255).astype(int).tolist()
+    # merge-block-major: (0,0),(0,1),(1,0),(1,1),(0,2),(0,3),(1,2),(1,3) ...
+    assert raw[:8] == [0, 1, 6, 7, 2, 3, 8, 9]
+    ids = proc.prompt_ids(6, TaskNames.ocr_with_boxes, "", math_mode=False)
+    s = tk.system_tokens
+    assert ids == [s["<IMAGE>"]] * 6 + [s["<REG1>"], s["<REG2>"], s["<REG3>"], s["<REG4>"], s["<OCR-WB>"], s["<NO-MATH>"], s["<EOI>"]]
+
+
+def test_scale_to_fit_area_budget():
+    f = SuryaOCRProcessor.scale_to_fit
+    a = f(np.zeros((64, 512, 3), np.float32), (1024, 256))
+    assert a.shape[:2] == (64, 512)                       # 32768 px: inside [168^2, 1024*256]
+    b = f(np.zeros((64, 128, 3), np.float32), (1024, 256))
+    assert b.shape[:2] == (119, 238)                      # ceil(64*s), ceil(128*s), s = sqrt(28224/8192)
+    c = f(np.zeros((600, 1000, 3), np.float32), (1024, 256))
+    assert c.shape[0] * c.shape[1] <= 1024 * 256
+
+
+def test_resize_identity_and_constant():
+    img = np.random.default_rng(0).random((20, 30, 3)).astype(np.float32)
+    assert np.array_equal(imageops.resize(img, 30, 20, "cubic"), img)
+    const = np.full((10, 12, 3), 7.0, np.float32)
+    for kind in ("cubic", "lanczos4"):
+        out = imageops.resize(const, 25, 31, kind)
+        assert out.shape == (31, 25, 3) and np.allclose(out, 7.0, atol=1e-5)
+
+
+def test_fill_poly_mask_rectangle_and_triangle():
+    m = imageops.fill_poly_mask(10, 10, [(2, 2), (7, 2), (7, 6), (2, 6)])
+    assert m[2:7, 2:8].all() and m.sum() == 5 * 6
+    t = imageops.fill_poly_mask(10, 10, [(0, 0), (9, 0), (0, 9)])
+    assert t[0, 0] and t[0, 9] and t[9, 0] and not t[9, 9]
+
+
+def test_detect_repeat_token_rule():
+    assert not pp.detect_repeat_token([1] * 39)
+    assert pp.detect_repeat_token([1] * 40)
+    assert pp.detect_repeat_token([1, 2] * 20)
+    assert not pp.detect_repeat_token(list(range(40)))
+    assert not pp.detect_repeat_token([1, 2, 3, 4, 5, 6] * 7)
+
+
+def test_clean_math_tags_reference_cases():
+    # the two weight-free cases of the reference's own tests (tests/test_recognition.py:55-67)
+    assert pp.clean_math_tags("text <math><b>x</b></math> </math>") == "text <math>x</math> "
+    assert pp.clean_math_tags("a <math> </math> b") == "a  b"
+    assert pp.unwrap_math("<math>hello</math>") == "hello"
+    assert pp.unwrap_math("<math>a+b</math>") == "<math>a+b</math>"
+
+
+def test_prediction_to_polygon_batch_centre_box():
+    pred = np.zeros((1, 1, 6), np.float32)
+    pred[0, 0] = [512, 512, 100, 50, 512, 512]            # no skew (skew centred at bbox_size // 2)
+    poly = pp.prediction_to_polygon_batch(pred, [(64, 512, 3)], 1025, 512)
+    w, h = 512 / 1025, 64 / 1025
+    assert np.allclose(poly[0, 0], [[462 * w, 487 * h], [562 * w, 487 * h], [562 * w, 537 * h], [462 * w, 537 * h]], atol=1e-4)
+
+
+def test_polygon_box_semantics():
+    b = PolygonBox(polygon=[10, 20, 110, 60])
+    assert b.bbox == [10, 20, 110, 60] and b.width == 100 and b.height == 40
+    b.expand(0, 0.05)
+    assert b.bbox == [10, 18, 110, 62]
+    b.rescale((100, 100), (50, 200))
+    assert b.polygon[0] == [5, 36]
+    with pytest.raises(ValueError):
+        PolygonBox(polygon=[1, 2, 3])
+
+
+def test_words_from_chars_and_fix_tags():
+    line = PolygonBox(polygon=[0, 0, 100, 10])
+    chars = [TextChar(text=c, polygon=[i * 10, 0, i * 10 + 8, 10], confidence=0.9) for i, c in enumerate("ab cd")]
+    words = pp.words_from_chars(chars, line)
+    assert [w.text for w in words] == ["ab", "cd"]
+    st = {"formatting": ["<b>", "</b>", "<br>"], "math_external": ["<math>", "</math>"]}
+    cs = [TextChar(text="<b>", polygon=[0, 0, 1, 1], bbox_valid=False), TextChar(text="x", polygon=[0, 0, 1, 1])]
+    out = pp.fix_unbalanced_tags(cs, st)
+    assert out[-1].text == "</b>"
