@@ -55,11 +55,12 @@ def lib() -> C.CDLL:
             raise SuryaAmdError(
                 f"{LIB_PATH} not found: build it with `python -m surya_amd.build` (hipcc --offload-arch=gfx950). "
                 "surya_amd has no CPU/PyTorch fallback for the model path.")
+        # torch must load ITS libamdhip64.so.7 first: the library shares device pointers and streams with torch, so both
+        # have to bind to one HIP runtime instance (same SONAME -> the loader reuses the copy that is already mapped).
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.surya_amd_version.restype = C.c_char_p
         _lib.surya_rec_workspace_bytes.restype = C.c_size_t
-        for name in dir(_lib):
-            pass
     return _lib
 
 
