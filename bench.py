@@ -150,7 +150,8 @@ def main():
         launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
         L.check(lib.surya_prof_read(n, launches, ms, fl, by), "surya_prof_read")
         lib.surya_prof_enable(0)
-        names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt 64x64 (decode-step GEMMs)", "gemm_nt 32x64", "other"]
+        names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)",
+                 "gemm_nt small tiles", "other"]
         cats = [{"kernel": names[i], "launches": launches[i], "ms": ms[i], "tflops": (fl[i] / ms[i] / 1e9) if ms[i] else 0.0,
                  "gbs": (by[i] / ms[i] / 1e6) if ms[i] else 0.0} for i in range(n) if launches[i]]
         dom = max(cats, key=lambda c: c["ms"])

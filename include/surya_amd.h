@@ -154,7 +154,7 @@ int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y,
 
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): when enabled every GEMM launch is bracketed by hipEvents on its own
- * stream. surya_prof_read syncs the device and returns, per tile configuration (0: 128x128, 1: 64x64, 2: 32x64),
+ * stream. surya_prof_read syncs the device and returns, per tile-configuration bucket (0: 128x128, 1: tall 256-row tiles, 2: smaller tiles),
  * the number of launches, the summed event time (ms) and the summed ALGORITHMIC flops / bytes
  * (2MNK; X + W + C (+R) once each). Arrays need >= 4 entries. Not for use inside timed regions.
  * ---------------------------------------------------------------------------------------------------------- */

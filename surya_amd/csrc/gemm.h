@@ -10,8 +10,13 @@
 // output columns n of one row m -> 8/16-byte stores, float4 bias loads, and the (gate, up) pairs of the
 // interleaved SwiGLU weight land in one lane.
 //
-// LDS: [rows][8 chunks of 16 B], chunk index XOR-swizzled with (row & 7); register-staged double buffer,
-// one barrier per K-tile.
+// Pipeline: K-tiles are fetched TWO tiles ahead into alternating register sets and written to a double-buffered,
+// XOR-swizzled LDS image one iteration before use (one barrier per K-tile). The first version fetched one tile
+// ahead and was global-latency-bound (0.9-1.4 us per K-iteration at M=256: r01 profile).
+//
+// Tile menu: 128x128 (4 waves 2x2) for large problems; "tall" 256x64 / 256x32 (8 waves stacked in M) for the
+// decode regime M <= 256, where a block covers every row so each weight byte is fetched from HBM exactly once
+// and X is re-read from L2 only N/BN times.
 #pragma once
 #include "common.h"
 
@@ -31,27 +36,33 @@ struct GemmArgs {
 
 template <typename TI> struct Mfma;
 template <> struct Mfma<bf16_t> {
-    __device__ static __forceinline__ void run(f32x4& acc, const uint4& w, const uint4& x) {
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
     }
 };
 template <> struct Mfma<float> {
-    __device__ static __forceinline__ void run(f32x4& acc, const uint4& w, const uint4& x) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[0]), __uint_as_float(x[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[1]), __uint_as_float(x[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[2]), __uint_as_float(x[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[3]), __uint_as_float(x[3]), acc, 0, 0, 0);
     }
 };
 
-// BM x BN output tile per 256-thread workgroup; waves arranged WM x WN (WM*WN == 4).
+// BM x BN output tile per workgroup of WM x WN waves.
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
+    constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;   // 16-byte chunks per thread per tile
-    static_assert(WM * WN == 4 && FM >= 1 && FN >= 1 && XCH >= 1 && WCH >= 1, "tile");
+    // 16-byte chunks per thread per tile. When a tile has fewer chunks than threads (256x32: 256 W chunks, 512 threads)
+    // the upper threads duplicate the lower ones' chunk (same data to the same LDS slot) instead of being predicated:
+    // predicated loads cost an exec-mask branch + vmcnt(0) each and demote the staging registers to scratch.
+    constexpr int XCH = (BM * 8 + NT - 1) / NT, WCH = (BN * 8 + NT - 1) / NT;
+    constexpr int XMOD = XCH * NT > BM * 8 ? BM * 8 : XCH * NT, WMOD = WCH * NT > BN * 8 ? BN * 8 : WCH * NT;
+    static_assert(FM >= 1 && FN >= 1 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
+    static_assert((XCH == 1 || (BM * 8) % NT == 0) && (WCH == 1 || (BN * 8) % NT == 0), "staging split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: buf b: X tile [BM][128B] then W tile [BN][128B]
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
@@ -68,15 +79,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     int xdst[XCH], wdst[WCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-        int id = tid + i * 256, row = id >> 3, c = id & 7;
-        int gr = min(m0 + row, p.M - 1);
+        const int id = (tid + i * NT) % XMOD, row = id >> 3, c = id & 7;
+        const int gr = min(m0 + row, p.M - 1);
         xsrc[i] = reinterpret_cast<const unsigned char*>(p.X + (long)gr * p.ldx) + c * 16;
         xdst[i] = row * 128 + ((c ^ (row & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-        int id = tid + i * 256, row = id >> 3, c = id & 7;
-        int gr = min(n0 + row, p.N - 1);
+        const int id = (tid + i * NT) % WMOD, row = id >> 3, c = id & 7;
+        const int gr = min(n0 + row, p.N - 1);
         wsrc[i] = reinterpret_cast<const unsigned char*>(p.W + (long)gr * p.ldw) + c * 16;
         wdst[i] = XBYTES + row * 128 + ((c ^ (row & 7)) << 4);
     }
@@ -88,56 +99,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
         for (int i = 0; i < FM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / KE;
-    uint4 xr[XCH], wr[WCH];
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const uint4*>(xsrc[i]);
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) wr[i] = *reinterpret_cast<const uint4*>(wsrc[i]);
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) *reinterpret_cast<uint4*>(smem + xdst[i]) = xr[i];
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(smem + wdst[i]) = wr[i];
-    __syncthreads();
-
-    // fragment read offsets: row = base + (lane & 15), chunk = kk*4 + (lane >> 4)
-    const int frow = lane & 15, fch = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* cur = smem + (kt & 1) * BUF;
-        unsigned char* nxt = smem + ((kt + 1) & 1) * BUF;
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            const long koff = (long)(kt + 1) * 128;
-#pragma unroll
-            for (int i = 0; i < XCH; ++i) xr[i] = *reinterpret_cast<const uint4*>(xsrc[i] + koff);
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) wr[i] = *reinterpret_cast<const uint4*>(wsrc[i] + koff);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 xf[FM], wf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                int row = wm * WTM + i * 16 + frow;
-                xf[i] = *reinterpret_cast<const uint4*>(cur + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                int row = wn * WTN + j * 16 + frow;
-                wf[j] = *reinterpret_cast<const uint4*>(cur + XBYTES + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], wf[j], xf[i]);
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < XCH; ++i) *reinterpret_cast<uint4*>(nxt + xdst[i]) = xr[i];
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(nxt + wdst[i]) = wr[i];
-        }
-        __syncthreads();
+    // Two statically named register sets (runtime-indexed arrays would be demoted to scratch memory).
+    u32x4 xr0[XCH], wr0[WCH], xr1[XCH], wr1[WCH];
+#define SA_FETCH(XR, WR, KT)                                                                   \
+    {                                                                                          \
+        const long koff_ = (long)(KT) * 128;                                                   \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i)                                        \
+            XR[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + koff_);              \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                        \
+            WR[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + koff_);              \
     }
+#define SA_STASH(XR, WR, BUFP)                                                                 \
+    {                                                                                          \
+        unsigned char* b_ = (BUFP);                                                            \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i)                                        \
+            *reinterpret_cast<u32x4*>(b_ + xdst[i]) = XR[i];                       \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                        \
+            *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];                       \
+    }
+    const int frow = lane & 15, fch = lane >> 4;     // fragment: row = base + (lane & 15), chunk = kk*4 + (lane >> 4)
+#define SA_COMPUTE(CURP)                                                                                       \
+    {                                                                                                          \
+        const unsigned char* cur_ = (CURP);                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            u32x4 xf[FM], wf[FN];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
+                const int row = wm * WTM + i * 16 + frow;                                                      \
+                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
+                const int row = wn * WTN + j * 16 + frow;                                                      \
+                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
+                _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], wf[j], xf[i]);         \
+        }                                                                                                      \
+    }
+    // iteration kt: the set that held tile kt is free (tile kt already sits in LDS) -> refill it with tile kt+2;
+    // compute tile kt; publish tile kt+1 (fetched one iteration ago into the other set) to the other LDS buffer.
+    SA_FETCH(xr0, wr0, 0);
+    if (nk > 1) SA_FETCH(xr1, wr1, 1);
+    SA_STASH(xr0, wr0, smem);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) SA_FETCH(xr0, wr0, kt + 2);
+        SA_COMPUTE(smem);
+        if (kt + 1 < nk) SA_STASH(xr1, wr1, smem + BUF);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 3 < nk) SA_FETCH(xr1, wr1, kt + 3);
+            SA_COMPUTE(smem + BUF);
+            if (kt + 2 < nk) SA_STASH(xr0, wr0, smem);
+            __syncthreads();
+        }
+    }
+#undef SA_FETCH
+#undef SA_STASH
+#undef SA_COMPUTE
 
     // epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3}
 #pragma unroll
@@ -199,7 +217,8 @@ struct GemmProfiler {
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
-inline int gemm_cfg_id(int BM, int BN) { return BM == 128 ? 0 : (BM == 64 ? 1 : (BM == 32 ? 2 : 3)); }
+// profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
+inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (BM == 256 ? 1 : 2); }
 
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
@@ -214,7 +233,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     GemmProfiler& pf = gemm_profiler();
     const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
     if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, a);
     if (prof) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
         pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
@@ -227,16 +246,28 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// Tile choice: big tiles when the grid still fills 256 CUs, smaller ones for skinny problems (decode).
+// Tile choice. M <= 256 is the decode regime: one workgroup spans all rows (weights stream from HBM once), BN picked so
+// the grid has >= ~128 workgroups where N allows. Larger M uses 128x128 tiles, with 64x64 for problems too small to
+// fill the chip.
 template <typename TI, typename TO, int EPI>
 static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
     if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0) return SA_ERR_SHAPE;
+    if (a.M <= 256) {
+        if (a.M > 128) {
+            if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 256, 64, 8, 1, EPI>(a, s);
+            return launch_gemm_cfg<TI, TO, 256, 32, 8, 1, EPI>(a, s);
+        }
+        if (a.M > 64) {
+            if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
+            return launch_gemm_cfg<TI, TO, 128, 32, 4, 1, EPI>(a, s);
+        }
+        if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 64, 64, 4, 1, EPI>(a, s);
+        return launch_gemm_cfg<TI, TO, 64, 32, 4, 1, EPI>(a, s);
+    }
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    if (big >= 384) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
-    const long mid = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
-    if (mid >= 256 || a.M > 32) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
-    return launch_gemm_cfg<TI, TO, 32, 64, 1, 4, EPI>(a, s);
+    if (big >= 256) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
+    return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
 }
 
 }  // namespace sa
