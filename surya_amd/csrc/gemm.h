@@ -18,6 +18,8 @@
 // decode regime M <= 256, where a block covers every row so each weight byte is fetched from HBM exactly once
 // and X is re-read from L2 only N/BN times.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace sa {
@@ -32,6 +34,8 @@ struct GemmArgs {
     const TI* bias;              // [N] or nullptr
     const TO* R; long ldr;       // residual [M, N] (EPI_RESIDUAL), may alias C
     int M, N, K;                 // K % KE == 0, N % 4 == 0
+    int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
+    float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
 };
 
 template <typename TI> struct Mfma;
@@ -50,7 +54,7 @@ template <> struct Mfma<float> {
 };
 
 // BM x BN output tile per workgroup of WM x WN waves.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
@@ -70,8 +74,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int tile_id = SPLIT ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
+    const int ks = SPLIT ? (int)blockIdx.x % p.splitk : 0;       // slices of one tile are adjacent workgroups
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk_all = p.K / KE;
+    const int kt_begin = SPLIT ? (int)((long)ks * nk_all / p.splitk) : 0;
+    const int kt_end = SPLIT ? (int)((long)(ks + 1) * nk_all / p.splitk) : nk_all;
 
     // global source pointers for this thread's staging chunks (rows clamped into range)
     const unsigned char* xsrc[XCH];
@@ -81,14 +90,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     for (int i = 0; i < XCH; ++i) {
         const int id = (tid + i * NT) % XMOD, row = id >> 3, c = id & 7;
         const int gr = min(m0 + row, p.M - 1);
-        xsrc[i] = reinterpret_cast<const unsigned char*>(p.X + (long)gr * p.ldx) + c * 16;
+        xsrc[i] = reinterpret_cast<const unsigned char*>(p.X + (long)gr * p.ldx) + c * 16 + (long)kt_begin * 128;
         xdst[i] = row * 128 + ((c ^ (row & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int id = (tid + i * NT) % WMOD, row = id >> 3, c = id & 7;
         const int gr = min(n0 + row, p.N - 1);
-        wsrc[i] = reinterpret_cast<const unsigned char*>(p.W + (long)gr * p.ldw) + c * 16;
+        wsrc[i] = reinterpret_cast<const unsigned char*>(p.W + (long)gr * p.ldw) + c * 16 + (long)kt_begin * 128;
         wdst[i] = XBYTES + row * 128 + ((c ^ (row & 7)) << 4);
     }
 
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #pragma unroll
         for (int i = 0; i < FM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / KE;
+    const int nk = kt_end - kt_begin;
     // Two statically named register sets (runtime-indexed arrays would be demoted to scratch memory).
     u32x4 xr0[XCH], wr0[WCH], xr1[XCH], wr1[WCH];
 #define SA_FETCH(XR, WR, KT)                                                                   \
@@ -167,6 +176,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+            if constexpr (SPLIT) {
+                *reinterpret_cast<float4*>(p.part + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
+            }
             if (p.bias) {
                 float b[4];
                 load4(p.bias + n, b);
@@ -220,11 +233,11 @@ inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
 inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (BM == 256 ? 1 : 2); }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
-    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
     constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
-    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI>;
+    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT>;
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -239,8 +252,9 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
         pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
         pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
         const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : a.N;
-        pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
-                            (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
+        pf.bytes_of[pf.n] = SPLIT ? ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
+                                  : ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
+                                        (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
         ++pf.n;
     }
     return (int)hipGetLastError();
@@ -268,6 +282,26 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     if (big >= 256) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
     return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
+}
+
+// Split-K launch for the decode regime (M <= 256, small N): tiles x splitk workgroups so a skinny GEMM still covers the
+// chip; raw fp32 partial sums go to a.part[splitk][M][N] and the NEXT kernel combines them (launch-boundary reduce).
+// Returns the slice count actually used through a.splitk (caller passes the same struct to the consumer).
+static inline int pick_splitk(int tiles, int nk) {
+    int s = (256 + tiles / 2) / tiles;             // aim at ~256 workgroups
+    s = std::min(s, nk / 4);                       // keep >= 4 K-tiles per slice (pipeline fill)
+    return std::max(s, 1);
+}
+
+template <typename TI>
+static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return SA_OK;
+    if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || !a.part) return SA_ERR_SHAPE;
+    const int nk = a.K / Ty<TI>::KE;
+    a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk), 8);
+    if (a.M > 128) return launch_gemm_cfg<TI, TI, 256, 32, 8, 1, EPI_BIAS, true>(a, s);
+    if (a.M > 64) return launch_gemm_cfg<TI, TI, 128, 32, 4, 1, EPI_BIAS, true>(a, s);
+    return launch_gemm_cfg<TI, TI, 64, 32, 4, 1, EPI_BIAS, true>(a, s);
 }
 
 }  // namespace sa

@@ -280,11 +280,15 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 // single-query GQA attention over the slot's cache in one launch. 16 lanes share a key (16-byte slices of the
 // head dim, coalesced 256-byte rows for D=128 bf16), 16 keys in flight per workgroup, partial softmax states
 // merged through LDS. Replaces cache concat + 4-D mask + SDPA (decoder/__init__.py:193-234, cache.py:57-105).
+// The q/k/v row comes either from a finished qkv buffer or, after a split-K projection, from the fp32 partial slabs
+// (qkv_part[S][M][qkv_dim], summed here with the bias: the launch-boundary reduce of the split-K GEMM).
 template <typename T, int D, int MAXG>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ kc,
-                                                          T* __restrict__ vc, const int* __restrict__ active_slots,
-                                                          const int* __restrict__ kv_len, const float* __restrict__ inv_freq,
-                                                          int nq, int nkv, int Tmax, float scale) {
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_part, int S,
+                                                          const T* __restrict__ qkv_bias, T* __restrict__ out,
+                                                          T* __restrict__ kc, T* __restrict__ vc,
+                                                          const int* __restrict__ active_slots, const int* __restrict__ kv_len,
+                                                          const float* __restrict__ inv_freq, int nq, int nkv, int Tmax,
+                                                          float scale) {
     constexpr int EPL = D / 16;                 // head-dim elements per lane
     const int G = nq / nkv;
     const int a = blockIdx.x, kvh = blockIdx.y;
@@ -295,7 +299,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     __shared__ float knew[D], vnew[D];
     __shared__ float mg[4 * MAXG], lg[4 * MAXG];
     __shared__ float accs[4 * MAXG * D];
-    const T* row = qkv + (long)a * (nq + 2 * nkv) * D;
+    const int qkv_dim = (nq + 2 * nkv) * D;
+    const int Mrows = gridDim.x;
+    auto ldq = [&](int col) -> float {              // element `col` of this row of the fused qkv projection
+        if (qkv_part) {
+            float acc = Ty<T>::ld(qkv_bias + col);
+            for (int sidx = 0; sidx < S; ++sidx) acc += qkv_part[((long)sidx * Mrows + a) * qkv_dim + col];
+            return Ty<T>::rnd(acc);
+        }
+        return Ty<T>::ld(qkv + (long)a * qkv_dim + col);
+    };
     const int half = D / 2;
     const float fpos = (float)len;
     for (int it = tid; it < (G + 1) * half; it += 256) {
@@ -303,8 +316,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         float sn, cs;
         sincosf(fpos * inv_freq[i], &sn, &cs);
         cs = Ty<T>::rnd(cs); sn = Ty<T>::rnd(sn);
-        const T* v = (hh < G) ? row + (long)(kvh * G + hh) * D : row + (long)(nq + kvh) * D;
-        const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
+        const int vcol = (hh < G) ? (kvh * G + hh) * D : (nq + kvh) * D;
+        const float x1 = ldq(vcol + i), x2 = ldq(vcol + i + half);
         const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
         if (hh < G) {
             qs[hh * D + i] = y1 * scale; qs[hh * D + i + half] = y2 * scale;
@@ -315,9 +328,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         }
     }
     for (int i = tid; i < D; i += 256) {
-        const T val = row[(long)(nq + nkv + kvh) * D + i];
-        vnew[i] = Ty<T>::ld(&val);
-        vc[(((long)slot * nkv + kvh) * Tmax + len) * D + i] = val;
+        const float val = ldq((nq + nkv + kvh) * D + i);
+        vnew[i] = val;
+        Ty<T>::st(vc + (((long)slot * nkv + kvh) * Tmax + len) * D + i, val);
     }
     __syncthreads();
     float qreg[MAXG][EPL], acc[MAXG][EPL], m[MAXG], l[MAXG];
@@ -389,6 +402,76 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
             den += w * lg[g * MAXG + h];
         }
         Ty<T>::st(out + (long)a * nq * D + (long)(kvh * G + h) * D + dd, num / den);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Launch-boundary reduce of a split-K projection fused with the residual add and the NEXT RMSNorm:
+//   x <- T(x + bias + sum_s part[s])            (what the unsplit GEMM's EPI_RESIDUAL epilogue would have stored)
+//   y <- w * T(x * rsqrt(mean(x^2) + eps))      (Qwen2RMSNorm of the updated residual stream, optional)
+// One wave per row, row length H (decode: hidden size). Removes the separate rmsnorm launch of every decode layer.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* __restrict__ part, int S, int M, T* __restrict__ x,
+                                                                   const T* __restrict__ bias, const T* __restrict__ w,
+                                                                   T* __restrict__ y, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    T* xr = x + (long)row * H;
+    float ss = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        load4(xr + c, v);
+        if (bias) {
+            float b[4];
+            load4(bias + c, b);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        for (int s = 0; s < S; ++s) {
+            const float4 p4 = *reinterpret_cast<const float4*>(part + ((long)s * M + row) * H + c);
+            v[0] += p4.x; v[1] += p4.y; v[2] += p4.z; v[3] += p4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = Ty<T>::rnd(v[i]); ss += v[i] * v[i]; }
+        store4(xr + c, v[0], v[1], v[2], v[3]);
+    }
+    if (!w) return;
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    T* yr = y + (long)row * H;
+    for (int c = lane * 4; c < H; c += 256) {      // re-read of this lane's own stores (same lane, same addresses)
+        float v[4], g[4];
+        load4(xr + c, v);
+        load4(w + c, g);
+        store4(yr + c, g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
+               g[3] * Ty<T>::rnd(v[3] * rstd));
+    }
+}
+
+// Decode-step embedding fused with the first layer's input RMSNorm: x[a] = table[next_token[slot]], y[a] = norm(x[a]).
+template <typename T>
+__global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
+                                                              const int* __restrict__ active_slots, T* __restrict__ x,
+                                                              const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const T* src = table + (long)next_token[active_slots[a]] * H;
+    T* xr = x + (long)a * H;
+    float ss = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        load4(src + c, v);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        store4(xr + c, v[0], v[1], v[2], v[3]);
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    T* yr = y + (long)a * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4], g[4];
+        load4(src + c, v);
+        load4(w + c, g);
+        store4(yr + c, g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
+               g[3] * Ty<T>::rnd(v[3] * rstd));
     }
 }
 

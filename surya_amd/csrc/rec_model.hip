@@ -161,6 +161,7 @@ struct RecModel : RecBase {
     // decoder workspaces
     T *dx, *dh, *dqkv, *dattn, *dmlp, *dlast;
     float* logits;
+    float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
     int *kv_len, *next_token, *active_dev;
     int* out_token; float* out_score; int* out_bbox;     // [SA_MAX_STEPS][max_slots] (bbox x6)
@@ -193,6 +194,7 @@ struct RecModel : RecBase {
         size_t o_dmlp = take(Tm * c.dec_inter * sizeof(T));
         size_t o_dlast = take(S * c.dec_hidden * sizeof(T));
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
+        size_t o_part = take((size_t)8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));
         const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
         size_t o_k = take(kv_elems * sizeof(T));
         size_t o_v = take(kv_elems * sizeof(T));
@@ -206,6 +208,7 @@ struct RecModel : RecBase {
             m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
             m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
             m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits);
+            m->part = (float*)(b + o_part);
             m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
             m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active);
             m->out_token = (int*)(b + o_out);
@@ -368,8 +371,8 @@ struct RecModel : RecBase {
     }
 
     // ------------------------------------------------------------------------------------------ decoder
-    int decoder_layers(int M, bool is_prefill, const int* d_tok_slot, const int* d_tok_pos, const AttnSegs* sg, int n_tiles,
-                       hipStream_t s) {
+    // Prefill: packed prompt tokens, causal attention over the freshly written cache rows.
+    int decoder_layers_prefill(int M, const int* d_tok_slot, const int* d_tok_pos, const AttnSegs* sg, int n_tiles, hipStream_t s) {
         const int Hd = c.dec_hidden, nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim, I = c.dec_inter;
         const int qkv_d = (nq + 2 * nkv) * d;
         const float scale = 1.0f / sqrtf((float)d);
@@ -382,25 +385,10 @@ struct RecModel : RecBase {
             if ((rc = rmsnorm(dx, Hd, WD(l, SA_RD_LN1), dh, Hd, nullptr, M, Hd, c.dec_eps, s))) return rc;
             if ((rc = gemm<EPI_BIAS>(dh, Hd, WD(l, SA_RD_QKV_W), Hd, dqkv, qkv_d, WD(l, SA_RD_QKV_B), nullptr, 0, M, qkv_d, Hd, s)))
                 return rc;
-            if (is_prefill) {
-                hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, inv_freq, kc,
-                                   vc, nq, nkv, d, c.max_kv_len);
-                if ((rc = attention(d, dqkv, kc, vc, dattn, *sg, n_tiles, nq, qkv_d, d, d, (long)c.max_kv_len * d, (long)nq * d,
-                                    d, nq / nkv, 1, scale, s))) return rc;
-            } else {
-                dim3 grid(M, nkv), block(256);
-#define SA_DEC(DD)                                                                                                      \
-    hipLaunchKernelGGL((decode_attn_kernel<T, DD, 8>), grid, block, 0, s, dqkv, dattn, kc, vc, active_dev, kv_len, inv_freq, \
-                       nq, nkv, c.max_kv_len, scale)
-                switch (d) {
-                    case 32: SA_DEC(32); break;
-                    case 64: SA_DEC(64); break;
-                    case 128: SA_DEC(128); break;
-                    default: return SA_ERR_UNSUPPORTED;
-                }
-#undef SA_DEC
-                if ((rc = (int)hipGetLastError())) return rc;
-            }
+            hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, inv_freq, kc, vc,
+                               nq, nkv, d, c.max_kv_len);
+            if ((rc = attention(d, dqkv, kc, vc, dattn, *sg, n_tiles, nq, qkv_d, d, d, (long)c.max_kv_len * d, (long)nq * d, d,
+                                nq / nkv, 1, scale, s))) return rc;
             if ((rc = gemm<EPI_RESIDUAL>(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, dx, Hd, nullptr, dx, Hd, M, Hd, nq * d,
                                          s))) return rc;
             if ((rc = rmsnorm(dx, Hd, WD(l, SA_RD_LN2), dh, Hd, nullptr, M, Hd, c.dec_eps, s))) return rc;
@@ -410,10 +398,60 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
-    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, hipStream_t s) {
+    int splitk_gemm(const T* X, long ldx, const T* Wt, long ldw, int M, int N, int K, int* S, hipStream_t s) {
+        GemmArgs<T, T> a{X, ldx, Wt, ldw, nullptr, 0, nullptr, nullptr, 0, M, N, K, 1, part};
+        int rc = launch_gemm_splitk<T>(a, s);
+        *S = a.splitk;
+        return rc;
+    }
+    int reduce_residual_norm(int S, int M, const T* wnorm, T* y, hipStream_t s) {
+        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(cdiv(M, 4)), dim3(256), 0, s, part, S, M, dx, (const T*)nullptr,
+                           wnorm, y, c.dec_hidden, c.dec_eps);
+        return (int)hipGetLastError();
+    }
+
+    // One decode step for the M active slots. The three skinny projections (qkv, o, down) run split-K so they cover the
+    // chip; their partial sums are combined by the kernel that needs the result anyway: decode attention (qkv) and a
+    // fused residual-add + next-RMSNorm pass (o, down). Leaves the final-norm output of every row in `dlast`.
+    int decoder_layers_decode(int M, hipStream_t s) {
+        const int Hd = c.dec_hidden, nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim, I = c.dec_inter;
+        const int qkv_d = (nq + 2 * nkv) * d;
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t layer_kv = (size_t)c.max_slots * nkv * c.max_kv_len * d;
+        const float* inv_freq = reinterpret_cast<const float*>(w[SA_RW_DEC_INVFREQ]);
+        int rc, S = 1;
+        hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(M), dim3(64), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, dx,
+                           WD(0, SA_RD_LN1), dh, Hd, c.dec_eps);
+        for (int l = 0; l < c.dec_layers; ++l) {
+            T* kc = kcache + l * layer_kv;
+            T* vc = vcache + l * layer_kv;
+            if ((rc = splitk_gemm(dh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, &S, s))) return rc;
+            dim3 grid(M, nkv), block(256);
+#define SA_DEC(DD)                                                                                                          \
+    hipLaunchKernelGGL((decode_attn_kernel<T, DD, 8>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
+                       kc, vc, active_dev, kv_len, inv_freq, nq, nkv, c.max_kv_len, scale)
+            switch (d) {
+                case 32: SA_DEC(32); break;
+                case 64: SA_DEC(64); break;
+                case 128: SA_DEC(128); break;
+                default: return SA_ERR_UNSUPPORTED;
+            }
+#undef SA_DEC
+            if ((rc = (int)hipGetLastError())) return rc;
+            if ((rc = splitk_gemm(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, &S, s))) return rc;
+            if ((rc = reduce_residual_norm(S, M, WD(l, SA_RD_LN2), dh, s))) return rc;
+            if ((rc = gemm<EPI_SWIGLU>(dh, Hd, WD(l, SA_RD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
+            if ((rc = splitk_gemm(dmlp, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, &S, s))) return rc;
+            const bool last = (l + 1 == c.dec_layers);
+            if ((rc = reduce_residual_norm(S, M, last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1), last ? dlast : dh, s))) return rc;
+        }
+        return SA_OK;
+    }
+
+    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s) {
         const int Hd = c.dec_hidden;
         int rc;
-        if ((rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), dlast, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
+        if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), dlast, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
         GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
         if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
         const size_t so = (size_t)step * c.max_slots;
@@ -479,8 +517,8 @@ struct RecModel : RecBase {
         if (!d_sg.o_off) return SA_ERR_NOMEM;
         if ((rc = st.flush(s))) return rc;
         hipLaunchKernelGGL(set_slot_state_kernel, dim3(cdiv(n_seqs, 256)), dim3(256), 0, s, d_slots, d_lens, kv_len, n_seqs);
-        if ((rc = decoder_layers(Ttot, true, d_tok_slot, d_tok_pos, &d_sg, (int)sg.tile_seg.size(), s))) return rc;
-        return heads(n_seqs, d_last, d_slots, 0, 0, s);
+        if ((rc = decoder_layers_prefill(Ttot, d_tok_slot, d_tok_pos, &d_sg, (int)sg.tile_seg.size(), s))) return rc;
+        return heads(n_seqs, d_last, d_slots, 0, 0, false, s);
     }
 
     int set_active(const int32_t* slots, int n, hipStream_t s) override {
@@ -502,10 +540,8 @@ struct RecModel : RecBase {
         if (M == 0) return SA_OK;
         int rc;
         for (int step = 0; step < n_steps; ++step) {
-            hipLaunchKernelGGL(embed_slots_kernel<T>, dim3(M), dim3(128), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, dx,
-                               c.dec_hidden);
-            if ((rc = decoder_layers(M, false, nullptr, nullptr, nullptr, 0, s))) return rc;
-            if ((rc = heads(M, nullptr, active_dev, step, 1, s))) return rc;
+            if ((rc = decoder_layers_decode(M, s))) return rc;
+            if ((rc = heads(M, nullptr, active_dev, step, 1, true, s))) return rc;
         }
         return SA_OK;
     }
