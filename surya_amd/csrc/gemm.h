@@ -146,22 +146,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     }
     // iteration kt: the set that held tile kt is free (tile kt already sits in LDS) -> refill it with tile kt+2;
     // compute tile kt; publish tile kt+1 (fetched one iteration ago into the other set) to the other LDS buffer.
+    // Fetches and publishes are UNCONDITIONAL (tile index clamped to the last tile, redundant at the tail): with a
+    // conditional fetch hipcc cannot count the loads in flight at the merge point and falls back to vmcnt(0) before
+    // every fetch, which collapses the prefetch distance to one tile (seen in the r01 ISA: ~1 us per K-iteration).
+    const int last = nk - 1;
     SA_FETCH(xr0, wr0, 0);
-    if (nk > 1) SA_FETCH(xr1, wr1, 1);
+    SA_FETCH(xr1, wr1, min(1, last));
     SA_STASH(xr0, wr0, smem);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) SA_FETCH(xr0, wr0, kt + 2);
+    const int pairs = nk >> 1;
+    for (int pi = 0; pi < pairs; ++pi) {
+        const int kt = 2 * pi;
+        // sched_barrier(0) pins fetch -> compute -> publish: left alone, hipcc hoists the publish (and its vmcnt wait for
+        // loads issued a few instructions earlier) above the MFMAs, exposing the full global latency every iteration.
+        SA_FETCH(xr0, wr0, min(kt + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
         SA_COMPUTE(smem);
-        if (kt + 1 < nk) SA_STASH(xr1, wr1, smem + BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        SA_STASH(xr1, wr1, smem + BUF);
         __syncthreads();
-        if (kt + 1 < nk) {
-            if (kt + 3 < nk) SA_FETCH(xr1, wr1, kt + 3);
-            SA_COMPUTE(smem + BUF);
-            if (kt + 2 < nk) SA_STASH(xr0, wr0, smem);
-            __syncthreads();
-        }
+        SA_FETCH(xr1, wr1, min(kt + 3, last));
+        __builtin_amdgcn_sched_barrier(0);
+        SA_COMPUTE(smem + BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        SA_STASH(xr0, wr0, smem);
+        __syncthreads();
     }
+    if (nk & 1) SA_COMPUTE(smem);          // odd tail: tile nk-1 was published to buffer 0 by the last pair
 #undef SA_FETCH
 #undef SA_STASH
 #undef SA_COMPUTE

@@ -414,12 +414,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* __restrict__ part, int S, int M, T* __restrict__ x,
                                                                    const T* __restrict__ bias, const T* __restrict__ w,
                                                                    T* __restrict__ y, int H, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x, tid = threadIdx.x;       // one workgroup per row: M workgroups keep the chip busy at M = 256
+    __shared__ float red[4];
     T* xr = x + (long)row * H;
     float ss = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
+    for (int c = tid * 4; c < H; c += 1024) {
         float v[4];
         load4(xr + c, v);
         if (bias) {
@@ -437,9 +436,11 @@ __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* 
     }
     if (!w) return;
     ss = wave_sum(ss);
-    const float rstd = rsqrtf(ss / (float)H + eps);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
     T* yr = y + (long)row * H;
-    for (int c = lane * 4; c < H; c += 256) {      // re-read of this lane's own stores (same lane, same addresses)
+    for (int c = tid * 4; c < H; c += 1024) {             // re-read of this thread's own stores (same addresses)
         float v[4], g[4];
         load4(xr + c, v);
         load4(w + c, g);

@@ -405,7 +405,7 @@ struct RecModel : RecBase {
         return rc;
     }
     int reduce_residual_norm(int S, int M, const T* wnorm, T* y, hipStream_t s) {
-        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(cdiv(M, 4)), dim3(256), 0, s, part, S, M, dx, (const T*)nullptr,
+        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(256), 0, s, part, S, M, dx, (const T*)nullptr,
                            wnorm, y, c.dec_hidden, c.dec_eps);
         return (int)hipGetLastError();
     }
