@@ -241,23 +241,34 @@ __global__ void embed_slots_kernel(const T* __restrict__ table, const int* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Decoder RoPE table, built once per model: (cos, sin)(pos * inv_freq[i]) in fp32, then rounded to the storage type
+// exactly where the reference rounds them (Qwen2RotaryEmbedding.forward, decoder/__init__.py:346-361).
+template <typename T>
+__global__ void rope_table_kernel(const float* __restrict__ inv_freq, float2* __restrict__ table, int Tmax, int half) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Tmax * half) return;
+    const int pos = idx / half, i = idx % half;
+    float sn, cs;
+    sincosf((float)pos * inv_freq[i], &sn, &cs);
+    table[idx] = make_float2(Ty<T>::rnd(cs), Ty<T>::rnd(sn));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Decoder prefill: RoPE on q (in place) and k, append k/v to the slot KV cache.
 // qkv [Ttot, (nq + 2 nkv) * D]; cache layout [slot][kv_head][T_max][D]; cos/sin are rounded to T before use
 // (decoder/__init__.py:361), rotate_half pairing (:53-84).
 template <typename T>
 __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict__ tok_slot, const int* __restrict__ tok_pos,
-                                      const float* __restrict__ inv_freq, T* __restrict__ kc, T* __restrict__ vc,
+                                      const float2* __restrict__ rope_cs, T* __restrict__ kc, T* __restrict__ vc,
                                       int nq, int nkv, int D, int Tmax) {
     const int t = blockIdx.x;
     const int slot = tok_slot[t], pos = tok_pos[t];
     const int half = D / 2;
     T* row = qkv + (long)t * (nq + 2 * nkv) * D;
-    const float fpos = (float)pos;
     for (int it = threadIdx.x; it < (nq + nkv) * half; it += blockDim.x) {
         const int i = it % half, hh = it / half;           // hh < nq: q head, else k head
-        float sn, cs;
-        sincosf(fpos * inv_freq[i], &sn, &cs);
-        cs = Ty<T>::rnd(cs); sn = Ty<T>::rnd(sn);
+        const float2 csn = rope_cs[(long)pos * half + i];
+        const float cs = csn.x, sn = csn.y;
         T* v = row + (long)hh * D;
         const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
         const float y1 = x1 * cs - x2 * sn, y2 = x2 * cs + x1 * sn;
@@ -282,12 +293,36 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 // merged through LDS. Replaces cache concat + 4-D mask + SDPA (decoder/__init__.py:193-234, cache.py:57-105).
 // The q/k/v row comes either from a finished qkv buffer or, after a split-K projection, from the fp32 partial slabs
 // (qkv_part[S][M][qkv_dim], summed here with the bias: the launch-boundary reduce of the split-K GEMM).
+// RoPE factors come from a table built once per model: rope_cs[pos][i] = (cos, sin) of pos * inv_freq[i], already rounded
+// to the storage type as the reference does (decoder/__init__.py:361) -- no per-step sincosf.
+template <typename T, int EPL>
+__device__ __forceinline__ void load_slice(const T* p, float (&o)[EPL]) {      // EPL contiguous elements, widest loads
+    constexpr int BYTES = EPL * sizeof(T);
+    if constexpr (BYTES >= 16) {
+#pragma unroll
+        for (int c = 0; c < BYTES / 16; ++c) {
+            float t[Ty<T>::V16];
+            unpack16(*reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + c * 16), t, (T*)nullptr);
+#pragma unroll
+            for (int i = 0; i < Ty<T>::V16; ++i) o[c * Ty<T>::V16 + i] = t[i];
+        }
+    } else if constexpr (BYTES == 8 && sizeof(T) == 2) {
+        float t[4];
+        load4(p, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = t[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) o[i] = Ty<T>::ld(p + i);
+    }
+}
+
 template <typename T, int D, int MAXG>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_part, int S,
                                                           const T* __restrict__ qkv_bias, T* __restrict__ out,
                                                           T* __restrict__ kc, T* __restrict__ vc,
                                                           const int* __restrict__ active_slots, const int* __restrict__ kv_len,
-                                                          const float* __restrict__ inv_freq, int nq, int nkv, int Tmax,
+                                                          const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
                                                           float scale) {
     constexpr int EPL = D / 16;                 // head-dim elements per lane
     const int G = nq / nkv;
@@ -310,12 +345,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         return Ty<T>::ld(qkv + (long)a * qkv_dim + col);
     };
     const int half = D / 2;
-    const float fpos = (float)len;
     for (int it = tid; it < (G + 1) * half; it += 256) {
         const int i = it % half, hh = it / half;            // hh < G: q head of this group, hh == G: the k head
-        float sn, cs;
-        sincosf(fpos * inv_freq[i], &sn, &cs);
-        cs = Ty<T>::rnd(cs); sn = Ty<T>::rnd(sn);
+        const float2 csn = rope_cs[(long)len * half + i];
+        const float cs = csn.x, sn = csn.y;
         const int vcol = (hh < G) ? (kvh * G + hh) * D : (nq + kvh) * D;
         const float x1 = ldq(vcol + i), x2 = ldq(vcol + i + half);
         const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
@@ -342,29 +375,41 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
     const T* kb = kc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
     const T* vb = vc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
-    // keys 0..len-1 from the cache, key `len` (the new token) from LDS, handled by the group it falls to
-    for (int j = kg; j <= len; j += 16) {
-        float kf[EPL], vf[EPL];
-        if (j < len) {
+    // keys 0..len-1 from the cache, key `len` (the new token) from LDS. 4 keys per group are loaded before any of them
+    // is used (4 x 16 keys x 2 x 256 B in flight per workgroup): the first version walked one dependent K/V load pair
+    // per iteration and spent ~1.5 us of memory latency on each of them.
+    constexpr int UN = 4;
+    for (int j0 = kg; j0 <= len; j0 += 16 * UN) {
+        float kf[UN][EPL], vf[UN][EPL];
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) { kf[i] = Ty<T>::ld(kb + (long)j * D + i); vf[i] = Ty<T>::ld(vb + (long)j * D + i); }
-        } else {
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + 16 * u;
+            if (j < len) {
+                load_slice<T, EPL>(kb + (long)j * D, kf[u]);
+                load_slice<T, EPL>(vb + (long)j * D, vf[u]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) { kf[i] = knew[e * EPL + i]; vf[i] = vnew[e * EPL + i]; }
+                for (int i = 0; i < EPL; ++i) { kf[u][i] = knew[e * EPL + i]; vf[u][i] = vnew[e * EPL + i]; }
+            }
         }
 #pragma unroll
-        for (int h = 0; h < MAXG; ++h) {
-            if (h < G) {
-                float d = 0.f;
+        for (int u = 0; u < UN; ++u) {
+            if (j0 + 16 * u <= len) {              // uniform within the 16 lanes of a key group
 #pragma unroll
-                for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[i];
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-                const float mn = fmaxf(m[h], d);
-                const float al = __expf(m[h] - mn), pj = __expf(d - mn);
-                l[h] = l[h] * al + pj;
+                for (int h = 0; h < MAXG; ++h) {
+                    if (h < G) {
+                        float d = 0.f;
 #pragma unroll
-                for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[i];
-                m[h] = mn;
+                        for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[u][i];
+                        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                        const float mn = fmaxf(m[h], d);
+                        const float al = __expf(m[h] - mn), pj = __expf(d - mn);
+                        l[h] = l[h] * al + pj;
+#pragma unroll
+                        for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[u][i];
+                        m[h] = mn;
+                    }
+                }
             }
         }
     }

@@ -161,6 +161,7 @@ struct RecModel : RecBase {
     // decoder workspaces
     T *dx, *dh, *dqkv, *dattn, *dmlp, *dlast;
     float* logits;
+    float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
     float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
     int *kv_len, *next_token, *active_dev;
@@ -194,6 +195,7 @@ struct RecModel : RecBase {
         size_t o_dmlp = take(Tm * c.dec_inter * sizeof(T));
         size_t o_dlast = take(S * c.dec_hidden * sizeof(T));
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
+        size_t o_rope = take((size_t)c.max_kv_len * (c.dec_head_dim / 2) * sizeof(float2));
         size_t o_part = take((size_t)8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));
         const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
         size_t o_k = take(kv_elems * sizeof(T));
@@ -208,7 +210,7 @@ struct RecModel : RecBase {
             m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
             m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
             m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits);
-            m->part = (float*)(b + o_part);
+            m->part = (float*)(b + o_part); m->rope_cs = (float2*)(b + o_rope);
             m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
             m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active);
             m->out_token = (int*)(b + o_out);
@@ -225,6 +227,12 @@ struct RecModel : RecBase {
         arena_bytes = layout(c, nullptr);
         SA_HIP(hipMalloc((void**)&arena, arena_bytes));
         layout(c, this);
+        {
+            const int half = c.dec_head_dim / 2, n = c.max_kv_len * half;
+            hipLaunchKernelGGL(rope_table_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const float*>(w[SA_RW_DEC_INVFREQ]), rope_cs, c.max_kv_len, half);
+            SA_HIP(hipGetLastError());
+        }
         SA_HIP(hipMemset(kv_len, 0, c.max_slots * sizeof(int)));
         SA_HIP(hipMemset(next_token, 0, c.max_slots * sizeof(int)));
         SA_HIP(hipMemset(out_token, 0, out_bytes));
@@ -385,7 +393,7 @@ struct RecModel : RecBase {
             if ((rc = rmsnorm(dx, Hd, WD(l, SA_RD_LN1), dh, Hd, nullptr, M, Hd, c.dec_eps, s))) return rc;
             if ((rc = gemm<EPI_BIAS>(dh, Hd, WD(l, SA_RD_QKV_W), Hd, dqkv, qkv_d, WD(l, SA_RD_QKV_B), nullptr, 0, M, qkv_d, Hd, s)))
                 return rc;
-            hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, inv_freq, kc, vc,
+            hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, rope_cs, kc, vc,
                                nq, nkv, d, c.max_kv_len);
             if ((rc = attention(d, dqkv, kc, vc, dattn, *sg, n_tiles, nq, qkv_d, d, d, (long)c.max_kv_len * d, (long)nq * d, d,
                                 nq / nkv, 1, scale, s))) return rc;
@@ -427,15 +435,15 @@ struct RecModel : RecBase {
             T* vc = vcache + l * layer_kv;
             if ((rc = splitk_gemm(dh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, &S, s))) return rc;
             dim3 grid(M, nkv), block(256);
-#define SA_DEC(DD)                                                                                                          \
-    hipLaunchKernelGGL((decode_attn_kernel<T, DD, 8>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
-                       kc, vc, active_dev, kv_len, inv_freq, nq, nkv, c.max_kv_len, scale)
-            switch (d) {
-                case 32: SA_DEC(32); break;
-                case 64: SA_DEC(64); break;
-                case 128: SA_DEC(128); break;
-                default: return SA_ERR_UNSUPPORTED;
-            }
+#define SA_DEC(DD, GG)                                                                                                       \
+    hipLaunchKernelGGL((decode_attn_kernel<T, DD, GG>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
+                       kc, vc, active_dev, kv_len, rope_cs, nq, nkv, c.max_kv_len, scale)
+            const int G = nq / nkv;
+            if (d == 128 && G <= 5) SA_DEC(128, 5);
+            else if (d == 128) SA_DEC(128, 8);
+            else if (d == 64) SA_DEC(64, 8);
+            else if (d == 32) SA_DEC(32, 8);
+            else return SA_ERR_UNSUPPORTED;
 #undef SA_DEC
             if ((rc = (int)hipGetLastError())) return rc;
             if ((rc = splitk_gemm(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, &S, s))) return rc;
