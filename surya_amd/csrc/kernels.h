@@ -296,44 +296,59 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 // RoPE factors come from a table built once per model: rope_cs[pos][i] = (cos, sin) of pos * inv_freq[i], already rounded
 // to the storage type as the reference does (decoder/__init__.py:361) -- no per-step sincosf.
 template <typename T, int EPL>
-__device__ __forceinline__ void load_slice(const T* p, float (&o)[EPL]) {      // EPL contiguous elements, widest loads
-    constexpr int BYTES = EPL * sizeof(T);
-    if constexpr (BYTES >= 16) {
+struct RawSlice {                                   // EPL contiguous elements of one K/V row, kept packed in registers
+    static constexpr int NW = (EPL * (int)sizeof(T) + 3) / 4;
+    unsigned int w[NW];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (NW % 4 == 0) {
 #pragma unroll
-        for (int c = 0; c < BYTES / 16; ++c) {
-            float t[Ty<T>::V16];
-            unpack16(*reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + c * 16), t, (T*)nullptr);
+            for (int c = 0; c < NW / 4; ++c) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p) + c * 16);
+                w[c * 4] = v[0]; w[c * 4 + 1] = v[1]; w[c * 4 + 2] = v[2]; w[c * 4 + 3] = v[3];
+            }
+        } else if constexpr (NW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            w[0] = v.x; w[1] = v.y;
+        } else {
 #pragma unroll
-            for (int i = 0; i < Ty<T>::V16; ++i) o[c * Ty<T>::V16 + i] = t[i];
+            for (int c = 0; c < NW; ++c) w[c] = reinterpret_cast<const unsigned int*>(p)[c];
         }
-    } else if constexpr (BYTES == 8 && sizeof(T) == 2) {
-        float t[4];
-        load4(p, t);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = t[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) o[i] = Ty<T>::ld(p + i);
     }
-}
+    __device__ __forceinline__ float get(int i) const {          // i is a compile-time constant after unrolling
+        if constexpr (sizeof(T) == 4) return __uint_as_float(w[i]);
+        else return (i & 1) ? __uint_as_float(w[i >> 1] & 0xffff0000u) : __uint_as_float(w[i >> 1] << 16);
+    }
+};
 
 template <typename T, int D, int MAXG>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_part, int S,
                                                           const T* __restrict__ qkv_bias, T* __restrict__ out,
                                                           T* __restrict__ kc, T* __restrict__ vc,
-                                                          const int* __restrict__ active_slots, const int* __restrict__ kv_len,
+                                                          const int* __restrict__ active_slots, const int* __restrict__ row_len,
                                                           const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
                                                           float scale) {
     constexpr int EPL = D / 16;                 // head-dim elements per lane
+    constexpr int UN = 8;                       // keys per key-group loaded ahead: 128 cached keys in flight per workgroup
     const int G = nq / nkv;
     const int a = blockIdx.x, kvh = blockIdx.y;
     const int slot = active_slots[a];
-    const int len = kv_len[slot];               // cached tokens before this step == RoPE position of the new token
+    const int len = row_len[a];                 // cached tokens before this step == RoPE position of the new token
     const int tid = threadIdx.x, kg = tid >> 4, e = tid & 15;
     __shared__ float qs[MAXG * D];
     __shared__ float knew[D], vnew[D];
     __shared__ float mg[4 * MAXG], lg[4 * MAXG];
     __shared__ float accs[4 * MAXG * D];
+    const T* kb = kc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
+    const T* vb = vc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
+    // Cached K/V rows do not depend on this step's projections: start fetching the first UN keys of every key group
+    // BEFORE the q/k/v prologue so their HBM latency overlaps it (the kernel is a chain of dependent memory round trips).
+    RawSlice<T, EPL> kr[UN], vr[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int j = min(kg + 16 * u, max(len - 1, 0));          // clamped: rows >= len are never used
+        kr[u].load(kb + (long)j * D);
+        vr[u].load(vb + (long)j * D);
+    }
     const int qkv_dim = (nq + 2 * nkv) * D;
     const int Mrows = gridDim.x;
     auto ldq = [&](int col) -> float {              // element `col` of this row of the fused qkv projection
@@ -373,45 +388,57 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < EPL; ++i) { acc[h][i] = 0.f; qreg[h][i] = (h < G) ? qs[h * D + e * EPL + i] : 0.f; }
     }
-    const T* kb = kc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
-    const T* vb = vc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
-    // keys 0..len-1 from the cache, key `len` (the new token) from LDS. 4 keys per group are loaded before any of them
-    // is used (4 x 16 keys x 2 x 256 B in flight per workgroup): the first version walked one dependent K/V load pair
-    // per iteration and spent ~1.5 us of memory latency on each of them.
-    constexpr int UN = 4;
-    for (int j0 = kg; j0 <= len; j0 += 16 * UN) {
-        float kf[UN][EPL], vf[UN][EPL];
+    auto accumulate = [&](const float (&kf)[EPL], const float (&vf)[EPL]) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + 16 * u;
-            if (j < len) {
-                load_slice<T, EPL>(kb + (long)j * D, kf[u]);
-                load_slice<T, EPL>(vb + (long)j * D, vf[u]);
-            } else {
+        for (int h = 0; h < MAXG; ++h) {
+            if (h < G) {
+                float d = 0.f;
 #pragma unroll
-                for (int i = 0; i < EPL; ++i) { kf[u][i] = knew[e * EPL + i]; vf[u][i] = vnew[e * EPL + i]; }
+                for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[i];
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                const float mn = fmaxf(m[h], d);
+                const float al = __expf(m[h] - mn), pj = __expf(d - mn);
+                l[h] = l[h] * al + pj;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[i];
+                m[h] = mn;
             }
         }
+    };
+    // cached keys [0, min(len, 16 * UN)) from the preloaded registers
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (j0 + 16 * u <= len) {              // uniform within the 16 lanes of a key group
+    for (int u = 0; u < UN; ++u) {
+        if (kg + 16 * u < len) {                    // uniform within the 16 lanes of a key group
+            float kf[EPL], vf[EPL];
 #pragma unroll
-                for (int h = 0; h < MAXG; ++h) {
-                    if (h < G) {
-                        float d = 0.f;
+            for (int i = 0; i < EPL; ++i) { kf[i] = kr[u].get(i); vf[i] = vr[u].get(i); }
+            accumulate(kf, vf);
+        }
+    }
+    // longer contexts: the remaining cached keys, UN/2 per group in flight
+    for (int j0 = kg + 16 * UN; j0 < len; j0 += 16 * (UN / 2)) {
 #pragma unroll
-                        for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[u][i];
-                        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-                        const float mn = fmaxf(m[h], d);
-                        const float al = __expf(m[h] - mn), pj = __expf(d - mn);
-                        l[h] = l[h] * al + pj;
+        for (int u = 0; u < UN / 2; ++u) {
+            const int j = min(j0 + 16 * u, len - 1);
+            kr[u].load(kb + (long)j * D);
+            vr[u].load(vb + (long)j * D);
+        }
 #pragma unroll
-                        for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[u][i];
-                        m[h] = mn;
-                    }
-                }
+        for (int u = 0; u < UN / 2; ++u) {
+            if (j0 + 16 * u < len) {
+                float kf[EPL], vf[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) { kf[i] = kr[u].get(i); vf[i] = vr[u].get(i); }
+                accumulate(kf, vf);
             }
         }
+    }
+    // the new token's key/value (position len) from LDS, taken by the key group it falls to
+    if ((len & 15) == kg) {
+        float kf[EPL], vf[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) { kf[i] = knew[e * EPL + i]; vf[i] = vnew[e * EPL + i]; }
+        accumulate(kf, vf);
     }
     // merge the 4 key groups of each wave with shuffles, then the 4 waves through LDS
     const int wave = tid >> 6;
@@ -497,10 +524,13 @@ __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* 
 // Decode-step embedding fused with the first layer's input RMSNorm: x[a] = table[next_token[slot]], y[a] = norm(x[a]).
 template <typename T>
 __global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
-                                                              const int* __restrict__ active_slots, T* __restrict__ x,
+                                                              const int* __restrict__ active_slots, const int* __restrict__ kv_len,
+                                                              int* __restrict__ row_len, T* __restrict__ x,
                                                               const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
     const int a = blockIdx.x, lane = threadIdx.x;
-    const T* src = table + (long)next_token[active_slots[a]] * H;
+    const int slot = active_slots[a];
+    if (lane == 0) row_len[a] = kv_len[slot];      // compact per-row context length for this step's attention kernels
+    const T* src = table + (long)next_token[slot] * H;
     T* xr = x + (long)a * H;
     float ss = 0.f;
     for (int c = lane * 4; c < H; c += 256) {

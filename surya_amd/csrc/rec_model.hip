@@ -164,7 +164,7 @@ struct RecModel : RecBase {
     float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
     float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
-    int *kv_len, *next_token, *active_dev;
+    int *kv_len, *next_token, *active_dev, *row_len;
     int* out_token; float* out_score; int* out_bbox;     // [SA_MAX_STEPS][max_slots] (bbox x6)
     char* out_host = nullptr;                            // pinned mirror of the three output arrays
     size_t out_bytes = 0;
@@ -203,6 +203,7 @@ struct RecModel : RecBase {
         size_t o_kvlen = take(S * sizeof(int));
         size_t o_next = take(S * sizeof(int));
         size_t o_active = take(S * sizeof(int));
+        size_t o_rowlen = take(S * sizeof(int));
         size_t o_out = take((size_t)SA_MAX_STEPS * S * 8 * sizeof(int));
         if (m) {
             char* b = m->arena;
@@ -212,7 +213,7 @@ struct RecModel : RecBase {
             m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits);
             m->part = (float*)(b + o_part); m->rope_cs = (float2*)(b + o_rope);
             m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
-            m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active);
+            m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active); m->row_len = (int*)(b + o_rowlen);
             m->out_token = (int*)(b + o_out);
             m->out_score = (float*)(m->out_token + (size_t)SA_MAX_STEPS * S);
             m->out_bbox = (int*)(m->out_score + (size_t)SA_MAX_STEPS * S);
@@ -428,8 +429,8 @@ struct RecModel : RecBase {
         const size_t layer_kv = (size_t)c.max_slots * nkv * c.max_kv_len * d;
         const float* inv_freq = reinterpret_cast<const float*>(w[SA_RW_DEC_INVFREQ]);
         int rc, S = 1;
-        hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(M), dim3(64), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, dx,
-                           WD(0, SA_RD_LN1), dh, Hd, c.dec_eps);
+        hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(M), dim3(64), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, kv_len,
+                           row_len, dx, WD(0, SA_RD_LN1), dh, Hd, c.dec_eps);
         for (int l = 0; l < c.dec_layers; ++l) {
             T* kc = kcache + l * layer_kv;
             T* vc = vcache + l * layer_kv;
@@ -437,7 +438,7 @@ struct RecModel : RecBase {
             dim3 grid(M, nkv), block(256);
 #define SA_DEC(DD, GG)                                                                                                       \
     hipLaunchKernelGGL((decode_attn_kernel<T, DD, GG>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
-                       kc, vc, active_dev, kv_len, rope_cs, nq, nkv, c.max_kv_len, scale)
+                       kc, vc, active_dev, row_len, rope_cs, nq, nkv, c.max_kv_len, scale)
             const int G = nq / nkv;
             if (d == 128 && G <= 5) SA_DEC(128, 5);
             else if (d == 128) SA_DEC(128, 8);
