@@ -349,23 +349,37 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         kr[u].load(kb + (long)j * D);
         vr[u].load(vb + (long)j * D);
     }
+    // This row's q heads (G), k head and v head of the fused qkv projection -> LDS `xrow` as floats. After a split-K
+    // projection they are the sum of S fp32 slabs + bias; all S loads of a column are issued together (a runtime-bound
+    // `for s` loop makes hipcc wait for every load before the next one: ~1.5 us per slab per column).
     const int qkv_dim = (nq + 2 * nkv) * D;
     const int Mrows = gridDim.x;
-    auto ldq = [&](int col) -> float {              // element `col` of this row of the fused qkv projection
+    __shared__ float xrow[(MAXG + 2) * D];
+    for (int it = tid; it < (G + 2) * D; it += 256) {
+        const int hh = it / D, i = it % D;                  // hh < G: q head; G: k head; G + 1: v head
+        const int col = (hh < G ? (kvh * G + hh) * D : (hh == G ? (nq + kvh) * D : (nq + nkv + kvh) * D)) + i;
+        float val;
         if (qkv_part) {
-            float acc = Ty<T>::ld(qkv_bias + col);
-            for (int sidx = 0; sidx < S; ++sidx) acc += qkv_part[((long)sidx * Mrows + a) * qkv_dim + col];
-            return Ty<T>::rnd(acc);
+            float p8[8];
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx)
+                p8[sidx] = (sidx < S) ? qkv_part[((long)sidx * Mrows + a) * qkv_dim + col] : 0.f;
+            val = Ty<T>::ld(qkv_bias + col);
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) val += p8[sidx];
+            val = Ty<T>::rnd(val);
+        } else {
+            val = Ty<T>::ld(qkv + (long)a * qkv_dim + col);
         }
-        return Ty<T>::ld(qkv + (long)a * qkv_dim + col);
-    };
+        xrow[it] = val;
+    }
+    __syncthreads();
     const int half = D / 2;
     for (int it = tid; it < (G + 1) * half; it += 256) {
         const int i = it % half, hh = it / half;            // hh < G: q head of this group, hh == G: the k head
         const float2 csn = rope_cs[(long)len * half + i];
         const float cs = csn.x, sn = csn.y;
-        const int vcol = (hh < G) ? (kvh * G + hh) * D : (nq + kvh) * D;
-        const float x1 = ldq(vcol + i), x2 = ldq(vcol + i + half);
+        const float x1 = xrow[hh * D + i], x2 = xrow[hh * D + i + half];
         const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
         if (hh < G) {
             qs[hh * D + i] = y1 * scale; qs[hh * D + i + half] = y2 * scale;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         }
     }
     for (int i = tid; i < D; i += 256) {
-        const float val = ldq((nq + nkv + kvh) * D + i);
+        const float val = xrow[(G + 1) * D + i];
         vnew[i] = val;
         Ty<T>::st(vc + (((long)slot * nkv + kvh) * Tmax + len) * D + i, val);
     }
@@ -498,10 +512,12 @@ __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* 
             load4(bias + c, b);
             v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
-        for (int s = 0; s < S; ++s) {
-            const float4 p4 = *reinterpret_cast<const float4*>(part + ((long)s * M + row) * H + c);
-            v[0] += p4.x; v[1] += p4.y; v[2] += p4.z; v[3] += p4.w;
-        }
+        float4 p4[8];                              // all slabs in flight at once (S <= 8), see decode_attn_kernel
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            p4[s] = (s < S) ? *reinterpret_cast<const float4*>(part + ((long)s * M + row) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { v[0] += p4[s].x; v[1] += p4[s].y; v[2] += p4[s].z; v[3] += p4[s].w; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = Ty<T>::rnd(v[i]); ss += v[i] * v[i]; }
         store4(xr + c, v[0], v[1], v[2], v[3]);
