@@ -350,34 +350,46 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         vr[u].load(vb + (long)j * D);
     }
     // This row's q heads (G), k head and v head of the fused qkv projection -> LDS `xrow` as floats. After a split-K
-    // projection they are the sum of S fp32 slabs + bias; all S loads of a column are issued together (a runtime-bound
-    // `for s` loop makes hipcc wait for every load before the next one: ~1.5 us per slab per column).
+    // projection they are the sum of S fp32 slabs + bias. Every load of this phase (all slabs of all of this thread's
+    // columns, the RoPE factors, and the K/V preload above) is issued before the first wait: written as loops with
+    // runtime bounds hipcc waits for each load in turn, and the kernel becomes ~8 dependent memory round trips.
     const int qkv_dim = (nq + 2 * nkv) * D;
     const int Mrows = gridDim.x;
+    const int half = D / 2;
     __shared__ float xrow[(MAXG + 2) * D];
-    for (int it = tid; it < (G + 2) * D; it += 256) {
-        const int hh = it / D, i = it % D;                  // hh < G: q head; G: k head; G + 1: v head
+    const float2 csn = rope_cs[(long)len * half + (tid % half)];     // it % half == tid % half for every item of a thread
+    constexpr int NI = ((MAXG + 2) * D + 255) / 256;
+    const int n_items = (G + 2) * D;
+    float p8[NI][8], bias_v[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int it = min(tid + k * 256, n_items - 1);      // clamped: out-of-range items reload the last one, unused
+        const int hh = it / D, i = it % D;                   // hh < G: q head; G: k head; G + 1: v head
         const int col = (hh < G ? (kvh * G + hh) * D : (hh == G ? (nq + kvh) * D : (nq + nkv + kvh) * D)) + i;
-        float val;
         if (qkv_part) {
-            float p8[8];
 #pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx)
-                p8[sidx] = (sidx < S) ? qkv_part[((long)sidx * Mrows + a) * qkv_dim + col] : 0.f;
-            val = Ty<T>::ld(qkv_bias + col);
-#pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx) val += p8[sidx];
-            val = Ty<T>::rnd(val);
+            for (int sidx = 0; sidx < 8; ++sidx)             // slab index clamped too: no branches around the loads
+                p8[k][sidx] = qkv_part[((long)min(sidx, S - 1) * Mrows + a) * qkv_dim + col];
+            bias_v[k] = Ty<T>::ld(qkv_bias + col);
         } else {
-            val = Ty<T>::ld(qkv + (long)a * qkv_dim + col);
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) p8[k][sidx] = 0.f;
+            bias_v[k] = Ty<T>::ld(qkv + (long)a * qkv_dim + col);
         }
-        xrow[it] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        float val = bias_v[k];
+        if (qkv_part) {
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) val += (sidx < S) ? p8[k][sidx] : 0.f;
+            val = Ty<T>::rnd(val);
+        }
+        if (tid + k * 256 < n_items) xrow[tid + k * 256] = val;
     }
     __syncthreads();
-    const int half = D / 2;
     for (int it = tid; it < (G + 1) * half; it += 256) {
         const int i = it % half, hh = it / half;            // hh < G: q head of this group, hh == G: the k head
-        const float2 csn = rope_cs[(long)len * half + i];
         const float cs = csn.x, sn = csn.y;
         const float x1 = xrow[hh * D + i], x2 = xrow[hh * D + i + half];
         const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
@@ -512,12 +524,15 @@ __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* 
             load4(bias + c, b);
             v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
-        float4 p4[8];                              // all slabs in flight at once (S <= 8), see decode_attn_kernel
+        f32x4 p4[8];                               // all slabs in flight at once (S <= 8), see decode_attn_kernel
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            p4[s] = (s < S) ? *reinterpret_cast<const float4*>(part + ((long)s * M + row) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < 8; ++s)                // clamped slab index: unconditional loads, masked below
+            p4[s] = *reinterpret_cast<const f32x4*>(part + ((long)min(s, S - 1) * M + row) * H + c);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { v[0] += p4[s].x; v[1] += p4[s].y; v[2] += p4[s].z; v[3] += p4[s].w; }
+        for (int s = 0; s < 8; ++s) {
+            const float on = (s < S) ? 1.f : 0.f;
+            v[0] += on * p4[s][0]; v[1] += on * p4[s][1]; v[2] += on * p4[s][2]; v[3] += on * p4[s][3];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = Ty<T>::rnd(v[i]); ss += v[i] * v[i]; }
         store4(xr + c, v[0], v[1], v[2], v[3]);
