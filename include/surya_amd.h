@@ -153,8 +153,50 @@ int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y,
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Detection model: EfficientViT-L backbone + SegFormer-style decode head + sigmoid + x4 bilinear upsample.
+ * Replaces EfficientViTForSemanticSegmentation.forward (surya/detection/model/encoderdecoder.py:734-753) and the
+ * interpolate + .float() of DetectionPredictor.batch_detection (surya/detection/__init__.py:119-132).
+ * The network is described as a list of ops over NHWC activation buffers (built by surya_amd/detection/plan.py from
+ * the reference's state-dict; BatchNorm folded, 3x3 weights as [Cout][ky][kx][Cin] with K padded to x64).
+ * ---------------------------------------------------------------------------------------------------------- */
+enum { SA_DET_INPUT = 0,       /* fp32 NCHW pixels -> NHWC, channels padded to `cout`                      */
+       SA_DET_CONV,            /* dense KxK conv as implicit GEMM: bias, act, optional residual `res`        */
+       SA_DET_DWCONV,          /* depthwise KxK: weights [K*K][C], bias, act                                 */
+       SA_DET_GROUPED1X1,      /* grouped 1x1, p0 = channels per group (in == out)                           */
+       SA_DET_LITEMLA,         /* ReLU linear attention; in0 = qkv conv, in1 = aggregated qkv; p0 = head dim */
+       SA_DET_UPCAT,           /* bilinear resize of in0 into channels [p0, p0+cin) of `out` (cout wide)     */
+       SA_DET_CLASSIFY,        /* 1x1 conv to `cout` labels + sigmoid -> fp32 planes                         */
+       SA_DET_UPSAMPLE_OUT };  /* fp32 planes -> output size, bilinear                                       */
+enum { SA_ACT_NONE = 0, SA_ACT_HSWISH = 1, SA_ACT_RELU = 2 };
+
+typedef struct surya_det_op {
+    int32_t type;
+    int32_t in0, in1, out, res;      /* buffer ids (-1 = none) */
+    int32_t cin, cout, k, stride, act;
+    int32_t hin, win, hout, wout;
+    int32_t w_idx, b_idx;            /* weight-table indices (-1 = none) */
+    int32_t p0, p1;                  /* CONV: pad, Kpad; see the enum for others */
+} surya_det_op;
+
+typedef struct surya_det_config {
+    int32_t n_ops, max_batch, height, width, num_labels, dtype;
+} surya_det_config;
+
+typedef struct surya_det surya_det;
+
+/* buf_elems[i] = elements PER IMAGE of activation buffer i (the library allocates max_batch times that). */
+int surya_det_create(const surya_det_config* cfg, const surya_det_op* ops, const void* const* weights, int n_weights,
+                     const size_t* buf_elems, int n_bufs, surya_det** out);
+int surya_det_destroy(surya_det* h);
+/* pixel_values: device fp32 [batch, 3, H, W] (rescaled + ImageNet-normalised, surya/detection/processor.py:126-146).
+ * heatmaps: device fp32 [batch, labels, H, W] (may be NULL); lowres: device fp32 [batch, labels, H/4, W/4] (may be NULL)
+ * = the model's own output before the predictor-side upsample. Enqueue only. */
+int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): when enabled every GEMM launch is bracketed by hipEvents on its own
- * stream. surya_prof_read syncs the device and returns, per tile-configuration bucket (0: 128x128, 1: tall 256-row tiles, 2: smaller tiles),
+ * stream. surya_prof_read syncs the device and returns, per bucket (0: 128x128 GEMM, 1: tall 256-row GEMM tiles, 2: smaller GEMM tiles,
+ * 3: implicit-GEMM convolutions),
  * the number of launches, the summed event time (ms) and the summed ALGORITHMIC flops / bytes
  * (2MNK; X + W + C (+R) once each). Arrays need >= 4 entries. Not for use inside timed regions.
  * ---------------------------------------------------------------------------------------------------------- */

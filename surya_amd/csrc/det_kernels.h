@@ -1,0 +1,427 @@
+// Kernels of the text-detection forward pass (EfficientViT-L backbone + SegFormer-style head,
+// surya/detection/model/encoderdecoder.py) for gfx950. Activations are NHWC so that a conv's K axis
+// (ky, kx, ci) is contiguous per tap: dense convs run as implicit GEMMs on the MFMA tiles of gemm.h with the
+// A-tile gathered on the fly (no im2col buffer); BatchNorm is folded into weights/bias at load time.
+#pragma once
+#include "gemm.h"
+
+namespace sa {
+
+enum DetAct { ACT_NONE = 0, ACT_HSWISH = 1, ACT_RELU = 2 };
+
+// ---------------------------------------------------------------------------------------------------
+// pixel_values fp32 NCHW [B,3,H,W] -> NHWC with channels padded to CP (zeros), storage type T.
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int H, int W, int CP) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;      // pixel index over B*H*W
+    if (p >= (long)B * H * W) return;
+    const long hw = (long)H * W;
+    const long b = p / hw, r = p % hw;
+    T* o = out + p * CP;
+    for (int c = 0; c < CP; ++c) Ty<T>::st(o + c, c < C ? in[(b * C + c) * hw + r] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution: out[m, n] = act(sum_{ky,kx,ci} in[b, oy*s+ky-p, ox*s+kx-p, ci] * w[n, (ky,kx,ci)] + bias[n]) (+ res)
+//   m = (b, oy, ox) output pixel, weights [Cout][KH*KW*Cin padded to a multiple of the K-tile] (zero padded).
+// Same tile machinery as gemm_nt_kernel (2-deep register prefetch, swizzled LDS, weight fragment first); only the
+// A-operand fetch differs: a 16-byte chunk = 8 (bf16) / 4 (fp32) consecutive input channels of one tap, zero outside.
+template <typename T>
+struct ConvArgs {
+    const T* in; const T* w; T* out; const T* bias; const T* res;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, act;
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int KE = Ty<T>::KE, V = Ty<T>::V16;
+    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+    constexpr int XCH = BM * 8 / NT, WCH = BN * 8 / NT;
+    static_assert(XCH >= 1 && WCH >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int XBYTES = BM * 128, BUF = XBYTES + BN * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int ntaps = p.KH * p.KW;
+
+    // per-chunk constants: output pixel of the row, chunk position inside the 128-byte K-row
+    int xb[XCH], xiy[XCH], xix[XCH], xc[XCH], xdst[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int m = min(m0 + row, M - 1);
+        const int b = m / (p.Ho * p.Wo), r = m % (p.Ho * p.Wo);
+        xb[i] = b; xiy[i] = (r / p.Wo) * p.stride - p.pad; xix[i] = (r % p.Wo) * p.stride - p.pad;
+        xc[i] = c * V;
+        xdst[i] = row * 128 + ((c ^ (row & 7)) << 4);
+    }
+    const unsigned char* wsrc[WCH];
+    int wdst[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int gr = min(n0 + row, p.Cout - 1);
+        wsrc[i] = reinterpret_cast<const unsigned char*>(p.w + (long)gr * p.Kpad) + c * 16;
+        wdst[i] = XBYTES + row * 128 + ((c ^ (row & 7)) << 4);
+    }
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = p.Kpad / KE;
+    u32x4 xr0[XCH], wr0[WCH], xr1[XCH], wr1[WCH];
+#define SA_CFETCH(XR, WR, KT)                                                                                   \
+    {                                                                                                           \
+        const int kbase_ = (KT) * KE;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                       \
+            const int k0 = kbase_ + xc[i];                                                                      \
+            const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;                                                  \
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;                                                    \
+            const int iy = xiy[i] + ky, ix = xix[i] + kx;                                                       \
+            const bool ok = (tap < ntaps) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);                    \
+            const long off = ok ? ((((long)xb[i] * p.H + iy) * p.W + ix) * p.Cin + ci) : 0;                     \
+            u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in + off);                                             \
+            const unsigned int msk_ = ok ? 0xffffffffu : 0u;                                                    \
+            v_[0] &= msk_; v_[1] &= msk_; v_[2] &= msk_; v_[3] &= msk_;                                         \
+            XR[i] = v_;                                                                                         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                                         \
+            WR[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + (long)(KT) * 128);                                \
+    }
+#define SA_CSTASH(XR, WR, BUFP)                                                                 \
+    {                                                                                          \
+        unsigned char* b_ = (BUFP);                                                            \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) *reinterpret_cast<u32x4*>(b_ + xdst[i]) = XR[i];   \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];   \
+    }
+    const int frow = lane & 15, fch = lane >> 4;
+#define SA_CCOMPUTE(CURP)                                                                                      \
+    {                                                                                                          \
+        const unsigned char* cur_ = (CURP);                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            u32x4 xf[FM], wf[FN];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
+                const int row = wm * WTM + i * 16 + frow;                                                      \
+                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
+                const int row = wn * WTN + j * 16 + frow;                                                      \
+                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
+                _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<T>::run(acc[j][i], wf[j], xf[i]);          \
+        }                                                                                                      \
+    }
+    const int last = nk - 1;
+    SA_CFETCH(xr0, wr0, 0);
+    SA_CFETCH(xr1, wr1, min(1, last));
+    SA_CSTASH(xr0, wr0, smem);
+    __syncthreads();
+    const int pairs = nk >> 1;
+    for (int pi = 0; pi < pairs; ++pi) {
+        const int kt = 2 * pi;
+        SA_CFETCH(xr0, wr0, min(kt + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        SA_CCOMPUTE(smem);
+        __builtin_amdgcn_sched_barrier(0);
+        SA_CSTASH(xr1, wr1, smem + BUF);
+        __syncthreads();
+        SA_CFETCH(xr1, wr1, min(kt + 3, last));
+        __builtin_amdgcn_sched_barrier(0);
+        SA_CCOMPUTE(smem + BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        SA_CSTASH(xr0, wr0, smem);
+        __syncthreads();
+    }
+    if (nk & 1) SA_CCOMPUTE(smem);
+#undef SA_CFETCH
+#undef SA_CSTASH
+#undef SA_CCOMPUTE
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
+            if (n >= p.Cout) continue;
+            float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+            if (p.bias) {
+                float b[4];
+                load4(p.bias + n, b);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (p.act == ACT_HSWISH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (p.res) {
+                float r4[4];
+                load4(p.res + (long)m * p.Cout + n, r4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += r4[r];
+            }
+            store4(p.out + (long)m * p.Cout + n, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static inline int launch_conv_cfg(const ConvArgs<T>& a, hipStream_t s) {
+    const int M = a.B * a.Ho * a.Wo;
+    const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
+    constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
+    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    GemmProfiler& pf = gemm_profiler();
+    const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
+    if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+    if (prof) {
+        (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
+        pf.cfg_of[pf.n] = 3;       // profiler bucket 3 = implicit-GEMM convolutions
+        pf.flops_of[pf.n] = 2.0 * M * a.Cout * a.KH * a.KW * a.Cin;
+        pf.bytes_of[pf.n] = ((double)a.B * a.H * a.W * a.Cin + (double)a.Cout * a.Kpad + (double)M * a.Cout * (a.res ? 2 : 1)) * sizeof(T);
+        ++pf.n;
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
+    if (a.Cin % Ty<T>::V16 != 0 || a.Kpad % Ty<T>::KE != 0 || a.Cout % 4 != 0) return SA_ERR_SHAPE;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    if (a.Cout >= 128 && cdivl(M, 128) * cdiv(a.Cout, 128) >= 256) return launch_conv_cfg<T, 128, 128, 2, 2>(a, s);
+    if (a.Cout >= 64 && cdivl(M, 128) * cdiv(a.Cout, 64) >= 128) return launch_conv_cfg<T, 128, 64, 4, 1>(a, s);
+    if (a.Cout >= 64) return launch_conv_cfg<T, 64, 64, 2, 2>(a, s);
+    return launch_conv_cfg<T, 128, 32, 4, 1>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depthwise KxK convolution (NHWC), bias + activation. One thread = one output pixel x 8/4 channels (16 bytes).
+// HBM-bound: reads K*K input vectors per output vector (neighbours hit L1/L2).
+template <typename T>
+__global__ void dwconv_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ out,
+                              int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int act) {
+    constexpr int V = Ty<T>::V16;
+    const int cv = C / V;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Ho * Wo * cv) return;
+    const int c0 = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    float acc[V];
+    if (bias) unpack16(*reinterpret_cast<const uint4*>(bias + c0), acc, (T*)nullptr);
+    else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    }
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * stride + ky - pad;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < K; ++kx) {
+            const int ix = ox * stride + kx - pad;
+            if (ix < 0 || ix >= W) continue;
+            float xv[V], wv[V];
+            unpack16(*reinterpret_cast<const uint4*>(in + (((long)b * H + iy) * W + ix) * C + c0), xv, (T*)nullptr);
+            unpack16(*reinterpret_cast<const uint4*>(w + (long)(ky * K + kx) * C + c0), wv, (T*)nullptr);   // weights [K*K][C]
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += xv[i] * wv[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = act == ACT_HSWISH ? hardswish_f(acc[i]) : (act == ACT_RELU ? fmaxf(acc[i], 0.f) : acc[i]);
+    T* o = out + pix * C + c0;
+#pragma unroll
+    for (int i = 0; i < V; i += 4) store4(o + i, acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Grouped 1x1 convolution with group size GD in == GD out (LiteMLA aggreg[1], encoderdecoder.py:317):
+// out[p, g*GD + o] = sum_i in[p, g*GD + i] * w[g*GD + o][i]. Workgroup = 8 pixels x one group (GD <= 32 lanes each).
+template <typename T>
+__global__ __launch_bounds__(256) void grouped1x1_kernel(const T* __restrict__ in, const T* __restrict__ w, T* __restrict__ out,
+                                                         long P, int C, int GD) {
+    __shared__ float ws[32 * 33];
+    __shared__ float xs[8 * 32];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 8;
+    for (int i = tid; i < GD * GD; i += 256) ws[(i / GD) * 33 + (i % GD)] = Ty<T>::ld(w + (long)(g * GD + i / GD) * GD + (i % GD));
+    for (int i = tid; i < 8 * GD; i += 256) {
+        const long pp = p0 + i / GD;
+        xs[(i / GD) * 32 + (i % GD)] = pp < P ? Ty<T>::ld(in + pp * C + g * GD + (i % GD)) : 0.f;
+    }
+    __syncthreads();
+    const int pl = tid / 32, o = tid % 32;
+    if (o < GD && p0 + pl < P) {
+        float acc = 0.f;
+        for (int i = 0; i < GD; ++i) acc += xs[pl * 32 + i] * ws[o * 33 + i];
+        Ty<T>::st(out + (p0 + pl) * C + g * GD + o, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LiteMLA ReLU linear attention (encoderdecoder.py:332-359), fp32 like the reference's _attn:
+//   kv = relu(K)^T [V | 1]  (dim x dim+1),  out = relu(Q) kv,  out[:, :dim] / (out[:, dim] + eps)
+// One workgroup per (image, head). Heads [0, heads_a) read q|k|v from `qa` (the qkv conv), the rest from `qb` (the
+// multi-scale aggregation) -- the reference's channel concat (:349) is never materialised. dim <= 32.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void litemla_kernel(const T* __restrict__ qa, const T* __restrict__ qb, T* __restrict__ out,
+                                                      int HW, int heads_a, int heads, float eps) {
+    constexpr int dim = DIM;
+    __shared__ float ks[64 * 32];
+    __shared__ float vs[64 * 33];
+    __shared__ float kv[32 * 33];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int Ca = heads_a * 3 * dim, Cb = (heads - heads_a) * 3 * dim;
+    const T* src = h < heads_a ? qa + (long)b * HW * Ca + h * 3 * dim : qb + (long)b * HW * Cb + (h - heads_a) * 3 * dim;
+    const int C = h < heads_a ? Ca : Cb;
+    const int d1 = dim + 1, npair = dim * d1;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};        // pairs tid, tid+256, ... (dim 32: 1056 pairs -> <= 5 per thread)
+    for (int n0 = 0; n0 < HW; n0 += 64) {
+        const int nn = min(64, HW - n0);
+        for (int i = tid; i < nn * dim; i += 256) {
+            const int n = i / dim, c = i % dim;
+            const T* row = src + (long)(n0 + n) * C;
+            ks[n * 32 + c] = fmaxf(Ty<T>::ld(row + dim + c), 0.f);
+            vs[n * 33 + c] = Ty<T>::ld(row + 2 * dim + c);
+            if (c == 0) vs[n * 33 + dim] = 1.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int pr = tid + r * 256;
+            if (pr < npair) {
+                const int i = pr / d1, j = pr % d1;
+                float a = acc[r];
+                for (int n = 0; n < nn; ++n) a += ks[n * 32 + i] * vs[n * 33 + j];
+                acc[r] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int pr = tid + r * 256;
+        if (pr < npair) kv[(pr / d1) * 33 + (pr % d1)] = acc[r];
+    }
+    __syncthreads();
+    const int Cout = heads * dim;
+    for (int n = tid; n < HW; n += 256) {
+        const T* row = src + (long)n * C;
+        float q[DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) q[i] = fmaxf(Ty<T>::ld(row + i), 0.f);
+        float den = 0.f;                       // the appended ones-column of v: sum_i q_i * sum_n k_ni
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) den += q[i] * kv[i * 33 + DIM];
+        const float inv = 1.0f / (den + eps);
+        T* dst = out + ((long)b * HW + n) * Cout + h * dim;
+#pragma unroll 2
+        for (int j = 0; j < DIM; j += 4) {
+            float o4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) {
+                o4[0] += q[i] * kv[i * 33 + j]; o4[1] += q[i] * kv[i * 33 + j + 1];
+                o4[2] += q[i] * kv[i * 33 + j + 2]; o4[3] += q[i] * kv[i * 33 + j + 3];
+            }
+            store4(dst + j, o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bilinear resize (align_corners=False, torch semantics) of an NHWC map into a channel slice of a wider NHWC map:
+// dst[b, y, x, c_off + c] = bilinear(src[b, :, :, c]).  Used for the decode head's upsample + concat (:709-715).
+__device__ __forceinline__ void bilin_coeff(int d, int in_size, float scale, int& i0, int& i1, float& l1) {
+    float s = ((float)d + 0.5f) * scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ void upsample_concat_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Hs, int Ws, int C, int Hd, int Wd,
+                                       int Cd, int c_off) {
+    constexpr int V = Ty<T>::V16;
+    const int cv = C / V;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Hd * Wd * cv) return;
+    const int c0 = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % Wd), y = (int)((pix / Wd) % Hd), b = (int)(pix / ((long)Wd * Hd));
+    int y0, y1, x0, x1; float ly, lx;
+    bilin_coeff(y, Hs, (float)Hs / (float)Hd, y0, y1, ly);
+    bilin_coeff(x, Ws, (float)Ws / (float)Wd, x0, x1, lx);
+    float a[V], bq[V], c[V], d[V];
+    const T* base = src + (long)b * Hs * Ws * C + c0;
+    unpack16(*reinterpret_cast<const uint4*>(base + ((long)y0 * Ws + x0) * C), a, (T*)nullptr);
+    unpack16(*reinterpret_cast<const uint4*>(base + ((long)y0 * Ws + x1) * C), bq, (T*)nullptr);
+    unpack16(*reinterpret_cast<const uint4*>(base + ((long)y1 * Ws + x0) * C), c, (T*)nullptr);
+    unpack16(*reinterpret_cast<const uint4*>(base + ((long)y1 * Ws + x1) * C), d, (T*)nullptr);
+    T* o = dst + pix * Cd + c_off + c0;
+    float r[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+        r[i] = (1.f - ly) * ((1.f - lx) * a[i] + lx * bq[i]) + ly * ((1.f - lx) * c[i] + lx * d[i]);
+#pragma unroll
+    for (int i = 0; i < V; i += 4) store4(o + i, r[i], r[i + 1], r[i + 2], r[i + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Classifier 1x1 conv (C -> L labels, L <= 4) + sigmoid, NHWC in -> fp32 NCHW planes [B, L, H, W] (:720, :747).
+// One wave per pixel would waste lanes: a thread owns a pixel and walks its C channels in 16-byte steps.
+template <typename T>
+__global__ void classify_sigmoid_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias,
+                                        float* __restrict__ out, long P, long HW, int C, int L) {
+    constexpr int V = Ty<T>::V16;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* row = in + p * C;
+    for (int c = 0; c < C; c += V) {
+        float xv[V];
+        unpack16(*reinterpret_cast<const uint4*>(row + c), xv, (T*)nullptr);
+        for (int l = 0; l < L; ++l) {
+            float wv[V];
+            unpack16(*reinterpret_cast<const uint4*>(w + (long)l * C + c), wv, (T*)nullptr);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[l] += xv[i] * wv[i];
+        }
+    }
+    const long b = p / HW, r = p % HW;
+    for (int l = 0; l < L; ++l) {
+        const float z = Ty<T>::rnd(acc[l] + Ty<T>::ld(bias + l));
+        out[(b * L + l) * HW + r] = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));       // expit in the model dtype, then .float()
+    }
+}
+
+// fp32 planes [N, Hs, Ws] -> [N, Hd, Wd], bilinear align_corners=False (detection/__init__.py:121-129).
+__global__ void upsample_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * Hd * Wd) return;
+    const int x = (int)(idx % Wd), y = (int)((idx / Wd) % Hd);
+    const long n = idx / ((long)Wd * Hd);
+    int y0, y1, x0, x1; float ly, lx;
+    bilin_coeff(y, Hs, (float)Hs / (float)Hd, y0, y1, ly);
+    bilin_coeff(x, Ws, (float)Ws / (float)Wd, x0, x1, lx);
+    const float* s = src + n * Hs * Ws;
+    dst[idx] = (1.f - ly) * ((1.f - lx) * s[(long)y0 * Ws + x0] + lx * s[(long)y0 * Ws + x1]) +
+               ly * ((1.f - lx) * s[(long)y1 * Ws + x0] + lx * s[(long)y1 * Ws + x1]);
+}
+
+}  // namespace sa

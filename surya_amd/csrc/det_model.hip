@@ -1,0 +1,169 @@
+// Text-detection forward pass on MI355X: an op-list interpreter over NHWC activation buffers.
+// The Python loader (surya_amd/detection/plan.py) walks the EfficientViT-L + decode-head structure
+// (surya/detection/model/encoderdecoder.py:484-753), folds BatchNorm into weights/bias, lays the weights out for
+// the kernels and emits one `surya_det_op` per launch; this file owns the buffers and sequences the kernels.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/surya_amd.h"
+#include "det_kernels.h"
+
+namespace sa {
+
+struct DetBase {
+    virtual ~DetBase() {}
+    virtual int forward(const float* pixels, int B, float* heat, float* lowres, hipStream_t s) = 0;
+};
+
+template <typename T>
+struct DetModel : DetBase {
+    std::vector<surya_det_op> ops;
+    std::vector<const void*> w;
+    std::vector<size_t> buf_elems;       // per image
+    std::vector<T*> bufs;
+    float* planes = nullptr;             // [max_batch, labels, H/4, W/4] fp32
+    char* arena = nullptr;
+    int max_batch = 0, H = 0, W = 0, labels = 0, in_cp = 8;
+
+    int init(const surya_det_config& c, const surya_det_op* o, const void* const* weights, int n_weights, const size_t* be,
+             int n_bufs) {
+        ops.assign(o, o + c.n_ops);
+        w.assign(weights, weights + n_weights);
+        buf_elems.assign(be, be + n_bufs);
+        max_batch = c.max_batch; H = c.height; W = c.width; labels = c.num_labels;
+        size_t total = 0;
+        std::vector<size_t> offs(n_bufs);
+        for (int i = 0; i < n_bufs; ++i) { offs[i] = total; total += ((buf_elems[i] * max_batch * sizeof(T)) + 255) & ~(size_t)255; }
+        const size_t planes_off = total;
+        total += (size_t)max_batch * labels * (H / 4) * (W / 4) * sizeof(float) + 256;
+        SA_HIP(hipMalloc((void**)&arena, total));
+        bufs.resize(n_bufs);
+        for (int i = 0; i < n_bufs; ++i) bufs[i] = reinterpret_cast<T*>(arena + offs[i]);
+        planes = reinterpret_cast<float*>(arena + planes_off);
+        return SA_OK;
+    }
+    ~DetModel() override { if (arena) (void)hipFree(arena); }
+
+    const T* WT(int idx) const { return idx < 0 ? nullptr : reinterpret_cast<const T*>(w[idx]); }
+
+    int forward(const float* pixels, int B, float* heat, float* lowres, hipStream_t s) override {
+        if (B <= 0 || B > max_batch) return SA_ERR_ARG;
+        int rc;
+        for (const surya_det_op& op : ops) {
+            switch (op.type) {
+                case SA_DET_INPUT: {
+                    const long P = (long)B * op.hin * op.win;
+                    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels, bufs[op.out], B,
+                                       op.cin, op.hin, op.win, op.cout);
+                    break;
+                }
+                case SA_DET_CONV: {
+                    ConvArgs<T> a{bufs[op.in0], WT(op.w_idx), bufs[op.out], WT(op.b_idx), op.res >= 0 ? bufs[op.res] : nullptr,
+                                  B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.k, op.stride, op.p0, op.p1, op.act};
+                    if ((rc = launch_conv<T>(a, s))) return rc;
+                    break;
+                }
+                case SA_DET_DWCONV: {
+                    const long n = (long)B * op.hout * op.wout * (op.cin / Ty<T>::V16);
+                    hipLaunchKernelGGL(dwconv_kernel<T>, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx),
+                                       WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.k, op.stride, op.p0,
+                                       op.act);
+                    break;
+                }
+                case SA_DET_GROUPED1X1: {
+                    const long P = (long)B * op.hin * op.win;
+                    hipLaunchKernelGGL(grouped1x1_kernel<T>, dim3((unsigned)cdivl(P, 8), op.cin / op.p0), dim3(256), 0, s, bufs[op.in0],
+                                       WT(op.w_idx), bufs[op.out], P, op.cin, op.p0);
+                    break;
+                }
+                case SA_DET_LITEMLA: {
+                    const int HW = op.hin * op.win, heads = op.cout / op.p0, heads_a = heads / 2;
+                    dim3 grid(B, heads);
+                    if (op.p0 == 32)
+                        hipLaunchKernelGGL((litemla_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], bufs[op.out], HW,
+                                           heads_a, heads, 1e-5f);
+                    else if (op.p0 == 16)
+                        hipLaunchKernelGGL((litemla_kernel<T, 16>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], bufs[op.out], HW,
+                                           heads_a, heads, 1e-5f);
+                    else
+                        return SA_ERR_UNSUPPORTED;
+                    break;
+                }
+                case SA_DET_UPCAT: {
+                    const long n = (long)B * op.hout * op.wout * (op.cin / Ty<T>::V16);
+                    hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, s, bufs[op.in0],
+                                       bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.p0);
+                    break;
+                }
+                case SA_DET_CLASSIFY: {
+                    const long HWl = (long)op.hin * op.win, P = (long)B * HWl;
+                    hipLaunchKernelGGL(classify_sigmoid_kernel<T>, dim3((unsigned)cdivl(P, 128)), dim3(128), 0, s, bufs[op.in0],
+                                       WT(op.w_idx), WT(op.b_idx), planes, P, HWl, op.cin, op.cout);
+                    if (lowres)
+                        SA_HIP(hipMemcpyAsync(lowres, planes, (size_t)P * op.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    break;
+                }
+                case SA_DET_UPSAMPLE_OUT: {
+                    if (!heat) break;
+                    const long n = (long)B * op.cout * op.hout * op.wout;
+                    hipLaunchKernelGGL(upsample_planes_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, s, planes, heat,
+                                       B * op.cout, op.hin, op.win, op.hout, op.wout);
+                    break;
+                }
+                default: return SA_ERR_UNSUPPORTED;
+            }
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        return SA_OK;
+    }
+};
+
+}  // namespace sa
+
+using namespace sa;
+struct surya_det { std::unique_ptr<DetBase> impl; };
+
+extern "C" {
+
+int surya_det_create(const surya_det_config* cfg, const surya_det_op* ops, const void* const* weights, int n_weights,
+                     const size_t* buf_elems, int n_bufs, surya_det** out) {
+    if (!cfg || !ops || !weights || !buf_elems || !out || cfg->n_ops <= 0 || n_bufs <= 0 || cfg->max_batch <= 0) return SA_ERR_ARG;
+    if (cfg->height % 32 || cfg->width % 32 || cfg->num_labels < 1 || cfg->num_labels > 4) return SA_ERR_SHAPE;
+    for (int i = 0; i < cfg->n_ops; ++i) {
+        const surya_det_op& o = ops[i];
+        if (o.out >= n_bufs || o.in0 >= n_bufs || o.in1 >= n_bufs || o.res >= n_bufs || o.w_idx >= n_weights || o.b_idx >= n_weights)
+            return SA_ERR_ARG;
+    }
+    auto* h = new surya_det();
+    int rc;
+    if (cfg->dtype == SA_DTYPE_F32) {
+        auto m = std::make_unique<DetModel<float>>();
+        rc = m->init(*cfg, ops, weights, n_weights, buf_elems, n_bufs);
+        h->impl = std::move(m);
+    } else if (cfg->dtype == SA_DTYPE_BF16) {
+        auto m = std::make_unique<DetModel<bf16_t>>();
+        rc = m->init(*cfg, ops, weights, n_weights, buf_elems, n_bufs);
+        h->impl = std::move(m);
+    } else {
+        rc = SA_ERR_UNSUPPORTED;
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return SA_OK;
+}
+
+int surya_det_destroy(surya_det* h) {
+    if (!h) return SA_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    delete h;
+    return SA_OK;
+}
+
+int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream) {
+    if (!h || !pixel_values || (!heatmaps && !lowres)) return SA_ERR_ARG;
+    return h->impl->forward(pixel_values, batch, heatmaps, lowres, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""HipDetModel: the detection forward pass behind libsurya_amd.so (no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..config import DetConfig
+from .plan import build_det_plan
+
+
+class DetOpC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("type", "in0", "in1", "out", "res", "cin", "cout", "k", "stride", "act", "hin", "win",
+                                         "hout", "wout", "w_idx", "b_idx", "p0", "p1")]
+
+
+class HipDetModel:
+    def __init__(self, cfg: DetConfig, state_dict, *, height: int, width: int, dtype: torch.dtype = torch.bfloat16,
+                 device="cuda:0", max_batch: int = 16):
+        if not torch.cuda.is_available():
+            raise L.SuryaAmdError("HipDetModel needs a GPU (MI355X); there is no CPU fallback")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be float32 (reference mode) or bfloat16")
+        self.lib = L.lib()
+        self.lib.surya_det_create.argtypes = None
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.height, self.width, self.max_batch = height, width, max_batch
+        torch.cuda.set_device(self.device)
+        plan = build_det_plan(cfg, state_dict, height, width)
+        self.flops_per_image = plan.flops_per_image
+        self.weights = [w.to(device=self.device, dtype=dtype).contiguous() for w in plan.weights]
+        ops = (DetOpC * len(plan.ops))(*[DetOpC(**o) for o in plan.ops])
+        table = (C.c_void_p * len(self.weights))(*[w.data_ptr() for w in self.weights])
+        bufs = (C.c_size_t * len(plan.buf_elems))(*plan.buf_elems)
+        c = L.DetConfigC(n_ops=len(plan.ops), max_batch=max_batch, height=height, width=width, num_labels=cfg.num_labels,
+                         dtype=L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16)
+        self.handle = C.c_void_p()
+        L.check(self.lib.surya_det_create(C.byref(c), ops, table, len(self.weights), bufs, len(plan.buf_elems),
+                                          C.byref(self.handle)), "surya_det_create")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.surya_det_destroy(h)
+            self.handle = None
+
+    def forward(self, pixel_values: torch.Tensor, want_lowres: bool = False):
+        """pixel_values cuda fp32 [B,3,H,W] -> heatmaps fp32 [B, labels, H, W] (and [B, labels, H/4, W/4])."""
+        assert pixel_values.is_cuda and pixel_values.dtype == torch.float32 and pixel_values.is_contiguous()
+        B = pixel_values.shape[0]
+        assert tuple(pixel_values.shape[1:]) == (self.cfg.num_channels, self.height, self.width) and B <= self.max_batch
+        torch.cuda.set_device(self.device)
+        heat = torch.empty((B, self.cfg.num_labels, self.height, self.width), dtype=torch.float32, device=self.device)
+        low = torch.empty((B, self.cfg.num_labels, self.height // 4, self.width // 4), dtype=torch.float32,
+                          device=self.device) if want_lowres else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.surya_det_forward(self.handle, L.ptr(pixel_values), C.c_int(B), L.ptr(heat), L.ptr(low), stream),
+                "surya_det_forward")
+        return (heat, low) if want_lowres else heat
