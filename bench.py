@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--max-tokens", type=int, default=48)
     ap.add_argument("--steps-per-sync", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-det", action="store_true", help="skip the detection leg (pages/s)")
+    ap.add_argument("--det-config", default="DET-DEFAULT")
+    ap.add_argument("--det-pages", type=int, default=16)
+    ap.add_argument("--det-size", type=int, default=1024)
+    ap.add_argument("--det-steps", type=int, default=5)
     ap.add_argument("--cpu-lines", type=int, default=8)
     return ap.parse_args()
 
@@ -70,6 +75,73 @@ def cpu_baseline(cfg, sd, prep, n_lines, max_tokens):
     return {"value": round(n_lines / dt, 4), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_lines} of the same crops, max_tokens={max_tokens}, fp32 oracle incl. encoder+prefill+decode, "
                       f"{sum(len(t) for t in toks)} tokens in {dt:.1f}s"}
+
+
+def read_profile(lib, L):
+    n = 4
+    launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
+    L.check(lib.surya_prof_read(n, launches, ms, fl, by), "surya_prof_read")
+    names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)",
+             "gemm_nt small tiles", "conv_gemm (implicit-GEMM convolutions, NHWC)"]
+    return [{"kernel": names[i], "launches": launches[i], "ms": ms[i], "tflops": (fl[i] / ms[i] / 1e9) if ms[i] else 0.0,
+             "gbs": (by[i] / ms[i] / 1e6) if ms[i] else 0.0} for i in range(n) if launches[i]]
+
+
+def bench_det(args, local_rank, world, rank, barrier):
+    """Detection leg (BASELINE.json configs[2]): DetectionPredictor's model forward over 16 synthetic 1024^2 pages per GPU,
+    bf16, pixel_values resident in HBM -> fp32 heat maps on device. pages/s, roofline of the conv kernel, CPU oracle."""
+    from surya_amd import _lib as L
+    from surya_amd.config import det_config
+    from surya_amd.detection.model import HipDetModel
+    from surya_amd.synth import make_det_weights, make_pages
+    from oracle import det_oracle as do
+    cfg = det_config(args.det_config)
+    sd = make_det_weights(cfg, 0)
+    m = HipDetModel(cfg, sd, height=args.det_size, width=args.det_size, dtype=torch.bfloat16, device=f"cuda:{local_rank}",
+                    max_batch=args.det_pages)
+    pages = make_pages(args.det_pages, args.det_size, seed=1234 + rank)
+    x = do.normalise_pages(pages).cuda().contiguous()       # input normalisation only (host logic), not the measured path
+    for _ in range(2):
+        m.forward(x)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.det_steps):
+        heat = m.forward(x)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = None
+    if rank == 0:
+        lib = L.lib()
+        lib.surya_prof_enable(1)
+        m.forward(x)
+        cats = read_profile(lib, L)
+        lib.surya_prof_enable(0)
+        dom = max(cats, key=lambda c: c["ms"])
+        out = {"metric": "pages/sec detected (model forward, whole node)", "value": round(args.det_pages * world * args.det_steps / dt, 2),
+               "unit": "pages/s", "ms_per_step": round(dt / args.det_steps * 1e3, 2),
+               "config": {"workload": f"{args.det_pages} synthetic {args.det_size}x{args.det_size} pages/GPU, {args.det_config} synthetic weights, bf16, "
+                                      f"pixel_values in HBM -> fp32 heat maps in HBM", "gflop_per_page": round(m.flops_per_image / 1e9, 1)},
+               "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                            "whole_forward_tflops": round(m.flops_per_image * args.det_pages * args.det_steps / dt / 1e12, 2)},
+               "cpu_baseline": None}
+        if world == 1 and not args.no_cpu_baseline:
+            xs = do.normalise_pages(pages[:1])
+            do.heatmaps(sd, cfg, xs)
+            t0 = time.perf_counter()
+            do.heatmaps(sd, cfg, xs); do.heatmaps(sd, cfg, xs)
+            c = (time.perf_counter() - t0) / 2
+            out["cpu_baseline"] = {"value": round(1.0 / c, 3), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"1 of the same pages x2 after a warm-up, fp32 oracle (bit-identical to the reference module), {c:.2f}s/page"}
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -146,14 +218,8 @@ def main():
     if rank == 0:
         lib.surya_prof_enable(1)
         pred.generate(prep, args.batch)
-        n = 4
-        launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
-        L.check(lib.surya_prof_read(n, launches, ms, fl, by), "surya_prof_read")
+        cats = read_profile(lib, L)
         lib.surya_prof_enable(0)
-        names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)",
-                 "gemm_nt small tiles", "other"]
-        cats = [{"kernel": names[i], "launches": launches[i], "ms": ms[i], "tflops": (fl[i] / ms[i] / 1e9) if ms[i] else 0.0,
-                 "gbs": (by[i] / ms[i] / 1e6) if ms[i] else 0.0} for i in range(n) if launches[i]]
         dom = max(cats, key=lambda c: c["ms"])
         mfma_bound = dom["kernel"].startswith("gemm_nt 128")
         ach, peak, unit = (dom["tflops"], PEAK_BF16_TFLOPS, "TFLOP/s") if mfma_bound else (dom["gbs"], PEAK_HBM_GBS, "GB/s")
@@ -166,6 +232,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sd, prep, min(args.cpu_lines, args.lines), args.max_tokens)
 
+    det = None
+    if not args.no_det:
+        del pred
+        torch.cuda.empty_cache()
+        det = bench_det(args, local_rank, world, rank, barrier)
+
     if rank == 0:
         lines_total = args.lines * world * args.steps
         out = {
@@ -176,7 +248,7 @@ def main():
                                    f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
                        "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
                        "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "detection": det,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,153 @@
+"""DetectionPredictor: drop-in for surya.detection.DetectionPredictor on MI355X.
+
+Same call signature / result schema (surya/detection/__init__.py:22-48, detection/schema.py:12-17). The model forward,
+sigmoid and x4 upsample run in libsurya_amd.so (HipDetModel); tall-page splitting, PIL resizing and heat-map -> box
+post-processing stay on the host as in the reference. No CPU fallback for the model.
+"""
+from __future__ import annotations
+
+import math
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Generator, List, Tuple
+
+import numpy as np
+import torch
+from PIL import Image, ImageOps
+
+from ..common.predictor import BasePredictor, ModelLoader
+from ..config import DetConfig, det_config
+from ..settings import settings
+from .heatmap import TextDetectionResult, parallel_get_boxes
+from .model import HipDetModel
+
+
+class SegformerImageProcessor:
+    """rescale 1/255 + ImageNet normalise -> CHW float32 (surya/detection/processor.py:126-146); `size` from the checkpoint."""
+    image_mean = np.array([0.485, 0.456, 0.406], np.float32)
+    image_std = np.array([0.229, 0.224, 0.225], np.float32)
+
+    def __init__(self, size=None):
+        self.size = size or {"height": 512, "width": 512}
+
+    def __call__(self, image: np.ndarray):
+        a = (image.astype(np.float32) * np.float32(1 / 255.0) - self.image_mean) / self.image_std
+        return {"pixel_values": [np.ascontiguousarray(a.transpose(2, 0, 1))]}
+
+
+def get_total_splits(image_size, height):              # surya/detection/util.py:7-13
+    return math.ceil(image_size[1] / height) if image_size[1] > settings.DETECTOR_IMAGE_CHUNK_HEIGHT else 1
+
+
+def split_image(img: Image.Image, height: int):
+    """Tall pages (> DETECTOR_IMAGE_CHUNK_HEIGHT px) are cut into `height`-px strips, the last one white-padded
+    (surya/detection/util.py:16-36)."""
+    ih = img.size[1]
+    if ih <= settings.DETECTOR_IMAGE_CHUNK_HEIGHT:
+        return [img.copy()], [ih]
+    parts, heights = [], []
+    for i in range(math.ceil(ih / height)):
+        top, bottom = i * height, min((i + 1) * height, ih)
+        crop = img.crop((0, top, img.size[0], bottom))
+        if bottom - top < height:
+            crop = ImageOps.pad(crop, (img.size[0], height), color=255, centering=(0, 0))
+        parts.append(crop)
+        heights.append(bottom - top)
+    return parts, heights
+
+
+class DetectionModelLoader(ModelLoader):
+    """checkpoint: None / config name (synthetic weights) or {"config": DetConfig, "state_dict": ..., "size": int}."""
+
+    def __init__(self, checkpoint=None):
+        super().__init__(checkpoint)
+        ck = checkpoint
+        if isinstance(ck, dict):
+            self._cfg, self._sd, self._size = ck["config"], ck["state_dict"], int(ck.get("size", 1024))
+        else:
+            from ..synth import make_det_weights
+            self._cfg = det_config(ck if isinstance(ck, str) else settings.SURYA_AMD_DET_CONFIG)
+            self._sd = make_det_weights(self._cfg, 0)
+            self._size = int(os.environ.get("SURYA_AMD_DET_SIZE", "1024"))
+
+    def model(self, device=None, dtype=None, max_batch=None) -> HipDetModel:
+        if device is None or device == "cuda":
+            device = "cuda:0"
+        if dtype is None:
+            dtype = torch.bfloat16        # the reference picks fp16 on GPUs (detection/loader.py:31); BASELINE asks bf16
+        mb = max_batch or settings.DETECTOR_BATCH_SIZE or DetectionPredictor.default_batch_sizes["cuda"]
+        return HipDetModel(self._cfg, self._sd, height=self._size, width=self._size, dtype=dtype, device=device, max_batch=mb)
+
+    def processor(self, device=None, dtype=None) -> SegformerImageProcessor:
+        return SegformerImageProcessor({"height": self._size, "width": self._size})
+
+
+class DetectionPredictor(BasePredictor):
+    model_loader_cls = DetectionModelLoader
+    batch_size = settings.DETECTOR_BATCH_SIZE
+    default_batch_sizes = {"cpu": 8, "mps": 8, "cuda": 36, "xla": 18}
+
+    def __call__(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        gen = self.batch_detection(images, batch_size=batch_size)
+        futures = []
+        workers = max(1, min(settings.DETECTOR_POSTPROCESSING_CPU_WORKERS, len(images)))
+        if len(images) >= settings.DETECTOR_MIN_PARALLEL_THRESH:
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                for preds, sizes in gen:
+                    futures.extend(ex.submit(parallel_get_boxes, p, s, include_maps) for p, s in zip(preds, sizes))
+            return [f.result() for f in futures]
+        out = []
+        for preds, sizes in gen:
+            out.extend(parallel_get_boxes(p, s, include_maps) for p, s in zip(preds, sizes))
+        return out
+
+    def prepare_image(self, img: Image.Image) -> torch.Tensor:
+        new_size = (self.processor.size["width"], self.processor.size["height"])
+        img.thumbnail(new_size, Image.Resampling.LANCZOS)          # the reference's double resize (:50-57)
+        img = img.resize(new_size, Image.Resampling.LANCZOS)
+        arr = np.asarray(img, dtype=np.uint8)
+        return torch.from_numpy(self.processor(arr)["pixel_values"][0])
+
+    def batch_detection(self, images: List, batch_size=None) -> Generator[Tuple[List[List[np.ndarray]], List[Tuple[int, int]]], None, None]:
+        assert all(isinstance(im, Image.Image) for im in images)
+        if batch_size is None:
+            batch_size = self.get_batch_size()
+        batch_size = min(batch_size, self.model.max_batch)
+        nlab = self.model.cfg.num_labels
+        ph = self.processor.size["height"]
+        orig_sizes = [im.size for im in images]
+        splits = [get_total_splits(s, ph) for s in orig_sizes]
+        batches, cur, cur_n = [], [], 0
+        for i in range(len(images)):                               # greedy packing by tile count (:77-90)
+            if cur_n + splits[i] > batch_size:
+                if cur:
+                    batches.append(cur)
+                cur, cur_n = [], 0
+            cur.append(i)
+            cur_n += splits[i]
+        if cur:
+            batches.append(cur)
+        for idxs in batches:
+            batch_images = [images[j].convert("RGB") for j in idxs]
+            split_index, split_heights, parts = [], [], []
+            for k, im in enumerate(batch_images):
+                ps, hs = split_image(im, ph)
+                parts.extend(ps)
+                split_index.extend([k] * len(ps))
+                split_heights.extend(hs)
+            tiles = torch.stack([self.prepare_image(p) for p in parts], 0).contiguous()
+            heat_parts = []
+            for s in range(0, tiles.shape[0], self.model.max_batch):        # a single page may exceed max_batch tiles
+                chunk = tiles[s: s + self.model.max_batch].pin_memory().to(self.model.device, non_blocking=True)
+                heat_parts.append(self.model.forward(chunk))
+            logits = torch.cat(heat_parts, 0).cpu().numpy()                 # fp32, one D2H per batch (:132)
+            preds: List[List[np.ndarray]] = []
+            for i, (idx, height) in enumerate(zip(split_index, split_heights)):
+                maps = [logits[i][k] for k in range(nlab)]
+                if len(preds) <= idx:
+                    preds.append(maps)
+                else:
+                    if height < ph:
+                        maps = [m[:height, :] for m in maps]               # cut the white padding of the last strip
+                    preds[idx] = [np.vstack([preds[idx][k], maps[k]]) for k in range(nlab)]
+            yield preds, [orig_sizes[j] for j in idxs]

@@ -134,3 +134,41 @@ def test_words_from_chars_and_fix_tags():
     cs = [TextChar(text="<b>", polygon=[0, 0, 1, 1], bbox_valid=False), TextChar(text="x", polygon=[0, 0, 1, 1])]
     out = pp.fix_unbalanced_tags(cs, st)
     assert out[-1].text == "</b>"
+
+
+# ------------------------------------------------------------------------------------------- detection host logic
+def test_heatmap_boxes_on_synthetic_map():
+    from surya_amd.detection import heatmap as hm
+    m = np.full((128, 256), 0.05, np.float32)
+    m[20:32, 30:200] = 0.9                      # a wide line
+    m[60:70, 40:90] = 0.8                       # a short line
+    m[100:103, 10:13] = 0.9                     # 9 px: below the area filter
+    res = hm.parallel_get_boxes([m, m], (512, 256))
+    assert len(res.bboxes) == 2 and res.image_bbox == [0, 0, 512, 256]
+    b = sorted(res.bboxes, key=lambda b: b.bbox[1])[0]
+    # map (256 wide, 128 tall) -> image (512, 256): x2 both ways; dilation grows the box by ~sqrt(12)+1 px before rescale
+    assert 50 <= b.bbox[0] <= 60 and 398 <= b.bbox[2] <= 410 and 28 <= b.bbox[1] <= 40 and 64 <= b.bbox[3] <= 76
+    assert b.polygon[0][0] < b.polygon[1][0] and b.polygon[1][1] < b.polygon[2][1]      # TL, TR, BR, BL order
+    assert max(bb.confidence for bb in res.bboxes) == 1.0
+
+
+def test_dilate_and_min_area_rect():
+    from surya_amd.detection import heatmap as hm
+    m = np.zeros((9, 9), bool)
+    m[4, 4] = True
+    assert hm.dilate_rect(m, 3).sum() == 9 and hm.dilate_rect(m, 3)[3:6, 3:6].all()
+    d2 = hm.dilate_rect(m, 2)                   # even kernel: anchor k//2 = 1 -> window covers offsets [-1, 0]
+    assert d2.sum() == 4 and d2[4:6, 4:6].all()
+    pts = np.array([[0, 0], [10, 10], [12, 8], [2, -2]])        # a 45-degree rectangle
+    box = hm.min_area_rect_points(pts)
+    area = np.linalg.norm(box[0] - box[1]) * np.linalg.norm(box[1] - box[2])
+    assert abs(area - 40.0) < 1e-3
+
+
+def test_split_image_and_packing():
+    from PIL import Image
+    from surya_amd.detection.predictor import split_image, get_total_splits
+    img = Image.new("RGB", (300, 2500), "white")
+    parts, heights = split_image(img, 1024)
+    assert [p.size for p in parts] == [(300, 1024)] * 3 and heights == [1024, 1024, 452]
+    assert get_total_splits((300, 2500), 1024) == 3 and get_total_splits((300, 1400), 1024) == 1
