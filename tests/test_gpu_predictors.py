@@ -1,0 +1,122 @@
+"""GPU: the drop-in predictors end to end (host logic + HIP model) on synthetic pages / crops.
+
+Checks call signatures, output schemas and -- for recognition -- that the predictor's continuous-batching
+scheduler yields exactly the oracle's token stream for every line, for several batch sizes and steps-per-sync settings
+(results must not depend on scheduling)."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import rec_oracle as ro
+from oracle import det_oracle as do
+from surya_amd.config import rec_config, det_config
+from surya_amd.settings import settings
+from surya_amd.synth import make_rec_weights, make_det_weights, make_line_crops, make_pages
+
+pytestmark = pytest.mark.gpu
+
+
+def make_rec_predictor(cfg_name="REC-TINY", dtype=torch.float32, max_slots=8, max_tokens=16):
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    cfg = rec_config(cfg_name)
+    sd = make_rec_weights(cfg, 0)
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype_=None, **caps):
+            return super().model("cuda:0", dtype, max_slots=max_slots, max_kv_len=512, max_patches=8192, max_prefill_tokens=2048)
+
+    class Pred(RecognitionPredictor):
+        model_loader_cls = Loader
+        batch_size = max_slots
+
+    settings.RECOGNITION_MAX_TOKENS = max_tokens
+    return cfg, sd, Pred(checkpoint={"config": cfg, "state_dict": sd})
+
+
+def oracle_tokens(cfg, sd, pred, crops, max_tokens):
+    """Oracle on the predictor's own pre-processed prompts (same tiles / ids), one line at a time."""
+    from surya_amd.recognition.schema import TaskNames
+    flat = {"slices": crops, "input_text": [None] * len(crops), "task_names": [TaskNames.ocr_with_boxes] * len(crops)}
+    prep = pred.prepare_lines(flat, math_mode=True)
+    out = []
+    tiles = prep["tiles"].cpu()
+    for i in range(len(crops)):
+        a, b = int(prep["tile_offs"][i]), int(prep["tile_offs"][i + 1])
+        ids = torch.tensor([prep["prompt_ids"][i]])
+        am = torch.ones_like(ids)
+        pos = torch.arange(ids.shape[1])[None]
+        om = ro.OracleRecModel(cfg, sd, cfg.image_token_id)
+        t, _, _, _ = ro.generate(om, ids, tiles[a:b], [(1,) + tuple(prep["grids"][i])], am, pos, max_tokens, cfg.eos_token_id,
+                                 cfg.pad_token_id, cfg.nop_token_id)
+        out.append(t[0])
+    return prep, out
+
+
+@pytest.mark.parametrize("batch,steps_per_sync", [(8, 1), (3, 4), (5, 16)])
+def test_scheduler_tokens_equal_oracle(hip_lib, batch, steps_per_sync):
+    cfg, sd, pred = make_rec_predictor(max_slots=8, max_tokens=14)
+    crops = [c.astype(np.float32) for c in make_line_crops(11, seed=3)]
+    crops.sort(key=lambda c: -c.shape[1])
+    prep, ref = oracle_tokens(cfg, sd, pred, crops, 14)
+    settings.RECOGNITION_STEPS_PER_SYNC = steps_per_sync
+    toks, boxes, scores = pred.generate(prep, batch)
+    settings.RECOGNITION_STEPS_PER_SYNC = 4
+    assert [list(t) for t in toks] == ref
+    assert boxes.shape == (11, 14, 6) and all(len(s) == len(t) for s, t in zip(scores, toks))
+
+
+def test_recognition_predictor_call_schema(hip_lib):
+    from surya_amd.recognition.schema import OCRResult
+    cfg, sd, pred = make_rec_predictor(max_slots=4, max_tokens=10)
+    page = Image.fromarray(make_pages(1, 256, seed=5)[0])
+    bboxes = [[[10, 20, 200, 52], [12, 80, 120, 110], [0, 0, 0, 0]]]           # the last one is degenerate
+    out = pred([page], bboxes=bboxes, return_words=True, sort_lines=True)
+    assert len(out) == 1 and isinstance(out[0], OCRResult) and out[0].image_bbox == [0, 0, 256, 256]
+    assert len(out[0].text_lines) == 3
+    for line in out[0].text_lines:
+        d = line.model_dump()
+        assert {"text", "polygon", "confidence", "chars", "words", "original_text_good", "bbox"} <= set(d)
+        assert 0 <= (line.confidence or 0) <= 1
+        for ch in line.chars:
+            assert len(ch.polygon) == 4
+    with pytest.raises(AssertionError):
+        pred([page], task_names=["not_a_task"], bboxes=bboxes)
+    assert pred([], bboxes=[]) == []
+
+
+def test_detection_predictor_matches_oracle_boxes(hip_lib):
+    """Boxes from our post-processing fed with HIP heat maps == fed with oracle heat maps (SURVEY 8(c) cv2 gap)."""
+    from surya_amd.detection.predictor import DetectionPredictor, DetectionModelLoader
+    from surya_amd.detection import heatmap as hm
+    cfg = det_config("DET-TINY")
+    sd = make_det_weights(cfg, 0)
+
+    class Pred(DetectionPredictor):
+        model_loader_cls = DetectionModelLoader
+    pred = Pred(checkpoint={"config": cfg, "state_dict": sd, "size": 256}, dtype=torch.float32)
+    pages = [Image.fromarray(p) for p in make_pages(3, 256, seed=11)]
+    res = pred(pages, batch_size=2, include_maps=True)
+    assert len(res) == 3
+    x = do.normalise_pages([np.asarray(p) for p in pages])
+    ref_maps = do.heatmaps(sd, cfg, x).numpy()
+    for i, r in enumerate(res):
+        assert r.image_bbox == [0, 0, 256, 256] and r.vertical_lines == [] and r.heatmap is not None
+        ref = hm.parallel_get_boxes([ref_maps[i, 0], ref_maps[i, 1]], (256, 256))
+        assert [b.polygon for b in r.bboxes] == [b.polygon for b in ref.bboxes]
+        assert np.allclose([b.confidence for b in r.bboxes], [b.confidence for b in ref.bboxes], atol=1e-3)
+
+
+def test_detection_tall_page_is_split(hip_lib):
+    from surya_amd.detection.predictor import DetectionPredictor
+    cfg = det_config("DET-TINY")
+    sd = make_det_weights(cfg, 0)
+    pred = DetectionPredictor(checkpoint={"config": cfg, "state_dict": sd, "size": 256}, dtype=torch.float32)
+    settings.DETECTOR_IMAGE_CHUNK_HEIGHT = 300
+    try:
+        tall = Image.fromarray(np.vstack(make_pages(3, 256, seed=2))[:600])            # 256 wide, 600 tall -> 3 strips
+        gen = list(pred.batch_detection([tall], batch_size=4))
+        (preds, sizes), = gen
+        assert sizes == [(256, 600)] and preds[0][0].shape == (600, 256) and len(preds[0]) == 2
+    finally:
+        settings.DETECTOR_IMAGE_CHUNK_HEIGHT = 1400
