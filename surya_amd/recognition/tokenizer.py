@@ -58,9 +58,12 @@ class OCRTokenizer:
         for tag in self.special_tokens.get("all", []):
             if tag not in self.SPECIAL_TOKEN_MAPPING:
                 self.SPECIAL_TOKEN_MAPPING[tag] = self.qwen_offset + len(self.SPECIAL_TOKEN_MAPPING)
+        # synthetic configs reserve a fixed-size tag range (RecConfig.num_special_tokens): a randomly initialised model can
+        # emit any id, so every reserved id gets a placeholder tag (a real checkpoint defines all of its tag ids)
+        for n in range(len(self.SPECIAL_TOKEN_MAPPING), reserve_special):
+            self.SPECIAL_TOKEN_MAPPING[f"<RSV-{n}>"] = self.qwen_offset + n
+        self.num_special = len(self.SPECIAL_TOKEN_MAPPING)
         self.REVERSE_SPECIAL_TOKEN_MAPPING = {v: k for k, v in self.SPECIAL_TOKEN_MAPPING.items()}
-        # synthetic configs reserve a fixed-size tag range (RecConfig.num_special_tokens); unused ids decode to nothing
-        self.num_special = max(len(self.SPECIAL_TOKEN_MAPPING), reserve_special)
         self.special_token_offset = self.qwen_offset + self.num_special
         self._system = _prefix_regex(self.special_tokens.get("system", []))
         self._math = _prefix_regex(self.special_tokens.get("math_external", []))

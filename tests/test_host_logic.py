@@ -41,8 +41,7 @@ def test_tokenizer_roundtrip_three_ranges():
     assert sum(i >= tk.special_token_offset for i in ids) >= 7                    # UTF-16 units (emoji = 2)
     assert tk.decode(ids, task=TaskNames.ocr_with_boxes) == text
     assert tk.vocab_size == tk.special_token_offset + 65536
-    with pytest.raises(ValueError):
-        tk.decode([tk.special_token_offset - 1], task=TaskNames.ocr_with_boxes)  # reserved, unmapped tag id
+    assert tk.decode([tk.special_token_offset - 1], task=TaskNames.ocr_with_boxes) == "<RSV-63>"   # reserved placeholder tag
 
 
 def test_processor_tile_order_and_prompt():
