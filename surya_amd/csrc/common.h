@@ -11,6 +11,7 @@ namespace sa {
 
 typedef unsigned short bf16_t;   // storage type for bf16 (bit pattern)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // 16-byte register chunk. NOT HIP's uint4: arrays of that struct type are demoted to scratch memory by hipcc (measured:
 // the GEMM's staging registers went through scratch, 272 B/lane), native vector types stay in VGPRs.

@@ -36,7 +36,7 @@ template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<T>::KE, V = Ty<T>::V16;
-    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
     constexpr int XCH = BM * 8 / NT, WCH = BN * 8 / NT;
     static_assert(XCH >= 1 && WCH >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
         const int b = m / (p.Ho * p.Wo), r = m % (p.Ho * p.Wo);
         xb[i] = b; xiy[i] = (r / p.Wo) * p.stride - p.pad; xix[i] = (r % p.Wo) * p.stride - p.pad;
         xc[i] = c * V;
-        xdst[i] = row * 128 + ((c ^ (row & 7)) << 4);
+        xdst[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
     const unsigned char* wsrc[WCH];
     int wdst[WCH];
@@ -66,13 +66,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
         const int id = tid + i * NT, row = id >> 3, c = id & 7;
         const int gr = min(n0 + row, p.Cout - 1);
         wsrc[i] = reinterpret_cast<const unsigned char*>(p.w + (long)gr * p.Kpad) + c * 16;
-        wdst[i] = XBYTES + row * 128 + ((c ^ (row & 7)) << 4);
+        wdst[i] = XBYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
-    f32x4 acc[FN][FM];
+    f32x16 acc[FN][FM];
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
     const int nk = p.Kpad / KE;
     u32x4 xr0[XCH], wr0[WCH], xr1[XCH], wr1[WCH];
 #define SA_CFETCH(XR, WR, KT)                                                                                   \
@@ -99,19 +101,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) *reinterpret_cast<u32x4*>(b_ + xdst[i]) = XR[i];   \
         _Pragma("unroll") for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];   \
     }
-    const int frow = lane & 15, fch = lane >> 4;
+    const int frow = lane & 31, fch = lane >> 5;
 #define SA_CCOMPUTE(CURP)                                                                                      \
     {                                                                                                          \
         const unsigned char* cur_ = (CURP);                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                     \
             u32x4 xf[FM], wf[FN];                                                                              \
             _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
-                const int row = wm * WTM + i * 16 + frow;                                                      \
-                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+                const int row = wm * WTM + i * 32 + frow;                                                      \
+                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
-                const int row = wn * WTN + j * 16 + frow;                                                      \
-                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+                const int row = wn * WTN + j * 32 + frow;                                                      \
+                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
                 _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<T>::run(acc[j][i], wf[j], xf[i]);          \
@@ -144,33 +146,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
 #undef SA_CCOMPUTE
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
-            if (n >= p.Cout) continue;
-            float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            if (p.bias) {
-                float b[4];
-                load4(p.bias + n, b);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;
+                if (n >= p.Cout) continue;
+                float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                if (p.bias) {
+                    float b[4];
+                    load4(p.bias + n, b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if (p.act == ACT_HSWISH) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
+                } else if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (p.res) {
+                    float r4[4];
+                    load4(p.res + (long)m * p.Cout + n, r4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += r4[r];
+                }
+                store4(p.out + (long)m * p.Cout + n, v[0], v[1], v[2], v[3]);
             }
-            if (p.act == ACT_HSWISH) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
-            } else if (p.act == ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (p.res) {
-                float r4[4];
-                load4(p.res + (long)m * p.Cout + n, r4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += r4[r];
-            }
-            store4(p.out + (long)m * p.Cout + n, v[0], v[1], v[2], v[3]);
         }
     }
 }

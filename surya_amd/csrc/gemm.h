@@ -38,18 +38,22 @@ struct GemmArgs {
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
 };
 
+// 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
+// was LDS-bound at ~690 TF/s, r01 profile). Fragment of either operand: lane l holds 16 bytes = K-chunk (ks*2 + (l >> 5))
+// of row (l & 31); bf16: one v_mfma_f32_32x32x16_bf16; fp32: four v_mfma_f32_32x32x2_f32 on the chunk's 4 floats
+// (k-permuted identically on both operands, so the sum is unchanged and exact).
 template <typename TI> struct Mfma;
 template <> struct Mfma<bf16_t> {
-    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    __device__ static __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
     }
 };
 template <> struct Mfma<float> {
-    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[0]), __uint_as_float(x[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[1]), __uint_as_float(x[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[2]), __uint_as_float(x[2]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[3]), __uint_as_float(x[3]), acc, 0, 0, 0);
+    __device__ static __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w[0]), __uint_as_float(x[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w[1]), __uint_as_float(x[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w[2]), __uint_as_float(x[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w[3]), __uint_as_float(x[3]), acc, 0, 0, 0);
     }
 };
 
@@ -59,13 +63,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
     // 16-byte chunks per thread per tile. When a tile has fewer chunks than threads (256x32: 256 W chunks, 512 threads)
     // the upper threads duplicate the lower ones' chunk (same data to the same LDS slot) instead of being predicated:
     // predicated loads cost an exec-mask branch + vmcnt(0) each and demote the staging registers to scratch.
     constexpr int XCH = (BM * 8 + NT - 1) / NT, WCH = (BN * 8 + NT - 1) / NT;
     constexpr int XMOD = XCH * NT > BM * 8 ? BM * 8 : XCH * NT, WMOD = WCH * NT > BN * 8 ? BN * 8 : WCH * NT;
-    static_assert(FM >= 1 && FN >= 1 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
+    static_assert(FM >= 1 && FN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "tile");
     static_assert((XCH == 1 || (BM * 8) % NT == 0) && (WCH == 1 || (BN * 8) % NT == 0), "staging split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: buf b: X tile [BM][128B] then W tile [BN][128B]
@@ -91,21 +95,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         const int id = (tid + i * NT) % XMOD, row = id >> 3, c = id & 7;
         const int gr = min(m0 + row, p.M - 1);
         xsrc[i] = reinterpret_cast<const unsigned char*>(p.X + (long)gr * p.ldx) + c * 16 + (long)kt_begin * 128;
-        xdst[i] = row * 128 + ((c ^ (row & 7)) << 4);
+        xdst[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int id = (tid + i * NT) % WMOD, row = id >> 3, c = id & 7;
         const int gr = min(n0 + row, p.N - 1);
         wsrc[i] = reinterpret_cast<const unsigned char*>(p.W + (long)gr * p.ldw) + c * 16 + (long)kt_begin * 128;
-        wdst[i] = XBYTES + row * 128 + ((c ^ (row & 7)) << 4);
+        wdst[i] = XBYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
 
-    f32x4 acc[FN][FM];
+    f32x16 acc[FN][FM];
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
     const int nk = kt_end - kt_begin;
     // Two statically named register sets (runtime-indexed arrays would be demoted to scratch memory).
@@ -126,19 +132,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                        \
             *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];                       \
     }
-    const int frow = lane & 15, fch = lane >> 4;     // fragment: row = base + (lane & 15), chunk = kk*4 + (lane >> 4)
+    const int frow = lane & 31, fch = lane >> 5;     // fragment: row = base + (lane & 31), chunk = ks*2 + (lane >> 5)
 #define SA_COMPUTE(CURP)                                                                                       \
     {                                                                                                          \
         const unsigned char* cur_ = (CURP);                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                     \
             u32x4 xf[FM], wf[FN];                                                                              \
             _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
-                const int row = wm * WTM + i * 16 + frow;                                                      \
-                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+                const int row = wm * WTM + i * 32 + frow;                                                      \
+                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
-                const int row = wn * WTN + j * 16 + frow;                                                      \
-                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 4 + fch) ^ (row & 7)) << 4)); \
+                const int row = wn * WTN + j * 32 + frow;                                                      \
+                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
                 _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], wf[j], xf[i]);         \
@@ -177,46 +183,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #undef SA_STASH
 #undef SA_COMPUTE
 
-    // epilogue: lane owns row m = .. + (lane & 15), columns n = .. + (lane >> 4) * 4 + {0..3}
+    // epilogue: 32x32 result D[n][m]: lane owns row m = .. + (lane & 31) and, per register group g = 0..3, the four
+    // consecutive columns n = .. + 8 g + 4 (lane >> 5) + {0..3}
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-            if constexpr (SPLIT) {
-                *reinterpret_cast<float4*>(p.part + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                continue;
-            }
-            if (p.bias) {
-                float b[4];
-                load4(p.bias + n, b);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r];
-            }
-            if constexpr (EPI == EPI_SWIGLU) {
-                // weight rows interleaved (gate_j, up_j): columns n..n+3 = g0,u0,g1,u1 -> outputs n/2, n/2+1
-                store2(p.C + (long)m * p.ldc + (n >> 1), silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
-            } else {
-                if constexpr (EPI == EPI_RESIDUAL) {
-                    float r4[4];
-                    load4(p.R + (long)m * p.ldr + n, r4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += r4[r];
-                } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-                } else if constexpr (EPI == EPI_HARDSWISH) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
-                } else if constexpr (EPI == EPI_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;
+                if (n >= p.N) continue;
+                float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                if constexpr (SPLIT) {
+                    *reinterpret_cast<float4*>(p.part + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
                 }
-                store4(p.C + (long)m * p.ldc + n, v[0], v[1], v[2], v[3]);
+                if (p.bias) {
+                    float b[4];
+                    load4(p.bias + n, b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if constexpr (EPI == EPI_SWIGLU) {
+                    // weight rows interleaved (gate_j, up_j): columns n..n+3 = g0,u0,g1,u1 -> outputs n/2, n/2+1
+                    store2(p.C + (long)m * p.ldc + (n >> 1), silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                } else {
+                    if constexpr (EPI == EPI_RESIDUAL) {
+                        float r4[4];
+                        load4(p.R + (long)m * p.ldr + n, r4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+                    } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                    } else if constexpr (EPI == EPI_HARDSWISH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
+                    } else if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    store4(p.C + (long)m * p.ldc + n, v[0], v[1], v[2], v[3]);
+                }
             }
         }
     }
@@ -287,8 +297,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
             return launch_gemm_cfg<TI, TO, 128, 32, 4, 1, EPI>(a, s);
         }
-        if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 64, 64, 4, 1, EPI>(a, s);
-        return launch_gemm_cfg<TI, TO, 64, 32, 4, 1, EPI>(a, s);
+        if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
+        return launch_gemm_cfg<TI, TO, 64, 32, 2, 1, EPI>(a, s);
     }
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     if (big >= 256) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
@@ -312,7 +322,7 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk), 8);
     if (a.M > 128) return launch_gemm_cfg<TI, TI, 256, 32, 8, 1, EPI_BIAS, true>(a, s);
     if (a.M > 64) return launch_gemm_cfg<TI, TI, 128, 32, 4, 1, EPI_BIAS, true>(a, s);
-    return launch_gemm_cfg<TI, TI, 64, 32, 4, 1, EPI_BIAS, true>(a, s);
+    return launch_gemm_cfg<TI, TI, 64, 32, 2, 1, EPI_BIAS, true>(a, s);
 }
 
 }  // namespace sa
