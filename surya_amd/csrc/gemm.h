@@ -36,6 +36,7 @@ struct GemmArgs {
     int M, N, K;                 // K % KE == 0, N % 4 == 0
     int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
+    int swz_m = 0, swz_n = 0;    // > 0: XCD-aware rasterisation in super-tiles of swz_m x swz_n output tiles (set by the launcher)
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -80,7 +81,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tile_id = SPLIT ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
     const int ks = SPLIT ? (int)blockIdx.x % p.splitk : 0;       // slices of one tile are adjacent workgroups
-    const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+    int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+    if (!SPLIT && p.swz_n > 0) {
+        // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only). Each XCD has a private 4 MiB L2,
+        // so the ~64 workgroups resident on one XCD should form a compact swz_m x swz_n patch of output tiles: they then
+        // share swz_m X-slabs and swz_n W-slabs through that L2 instead of each pulling its own pair from MALL/HBM
+        // (n-fastest order gave ~55 distinct slabs per 64 tiles and capped the 128x128 GEMM at ~0.65 PF/s, r01 profile).
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int per = p.swz_m * p.swz_n;
+        const int st = (j / per) * 8 + x, t = j % per;
+        const int nsn = (tiles_n + p.swz_n - 1) / p.swz_n;
+        tile_m = (st / nsn) * p.swz_m + t / p.swz_n;
+        tile_n = (st % nsn) * p.swz_n + t % p.swz_n;
+        if (tile_m >= (p.M + BM - 1) / BM || tile_n >= tiles_n) return;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk_all = p.K / KE;
     const int kt_begin = SPLIT ? (int)((long)ks * nk_all / p.splitk) : 0;
@@ -256,7 +270,17 @@ inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (
 
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
-    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
+    int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
+    GemmArgs<TI, TO> aa = a;
+    if (!SPLIT && BM == 128 && BN == 128) {          // XCD-aware super-tiles for the large-tile configuration
+        const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
+        if (tm * tn >= 512) {
+            aa.swz_n = std::min(tn, 8);
+            aa.swz_m = std::max(1, 64 / aa.swz_n);
+            const int n_super = cdiv(tm, aa.swz_m) * cdiv(tn, aa.swz_n);
+            tiles = cdiv(n_super, 8) * 8 * aa.swz_m * aa.swz_n;
+        }
+    }
     constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
     auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT>;
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
@@ -267,7 +291,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     GemmProfiler& pf = gemm_profiler();
     const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
     if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, aa);
     if (prof) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
         pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
