@@ -19,6 +19,7 @@
 // and X is re-read from L2 only N/BN times.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -197,39 +198,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #undef SA_STASH
 #undef SA_COMPUTE
 
-    // epilogue: 32x32 result D[n][m]: lane owns row m = .. + (lane & 31) and, per register group g = 0..3, the four
-    // consecutive columns n = .. + 8 g + 4 (lane >> 5) + {0..3}
+    // Epilogue through LDS. 32x32 result D[n][m]: a lane owns row m = .. + (lane & 31) and, per register group g, four
+    // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
+    // N = 1280 residual GEMMs ran at 400 TF/s on it). Instead the tile is staged in the (now idle) staging LDS with bias /
+    // activation applied, then stored as whole 16-byte chunks of contiguous rows; the residual is added on the way out.
+    __syncthreads();
+    constexpr int OW = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;         // output columns of this tile
+    using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
+    constexpr int ROWB = OW * (int)sizeof(TS), CPR = ROWB / 16;              // bytes and 16-byte chunks per tile row
+    constexpr int XM = CPR >= 8 ? 7 : CPR - 1;                               // chunk XOR mask (conflict-free b128 writes)
+    static_assert(BM * ROWB <= 2 * BUF && CPR >= 1, "output tile must fit the staging LDS");
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
+        const int row = wm * WTM + i * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;
-                if (n >= p.N) continue;
+                const int ncol = wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;   // tile-local column of v[0]
                 float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                if constexpr (SPLIT) {
-                    *reinterpret_cast<float4*>(p.part + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    continue;
-                }
-                if (p.bias) {
-                    float b[4];
-                    load4(p.bias + n, b);
+                if constexpr (!SPLIT) {
+                    if (p.bias) {
+                        const int n = min(n0 + ncol, p.N - 4);
+                        float b[4];
+                        load4(p.bias + n, b);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += b[r];
-                }
-                if constexpr (EPI == EPI_SWIGLU) {
-                    // weight rows interleaved (gate_j, up_j): columns n..n+3 = g0,u0,g1,u1 -> outputs n/2, n/2+1
-                    store2(p.C + (long)m * p.ldc + (n >> 1), silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
-                } else {
-                    if constexpr (EPI == EPI_RESIDUAL) {
-                        float r4[4];
-                        load4(p.R + (long)m * p.ldr + n, r4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += r4[r];
-                    } else if constexpr (EPI == EPI_GELU) {
+                        for (int r = 0; r < 4; ++r) v[r] += b[r];
+                    }
+                    if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
                     } else if constexpr (EPI == EPI_HARDSWISH) {
@@ -239,8 +235,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    store4(p.C + (long)m * p.ldc + n, v[0], v[1], v[2], v[3]);
                 }
+                if constexpr (EPI == EPI_SWIGLU && !SPLIT) {
+                    // weight rows interleaved (gate_j, up_j): columns ncol..+3 = g0,u0,g1,u1 -> outputs ncol/2, ncol/2+1
+                    const int boff = (ncol >> 1) * (int)sizeof(TS);
+                    TS* dst = reinterpret_cast<TS*>(smem + row * ROWB + ((((boff >> 4) ^ (row & XM)) << 4) | (boff & 15)));
+                    store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                } else {
+                    const int boff = ncol * (int)sizeof(TS);
+                    TS* dst = reinterpret_cast<TS*>(smem + row * ROWB + ((((boff >> 4) ^ (row & XM)) << 4) | (boff & 15)));
+                    store4(dst, v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int EPC = 16 / (int)sizeof(TS);                                // elements per 16-byte chunk
+    const int n_out = (EPI == EPI_SWIGLU && !SPLIT) ? p.N / 2 : p.N;
+    const int n0_out = (EPI == EPI_SWIGLU && !SPLIT) ? n0 / 2 : n0;
+    for (int id = tid; id < BM * CPR; id += NT) {
+        const int row = id / CPR, c = id % CPR;
+        const int m = m0 + row, n = n0_out + c * EPC;
+        if (m >= p.M || n >= n_out) continue;
+        u32x4 raw = *reinterpret_cast<const u32x4*>(smem + row * ROWB + ((c ^ (row & XM)) << 4));
+        if constexpr (SPLIT) {
+            *reinterpret_cast<u32x4*>(p.part + ((long)ks * p.M + m) * p.N + n) = raw;
+        } else {
+            if constexpr (EPI == EPI_RESIDUAL) {
+                float a[EPC], r[EPC];
+                const uint4 raw4 = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+                unpack16(raw4, a, (TO*)nullptr);
+                unpack16(*reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n), r, (TO*)nullptr);
+                TO* dst = p.C + (long)m * p.ldc + n;
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) store4(dst + e, a[e] + r[e], a[e + 1] + r[e + 1], a[e + 2] + r[e + 2], a[e + 3] + r[e + 3]);
+            } else {
+                *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = raw;
             }
         }
     }
@@ -311,7 +341,11 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
 template <typename TI, typename TO, int EPI>
 static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
-    if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0) return SA_ERR_SHAPE;
+    {   // rows are stored in 16-byte chunks: output width (N, or N/2 after SwiGLU) must be a multiple of 16 bytes of TO
+        const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
+        if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || n_out % (16 / (int)sizeof(TO)) != 0 || a.ldc % (16 / (int)sizeof(TO)) != 0)
+            return SA_ERR_SHAPE;
+    }
     if (a.M <= 256) {
         if (a.M > 128) {
             if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 256, 64, 8, 1, EPI>(a, s);
