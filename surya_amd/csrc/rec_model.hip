@@ -10,8 +10,11 @@
 //     movement -- admitting a prompt writes its K/V rows straight into a free slot;
 //   * the greedy head keeps next-token / length state on the device, so n decode steps need no host round trip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "../../include/surya_amd.h"
@@ -170,6 +173,13 @@ struct RecModel : RecBase {
     size_t out_bytes = 0;
     int n_active = 0;
     int last_rows = 0;
+    // hipGraph replay of decode steps: a step is ~113 short launches; captured once per (active rows, steps) and replayed
+    // from an internal stream (capture is not allowed on the legacy default stream torch hands us).
+    hipStream_t gstream = nullptr;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;
+    std::map<long, hipGraphExec_t> graphs;
+    std::set<long> seen_keys;
+    bool use_graph = true;
 
     const T* W(int idx) const { return reinterpret_cast<const T*>(w[idx]); }
     const T* WE(int l, int k) const { return W(SA_RW_ENC(l, k)); }
@@ -243,10 +253,19 @@ struct RecModel : RecBase {
         if (rc) return rc;
         rc = st_small.init((size_t)c.max_slots * 4 * sizeof(int) + 4096);
         if (rc) return rc;
+        SA_HIP(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
+        SA_HIP(hipEventCreateWithFlags(&gev_in, hipEventDisableTiming));
+        SA_HIP(hipEventCreateWithFlags(&gev_out, hipEventDisableTiming));
+        const char* ng = getenv("SURYA_AMD_NO_GRAPH");
+        use_graph = !(ng && ng[0] == '1');
         SA_HIP(hipDeviceSynchronize());
         return SA_OK;
     }
     ~RecModel() override {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        if (gstream) (void)hipStreamDestroy(gstream);
+        if (gev_in) (void)hipEventDestroy(gev_in);
+        if (gev_out) (void)hipEventDestroy(gev_out);
         st.destroy(); st_small.destroy();
         if (arena) (void)hipFree(arena);
         if (out_host) (void)hipHostFree(out_host);
@@ -543,15 +562,46 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
-    int decode(int n_steps, hipStream_t s) override {
-        if (n_steps < 0 || n_steps > SA_MAX_STEPS) return SA_ERR_ARG;
-        const int M = n_active;
-        if (M == 0) return SA_OK;
+    int decode_eager(int M, int n_steps, hipStream_t s) {
         int rc;
         for (int step = 0; step < n_steps; ++step) {
             if ((rc = decoder_layers_decode(M, s))) return rc;
             if ((rc = heads(M, nullptr, active_dev, step, 1, true, s))) return rc;
         }
+        return SA_OK;
+    }
+
+    int decode(int n_steps, hipStream_t s) override {
+        if (n_steps < 0 || n_steps > SA_MAX_STEPS) return SA_ERR_ARG;
+        const int M = n_active;
+        if (M == 0 || n_steps == 0) return SA_OK;
+        if (!use_graph || gemm_profiler().enabled) return decode_eager(M, n_steps, s);
+        const long key = (long)M * 64 + n_steps;
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            // first sight of this shape runs eagerly (one-time hipFuncSetAttribute calls must not happen inside a capture)
+            if (!seen_keys.count(key)) { seen_keys.insert(key); return decode_eager(M, n_steps, s); }
+            hipGraph_t g = nullptr;
+            SA_HIP(hipStreamBeginCapture(gstream, hipStreamCaptureModeThreadLocal));
+            int rc = decode_eager(M, n_steps, gstream);
+            hipError_t e = hipStreamEndCapture(gstream, &g);
+            if (rc || e != hipSuccess || !g) {                 // capture failed: fall back to eager launches for good
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                use_graph = false;
+                return decode_eager(M, n_steps, s);
+            }
+            hipGraphExec_t ex = nullptr;
+            e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { use_graph = false; (void)hipGetLastError(); return decode_eager(M, n_steps, s); }
+            it = graphs.emplace(key, ex).first;
+        }
+        SA_HIP(hipEventRecord(gev_in, s));
+        SA_HIP(hipStreamWaitEvent(gstream, gev_in, 0));
+        SA_HIP(hipGraphLaunch(it->second, gstream));
+        SA_HIP(hipEventRecord(gev_out, gstream));
+        SA_HIP(hipStreamWaitEvent(s, gev_out, 0));
         return SA_OK;
     }
 
