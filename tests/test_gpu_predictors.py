@@ -120,3 +120,21 @@ def test_detection_tall_page_is_split(hip_lib):
         assert sizes == [(256, 600)] and preds[0][0].shape == (600, 256) and len(preds[0]) == 2
     finally:
         settings.DETECTOR_IMAGE_CHUNK_HEIGHT = 1400
+
+
+def test_end_to_end_detect_crop_recognise(hip_lib):
+    """BASELINE.json configs[3] in miniature: RecognitionPredictor(images, det_predictor=...) -- detection boxes become
+    polygon crops (slice_polys_from_image) that feed the recogniser; every detected line yields one TextLine."""
+    from surya_amd.detection.predictor import DetectionPredictor
+    cfg_d = det_config("DET-TINY")
+    det = DetectionPredictor(checkpoint={"config": cfg_d, "state_dict": make_det_weights(cfg_d, 0), "size": 256}, dtype=torch.float32)
+    cfg, sd, rec = make_rec_predictor(max_slots=8, max_tokens=6)
+    pages = [Image.fromarray(p) for p in make_pages(2, 256, seed=21)]
+    det_res = det(pages)
+    out = rec(pages, det_predictor=det)
+    assert len(out) == 2
+    for r, d in zip(out, det_res):
+        assert len(r.text_lines) == len(d.bboxes)
+        for line, box in zip(r.text_lines, d.bboxes):
+            assert line.polygon == box.polygon
+    assert sum(len(r.text_lines) for r in out) > 0
