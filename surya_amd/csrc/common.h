@@ -80,6 +80,26 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
+// Cross-lane sums on the VALU (DPP) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 (an LDS round trip of
+// ~100 cycles per step: the decode-attention key loop spent 13 of its 24 us in those chains, tools/microbench).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 4 lanes; every lane of the group gets the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over each aligned group of 16 lanes (one DPP row); every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v = quad_sum(v);
+    v += dpp_mov<0x141>(v);       // row_half_mirror: lane i <-> 7 - i of its 8-lane half (quad sums are uniform per quad)
+    v += dpp_mov<0x140>(v);       // row_mirror: lane i <-> 15 - i of its row
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

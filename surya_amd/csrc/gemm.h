@@ -19,6 +19,7 @@
 // and X is re-read from L2 only N/BN times.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
     constexpr int ROWB = OW * (int)sizeof(TS), CPR = ROWB / 16;              // bytes and 16-byte chunks per tile row
     constexpr int XM = CPR >= 8 ? 7 : CPR - 1;                               // chunk XOR mask (conflict-free b128 writes)
-    static_assert(BM * ROWB <= 2 * BUF && CPR >= 1, "output tile must fit the staging LDS");
+    static_assert(BM * ROWB <= 160 * 1024 && CPR >= 1, "output tile must fit LDS (launcher sizes it)");
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = wm * WTM + i * 32 + (lane & 31);
@@ -311,7 +312,10 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
             tiles = cdiv(n_super, 8) * 8 * aa.swz_m * aa.swz_n;
         }
     }
-    constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
+    constexpr size_t out_w = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;
+    constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
+    constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * 2;
+    constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
     auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT>;
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     if (!attr_set) {
@@ -348,7 +352,18 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     if (a.M <= 256) {
         if (a.M > 128) {
-            if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 256, 64, 8, 1, EPI>(a, s);
+            static const int force_bn = [] { const char* e = getenv("SURYA_AMD_TALL_BN"); return e ? atoi(e) : 0; }();
+            if (force_bn == 6464) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);          // experiments (tools/microbench)
+            if (force_bn == 12864) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
+            if (force_bn == 128128) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
+            if (!force_bn) {
+                // measured at M = 256 (tools/microbench/gemm_shapes.py): lm_head-sized N -> 128x64 tiles; everything else -> 64x64
+                if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
+                return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
+            }
+            const int bn = force_bn;
+            if (bn == 128) return launch_gemm_cfg<TI, TO, 256, 128, 8, 1, EPI>(a, s);
+            if (bn == 64) return launch_gemm_cfg<TI, TO, 256, 64, 8, 1, EPI>(a, s);
             return launch_gemm_cfg<TI, TO, 256, 32, 8, 1, EPI>(a, s);
         }
         if (a.M > 64) {
@@ -366,8 +381,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
 // Split-K launch for the decode regime (M <= 256, small N): tiles x splitk workgroups so a skinny GEMM still covers the
 // chip; raw fp32 partial sums go to a.part[splitk][M][N] and the NEXT kernel combines them (launch-boundary reduce).
 // Returns the slice count actually used through a.splitk (caller passes the same struct to the consumer).
-static inline int pick_splitk(int tiles, int nk) {
-    int s = (256 + tiles / 2) / tiles;             // aim at ~256 workgroups
+static inline int pick_splitk(int tiles, int nk, int target) {
+    int s = (target + tiles / 2) / tiles;          // aim at ~target workgroups
     s = std::min(s, nk / 4);                       // keep >= 4 K-tiles per slice (pipeline fill)
     return std::max(s, 1);
 }
@@ -377,7 +392,16 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
     if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || !a.part) return SA_ERR_SHAPE;
     const int nk = a.K / Ty<TI>::KE;
-    a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk), 8);
+    // 64x64 tiles (4 M-tiles at M = 256) beat the tall 256-row tiles for these skinny projections: many light
+    // workgroups (32 KiB LDS, 4-5 per CU) hide the per-iteration load latency better than few heavy ones
+    // (tools/microbench/gemm_shapes.py: unsplit 64x64 11 us vs tall 16 us for qkv at M = 256).
+    static const int mode = [] { const char* e = getenv("SURYA_AMD_SPLIT_TILE"); return e ? atoi(e) : 6464; }();
+    static const int target = [] { const char* e = getenv("SURYA_AMD_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    if (mode == 6464) {
+        a.splitk = std::min(pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk, target), 8);
+        return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true>(a, s);
+    }
+    a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk, target / 2), 8);
     if (a.M > 128) return launch_gemm_cfg<TI, TI, 256, 32, 8, 1, EPI_BIAS, true>(a, s);
     if (a.M > 64) return launch_gemm_cfg<TI, TI, 128, 32, 4, 1, EPI_BIAS, true>(a, s);
     return launch_gemm_cfg<TI, TI, 64, 32, 2, 1, EPI_BIAS, true>(a, s);

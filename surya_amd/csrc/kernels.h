@@ -4,6 +4,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef SA_DBG_VARIANT
+#define SA_DBG_VARIANT 0     // tools/microbench only: 1 = no cached-key loop, 2 = no split-K slab loads, 3 = no LDS merge, 4 = no K/V preload
+#endif
+
 namespace sa {
 
 // ---------------------------------------------------------------------------------------------------
@@ -156,8 +160,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ q,
                         d += qr[i] * t4[0] + qr[i + 1] * t4[1] + qr[i + 2] * t4[2] + qr[i + 3] * t4[3];
                     }
                 }
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
+                d = quad_sum(d);
                 const bool ok = (j < nk) && (!causal || (kc + j) <= qi);
                 s[jj] = ok ? d : -INFINITY;
                 bm = fmaxf(bm, s[jj]);
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int j = min(kg + 16 * u, max(len - 1, 0));          // clamped: rows >= len are never used
+        if (SA_DBG_VARIANT == 4) { kr[u].load(kb); vr[u].load(vb); continue; }
         kr[u].load(kb + (long)j * D);
         vr[u].load(vb + (long)j * D);
     }
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         if (qkv_part) {
 #pragma unroll
             for (int sidx = 0; sidx < 8; ++sidx)             // slab index clamped too: no branches around the loads
-                p8[k][sidx] = qkv_part[((long)min(sidx, S - 1) * Mrows + a) * qkv_dim + col];
+                p8[k][sidx] = (SA_DBG_VARIANT == 2) ? 0.f : qkv_part[((long)min(sidx, S - 1) * Mrows + a) * qkv_dim + col];
             bias_v[k] = Ty<T>::ld(qkv_bias + col);
         } else {
 #pragma unroll
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
                 float d = 0.f;
 #pragma unroll
                 for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[i];
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                d = row16_sum(d);
                 const float mn = fmaxf(m[h], d);
                 const float al = __expf(m[h] - mn), pj = __expf(d - mn);
                 l[h] = l[h] * al + pj;
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     // cached keys [0, min(len, 16 * UN)) from the preloaded registers
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-        if (kg + 16 * u < len) {                    // uniform within the 16 lanes of a key group
+        if (SA_DBG_VARIANT != 1 && kg + 16 * u < len) {                    // uniform within the 16 lanes of a key group
             float kf[EPL], vf[EPL];
 #pragma unroll
             for (int i = 0; i < EPL; ++i) { kf[i] = kr[u].get(i); vf[i] = vr[u].get(i); }

@@ -7,7 +7,11 @@ lib = L.lib()
 shapes = [(46460, 6912, 1280, 3, "enc gate|up"), (46460, 3840, 1280, 0, "enc qkv"), (46460, 1280, 1280, 1, "enc proj"),
           (46460, 1280, 3456, 1, "enc down"), (15360, 10240, 1280, 3, "dec prefill gate|up"), (15360, 1280, 5120, 1, "dec prefill down"),
           (8192, 8192, 8192, 0, "square 8k"), (4096, 4096, 4096, 0, "square 4k"), (256, 10240, 1280, 3, "decode gate|up"),
-          (256, 81920, 1280, 0, "lm_head")]
+          (256, 81920, 1280, 0, "lm_head"), (256, 1792, 1280, 0, "decode qkv (unsplit)"), (256, 1280, 1280, 1, "decode o (unsplit)"),
+          (256, 1280, 5120, 1, "decode down (unsplit)")]
+import os
+if os.environ.get("ONLY_DECODE"):
+    shapes = [s for s in shapes if s[0] == 256]
 for M, N, K, epi, name in shapes:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     b = torch.randn(N, device="cuda").bfloat16()
