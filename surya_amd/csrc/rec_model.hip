@@ -20,6 +20,7 @@
 #include "../../include/surya_amd.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "decode_attn.h"
 
 namespace sa {
 
@@ -455,16 +456,38 @@ struct RecModel : RecBase {
             T* vc = vcache + l * layer_kv;
             if ((rc = splitk_gemm(dh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, &S, s))) return rc;
             dim3 grid(M, nkv), block(256);
-#define SA_DEC(DD, GG)                                                                                                       \
+            const int G = nq / nkv;
+            static const bool attn_v1 = [] { const char* e = getenv("SURYA_AMD_DECODE_ATTN"); return e && e[0] == '1'; }();
+#define SA_DEC1(DD, GG)                                                                                                      \
     hipLaunchKernelGGL((decode_attn_kernel<T, DD, GG>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
                        kc, vc, active_dev, row_len, rope_cs, nq, nkv, c.max_kv_len, scale)
-            const int G = nq / nkv;
-            if (d == 128 && G <= 5) SA_DEC(128, 5);
-            else if (d == 128) SA_DEC(128, 8);
-            else if (d == 64) SA_DEC(64, 8);
-            else if (d == 32) SA_DEC(32, 8);
-            else return SA_ERR_UNSUPPORTED;
-#undef SA_DEC
+#define SA_DEC2(DD, GG)                                                                                                      \
+    {                                                                                                                        \
+        auto kern = decode_attn_mfma_kernel<T, DD, GG>;                                                                      \
+        const size_t lds = decode_attn_mfma_lds<T, DD, GG>();                                                                \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                 \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, part, S, WD(l, SA_RD_QKV_B), dattn, kc, vc, active_dev, row_len, rope_cs, nq, \
+                           nkv, c.max_kv_len, scale);                                                                        \
+    }
+            if (attn_v1) {
+                if (d == 128 && G <= 5) SA_DEC1(128, 5);
+                else if (d == 128) SA_DEC1(128, 8);
+                else if (d == 64) SA_DEC1(64, 8);
+                else if (d == 32) SA_DEC1(32, 8);
+                else return SA_ERR_UNSUPPORTED;
+            } else {
+                if (d == 128 && G <= 5) SA_DEC2(128, 5)
+                else if (d == 128) SA_DEC2(128, 8)
+                else if (d == 64) SA_DEC2(64, 8)
+                else if (d == 32) SA_DEC2(32, 8)
+                else return SA_ERR_UNSUPPORTED;
+            }
+#undef SA_DEC1
+#undef SA_DEC2
             if ((rc = (int)hipGetLastError())) return rc;
             if ((rc = splitk_gemm(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, &S, s))) return rc;
             if ((rc = reduce_residual_norm(S, M, WD(l, SA_RD_LN2), dh, s))) return rc;
