@@ -373,6 +373,7 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
         return launch_gemm_cfg<TI, TO, 64, 32, 2, 1, EPI>(a, s);
     }
+    if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     if (big >= 256) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
     return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
