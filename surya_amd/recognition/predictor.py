@@ -360,6 +360,28 @@ class RecognitionPredictor(BasePredictor):
     def prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:
         return self.generate(self.prepare_lines(flat, math_mode), recognition_batch_size)
 
+    def sharded_prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:
+        """One process per GPU (torch.distributed initialised by the caller, e.g. torchrun): every rank holds the same
+        width-sorted line list, recognises the lines dealt to it round-robin and all ranks get all results back through
+        ONE all_gather (surya_amd/dist.py). No collective touches the per-step data path. Single process: plain loop."""
+        from .. import dist as sdist
+        rank, world = sdist.world_info()
+        n = len(flat["slices"])
+        if world == 1 or n == 0:
+            return self.prediction_loop(flat, recognition_batch_size, math_mode)
+        mine = sdist.shard_indices(n, world, rank)
+        local = {k: [flat[k][i] for i in mine] for k in ("slices", "input_text", "task_names")}
+        max_tokens = max(settings.RECOGNITION_MAX_TOKENS or self.tasks[t]["max_tokens"] for t in flat["task_names"])
+        if mine:
+            toks, boxes, scores = self.prediction_loop(local, recognition_batch_size, math_mode)
+            boxes = boxes.numpy()
+            if boxes.shape[1] < max_tokens:
+                boxes = np.pad(boxes, ((0, 0), (0, max_tokens - boxes.shape[1]), (0, 0)))
+        else:
+            toks, scores, boxes = [], [], np.zeros((0, max_tokens, 6), np.float32)
+        toks, scores, boxes = sdist.gather_line_outputs(toks, scores, boxes, mine, n, max_tokens, device=self.model.device)
+        return toks, torch.from_numpy(boxes), scores
+
     # ------------------------------------------------------------------------------------- output assembly
     def get_bboxes_text(self, flat, predicted_tokens, scores, predicted_polygons, drop_repeated_text=False) -> list:
         """Token stream -> TextChar list per line (reference :609-771): the stream is cut into runs of math-BPE ids,
@@ -445,7 +467,7 @@ class RecognitionPredictor(BasePredictor):
         for key in ("slices", "input_text", "task_names"):
             flat[key] = [flat[key][i] for i in order]
 
-        predicted_tokens, batch_bboxes, scores = self.prediction_loop(flat, recognition_batch_size, math_mode)
+        predicted_tokens, batch_bboxes, scores = self.sharded_prediction_loop(flat, recognition_batch_size, math_mode)
         bbox_size = self.model.cfg.bbox_size
         sizes = [img.shape for img in flat["slices"]]
         polys = prediction_to_polygon_batch(batch_bboxes.numpy(), sizes, bbox_size, bbox_size // 2)
