@@ -61,7 +61,7 @@ template <> struct Mfma<float> {
 };
 
 // BM x BN output tile per workgroup of WM x WN waves.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
@@ -86,22 +86,164 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
     if (!SPLIT && p.swz_n > 0) {
         // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only). Each XCD has a private 4 MiB L2,
-        // so the ~64 workgroups resident on one XCD should form a compact swz_m x swz_n patch of output tiles: they then
-        // share swz_m X-slabs and swz_n W-slabs through that L2 instead of each pulling its own pair from MALL/HBM
-        // (n-fastest order gave ~55 distinct slabs per 64 tiles and capped the 128x128 GEMM at ~0.65 PF/s, r01 profile).
+        // so the ~64 workgroups resident on one XCD should form a compact patch of output tiles: they then share a few
+        // X-slabs and W-slabs through that L2 instead of each pulling its own pair from MALL/HBM (n-fastest order gave ~55
+        // distinct slabs per 64 tiles and capped the 128x128 GEMM at ~0.65 PF/s, r01 profile).
+        // Tiles are numbered in super-tile order (super-rows of swz_m tile rows, cut into super-columns of swz_n tile
+        // columns, edge super-tiles shrunk to what exists, so only valid tiles are numbered); consecutive runs of 64
+        // numbers are dealt to the XCDs round-robin. Every XCD gets the same number of tiles: an earlier version dealt
+        // whole super-tiles including the clipped ones, and with N = 1280 (10 tile columns = one full + one quarter
+        // super-column) the odd XCDs drew only quarter super-tiles and the launch ran at 63 % (r01 microbench).
         const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        const int per = p.swz_m * p.swz_n;
-        const int st = (j / per) * 8 + x, t = j % per;
-        const int nsn = (tiles_n + p.swz_n - 1) / p.swz_n;
-        tile_m = (st / nsn) * p.swz_m + t / p.swz_n;
-        tile_n = (st % nsn) * p.swz_n + t % p.swz_n;
-        if (tile_m >= (p.M + BM - 1) / BM || tile_n >= tiles_n) return;
+        const int idx = ((j >> 6) * 8 + x) * 64 + (j & 63);
+        const int tiles_m = (p.M + BM - 1) / BM;
+        if (idx >= tiles_m * tiles_n) return;
+        const int per_row = p.swz_m * tiles_n;                          // tiles in a full super-row
+        const int sr = idx / per_row, rem = idx - sr * per_row;
+        const int h = min(p.swz_m, tiles_m - sr * p.swz_m);
+        const int sc = rem / (h * p.swz_n), rem2 = rem - sc * h * p.swz_n;
+        const int w = min(p.swz_n, tiles_n - sc * p.swz_n);
+        tile_m = sr * p.swz_m + rem2 / w;
+        tile_n = sc * p.swz_n + rem2 % w;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk_all = p.K / KE;
     const int kt_begin = SPLIT ? (int)((long)ks * nk_all / p.splitk) : 0;
     const int kt_end = SPLIT ? (int)((long)(ks + 1) * nk_all / p.splitk) : nk_all;
 
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    const int nk = kt_end - kt_begin;
+    const int last = nk - 1;
+    const int pairs = nk >> 1;
+    const int frow = lane & 31, fch = lane >> 5;     // fragment: row = base + (lane & 31), chunk = ks*2 + (lane >> 5)
+#define SA_FRAGS(XF, WF, KK)                                                                                   \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                       \
+            const int row = wm * WTM + i * 32 + frow;                                                          \
+            XF[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + ((((KK) * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                       \
+            const int row = wn * WTN + j * 32 + frow;                                                          \
+            WF[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + ((((KK) * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
+        }                                                                                                      \
+    }
+#define SA_MFMAS(XF, WF)                                   \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j)         \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], WF[j], XF[i]);
+    // Fragments of K-step kk+1 are read from LDS before the MFMAs of step kk are issued, so one wave keeps the matrix
+    // pipe busy without relying on a second resident wave to cover its ds_read latency.
+#define SA_COMPUTE(CURP)                                   \
+    {                                                      \
+        const unsigned char* cur_ = (CURP);                \
+        u32x4 xfa[FM], wfa[FN], xfb[FM], wfb[FN];          \
+        SA_FRAGS(xfa, wfa, 0);                             \
+        SA_FRAGS(xfb, wfb, 1);                             \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_MFMAS(xfa, wfa);                                \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_FRAGS(xfa, wfa, 2);                             \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_MFMAS(xfb, wfb);                                \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_FRAGS(xfb, wfb, 3);                             \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_MFMAS(xfa, wfa);                                \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        SA_MFMAS(xfb, wfb);                                \
+    }
+    if constexpr (GLDS > 0) {
+        // Direct-to-LDS staging (global_load_lds_dwordx4): one instruction moves 64 lanes x 16 bytes = 8 consecutive
+        // 128-byte tile rows from global memory into LDS at (wave-uniform M0 base) + lane * 16, with no staging VGPRs and
+        // no ds_write traffic (the register pipeline below is LDS-write-bound on big tiles, r01 profile). The LDS image is
+        // a plain linear copy, so the XOR swizzle is applied on the SOURCE side: lane l fills physical chunk (l & 7) of
+        // row r = base + (l >> 3) and therefore fetches logical chunk (l & 7) ^ ((r >> 1) & 7) of that row.
+        constexpr int NW = WM * WN, XI = BM / 8 / NW, WI = BN / 8 / NW;
+        static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "glds: whole 8-row groups per wave");
+        const unsigned char* xg[XI];
+        const unsigned char* wg[WI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            xg[i] = reinterpret_cast<const unsigned char*>(p.X + (long)min(m0 + row, p.M - 1) * p.ldx) + c * 16 + (long)kt_begin * 128;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            wg[i] = reinterpret_cast<const unsigned char*>(p.W + (long)min(n0 + row, p.N - 1) * p.ldw) + c * 16 + (long)kt_begin * 128;
+        }
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#define SA_ISSUE(BUFOFF, KT)                                                                                            \
+    {                                                                                                                   \
+        const long koff_ = (long)(KT) * 128;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                                \
+            (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                     \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
+            (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, 0);            \
+    }
+        if constexpr (GLDS == 2) {
+            // Two buffers, loop unrolled over both so every LDS offset is an immediate. Tile kt+1 streams into the other
+            // buffer while tile kt is multiplied; the vmcnt(0) + barrier at the end of the iteration both publishes tile
+            // kt+1 and retires every wave's reads of tile kt before its buffer is refilled. Big tiles run best this way:
+            // 64 KiB of LDS keeps two workgroups per CU, which hides more latency than a deeper ring with one (r01 microbench:
+            // 8k^3 985 TF/s with 2 stages, 830-860 with 3-4).
+#define SA_LANDED()                                      \
+    {                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __syncthreads();                                 \
+    }
+            SA_ISSUE(0, 0);
+            SA_LANDED();
+            for (int pi = 0; pi < pairs; ++pi) {
+                const int kt = 2 * pi;
+                SA_ISSUE(BUF, min(kt + 1, last));
+                __builtin_amdgcn_sched_barrier(0);
+                SA_COMPUTE(smem);
+                __builtin_amdgcn_sched_barrier(0);
+                SA_LANDED();
+                SA_ISSUE(0, min(kt + 2, last));
+                __builtin_amdgcn_sched_barrier(0);
+                SA_COMPUTE(smem + BUF);
+                __builtin_amdgcn_sched_barrier(0);
+                SA_LANDED();
+            }
+            if (nk & 1) SA_COMPUTE(smem);
+#undef SA_LANDED
+        } else {
+        // GLDS-stage ring: tiles kt .. kt+GLDS-2 are in flight or resident while tile kt is multiplied. Per iteration:
+        // wait until this wave's loads of tile kt have landed (vmcnt leaves the GLDS-2 younger tiles outstanding), one
+        // raw s_barrier (all waves' parts of tile kt are in LDS, and every wave is done with tile kt-1), refill the
+        // buffer tile kt-1 occupied with tile kt+GLDS-1, multiply tile kt. __syncthreads() is avoided inside the loop: its
+        // fence makes hipcc drain vmcnt to 0, which would collapse the prefetch distance to one tile. Tile indices are
+        // clamped (redundant loads into a dead buffer at the tail) so the number of loads in flight is a constant.
+        constexpr int LPT = XI + WI;                       // loads per tile per wave
+        static_assert((GLDS - 2) * LPT <= 63, "vmcnt range");
+#pragma unroll
+        for (int st = 0; st < GLDS - 1; ++st) SA_ISSUE(st * BUF, min(st, last));
+        int rd = 0, wr = (GLDS - 1) * BUF;                 // byte offsets of the buffer to multiply / to refill
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GLDS - 2) * LPT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            SA_ISSUE(wr, min(kt + GLDS - 1, last));
+            __builtin_amdgcn_sched_barrier(0);
+            SA_COMPUTE(smem + rd);
+            __builtin_amdgcn_sched_barrier(0);
+            rd = rd + BUF == GLDS * BUF ? 0 : rd + BUF;
+            wr = wr + BUF == GLDS * BUF ? 0 : wr + BUF;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: redundant loads must land before LDS is reused below
+        }
+#undef SA_ISSUE
+    } else {
     // global source pointers for this thread's staging chunks (rows clamped into range)
     const unsigned char* xsrc[XCH];
     const unsigned char* wsrc[WCH];
@@ -121,15 +263,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         wdst[i] = XBYTES + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
 
-    f32x16 acc[FN][FM];
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-    const int nk = kt_end - kt_begin;
     // Two statically named register sets (runtime-indexed arrays would be demoted to scratch memory).
     u32x4 xr0[XCH], wr0[WCH], xr1[XCH], wr1[WCH];
 #define SA_FETCH(XR, WR, KT)                                                                   \
@@ -148,35 +281,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         _Pragma("unroll") for (int i = 0; i < WCH; ++i)                                        \
             *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];                       \
     }
-    const int frow = lane & 31, fch = lane >> 5;     // fragment: row = base + (lane & 31), chunk = ks*2 + (lane >> 5)
-#define SA_COMPUTE(CURP)                                                                                       \
-    {                                                                                                          \
-        const unsigned char* cur_ = (CURP);                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                     \
-            u32x4 xf[FM], wf[FN];                                                                              \
-            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
-                const int row = wm * WTM + i * 32 + frow;                                                      \
-                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
-                const int row = wn * WTN + j * 32 + frow;                                                      \
-                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
-                _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], wf[j], xf[i]);         \
-        }                                                                                                      \
-    }
     // iteration kt: the set that held tile kt is free (tile kt already sits in LDS) -> refill it with tile kt+2;
     // compute tile kt; publish tile kt+1 (fetched one iteration ago into the other set) to the other LDS buffer.
     // Fetches and publishes are UNCONDITIONAL (tile index clamped to the last tile, redundant at the tail): with a
     // conditional fetch hipcc cannot count the loads in flight at the merge point and falls back to vmcnt(0) before
     // every fetch, which collapses the prefetch distance to one tile (seen in the r01 ISA: ~1 us per K-iteration).
-    const int last = nk - 1;
     SA_FETCH(xr0, wr0, 0);
     SA_FETCH(xr1, wr1, min(1, last));
     SA_STASH(xr0, wr0, smem);
     __syncthreads();
-    const int pairs = nk >> 1;
     for (int pi = 0; pi < pairs; ++pi) {
         const int kt = 2 * pi;
         // sched_barrier(0) pins fetch -> compute -> publish: left alone, hipcc hoists the publish (and its vmcnt wait for
@@ -197,7 +310,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     if (nk & 1) SA_COMPUTE(smem);          // odd tail: tile nk-1 was published to buffer 0 by the last pair
 #undef SA_FETCH
 #undef SA_STASH
+    }
 #undef SA_COMPUTE
+#undef SA_FRAGS
+#undef SA_MFMAS
 
     // Epilogue through LDS. 32x32 result D[n][m]: a lane owns row m = .. + (lane & 31) and, per register group g, four
     // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
@@ -299,24 +415,23 @@ inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
 inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (BM == 256 ? 1 : 2); }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
     GemmArgs<TI, TO> aa = a;
     if (!SPLIT && BM == 128 && BN == 128) {          // XCD-aware super-tiles for the large-tile configuration
         const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
         if (tm * tn >= 512) {
-            aa.swz_n = std::min(tn, 8);
+            aa.swz_n = cdiv(tn, cdiv(tn, 8));                 // equal-width super-columns of <= 8 tile columns
             aa.swz_m = std::max(1, 64 / aa.swz_n);
-            const int n_super = cdiv(tm, aa.swz_m) * cdiv(tn, aa.swz_n);
-            tiles = cdiv(n_super, 8) * 8 * aa.swz_m * aa.swz_n;
+            tiles = cdiv(tm * tn, 512) * 512;
         }
     }
     constexpr size_t out_w = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
-    constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * 2;
+    constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
     constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
-    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT>;
+    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS>;
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -356,10 +471,13 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if (force_bn == 6464) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);          // experiments (tools/microbench)
             if (force_bn == 12864) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
             if (force_bn == 128128) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
+            // S0xxxxx: direct-to-LDS variants with S stages
+            if (force_bn == 4006464) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 4>(a, s);
             if (!force_bn) {
                 // measured at M = 256 (tools/microbench/gemm_shapes.py): lm_head-sized N -> 128x64 tiles; everything else -> 64x64
-                if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
-                return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
+                // direct-to-LDS variants: gate|up 15.5 us vs 18.4 with register staging, lm_head 82.6 us vs 88.3
+                if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
+                return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
             }
             const int bn = force_bn;
             if (bn == 128) return launch_gemm_cfg<TI, TO, 256, 128, 8, 1, EPI>(a, s);
@@ -375,7 +493,12 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    if (big >= 256) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
+    static const int glds = [] { const char* e = getenv("SURYA_AMD_GLDS"); return e ? atoi(e) : 2; }();
+    if (big >= 256) {
+        if (glds == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
+        if (glds == 3) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 3>(a, s);
+        return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
+    }
     return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
 }
 
@@ -396,11 +519,16 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     // 64x64 tiles (4 M-tiles at M = 256) beat the tall 256-row tiles for these skinny projections: many light
     // workgroups (32 KiB LDS, 4-5 per CU) hide the per-iteration load latency better than few heavy ones
     // (tools/microbench/gemm_shapes.py: unsplit 64x64 11 us vs tall 16 us for qkv at M = 256).
-    static const int mode = [] { const char* e = getenv("SURYA_AMD_SPLIT_TILE"); return e ? atoi(e) : 6464; }();
-    static const int target = [] { const char* e = getenv("SURYA_AMD_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    static const int mode = [] { const char* e = getenv("SURYA_AMD_SPLIT_TILE"); return e ? atoi(e) : 4006464; }();
+    static const int target = [] { const char* e = getenv("SURYA_AMD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
     if (mode == 6464) {
         a.splitk = std::min(pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk, target), 8);
         return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true>(a, s);
+    }
+    if (mode == 2006464 || mode == 4006464) {
+        a.splitk = std::min(pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk, target), 8);
+        return mode == 2006464 ? launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 2>(a, s)
+                               : launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
     }
     a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk, target / 2), 8);
     if (a.M > 128) return launch_gemm_cfg<TI, TI, 256, 32, 8, 1, EPI_BIAS, true>(a, s);
