@@ -135,8 +135,10 @@ int surya_rec_read_outputs(surya_rec* h, int n_steps, int32_t* tokens, float* sc
  *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in
  *                ORIGINAL token order (= get_image_embeddings, common/surya/__init__.py:130-195) to `out`
  *                (device, compute dtype).
- *   copy_last_logits: async D2D copy of the fp32 logits [rows, vocab] of the last prefill/decode call into
- *                `dst` (device, capacity max_rows rows); row r = r-th sequence of the prefill / r-th active slot. */
+ *   copy_last_logits: fp32 logits [rows, vocab] of the last prefill / decode step into `dst` (device, capacity
+ *                max_rows rows); row r = r-th sequence of the prefill / r-th active slot. The product path keeps logits
+ *                in LDS (greedy reduction in the lm_head epilogue), so this recomputes them on `stream` from the
+ *                final-norm rows of that step. */
 int surya_rec_encode_only(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* out, void* stream);
 int surya_rec_copy_last_logits(surya_rec* h, float* dst, int max_rows, int* rows, void* stream);
 /* Force the token fed to the next decode step (teacher forcing in parity tests). */

@@ -26,7 +26,7 @@
 
 namespace sa {
 
-enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5 };
+enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6 };
 
 template <typename TI, typename TO>
 struct GemmArgs {
@@ -39,6 +39,10 @@ struct GemmArgs {
     int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
     int swz_m = 0, swz_n = 0;    // > 0: XCD-aware rasterisation in super-tiles of swz_m x swz_n output tiles (set by the launcher)
+    // EPI_ARGMAX (TO = float): C is not written; instead one float4 {max, bits of the first argmax column, sum exp(v - max), 0}
+    // per (row, tile column) goes to amax[m * cdiv(N, bn_used) + tile_n]; the launcher reports the tile width it chose.
+    float4* amax = nullptr;
+    mutable int bn_used = 0;
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -367,6 +371,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         }
     }
     __syncthreads();
+    if constexpr (EPI == EPI_ARGMAX) {
+        // Greedy-head partials straight from the staged tile: the [M, N] fp32 logits never travel to HBM (84 MB written and
+        // read twice per decode step at V = 81920, M = 256 -- more than the lm_head weights themselves).
+        static_assert(!SPLIT && std::is_same<TO, float>::value, "argmax epilogue works on fp32 tiles");
+        constexpr int TPR = NT / BM;                  // threads per tile row (adjacent lanes)
+        static_assert(NT % BM == 0 && (TPR & (TPR - 1)) == 0 && TPR <= 8 && CPR % TPR == 0, "argmax epilogue split");
+        constexpr int SEG = CPR / TPR;                // 16-byte chunks per thread
+        const int row = tid / TPR, part = tid % TPR;
+        const unsigned char* rowp = smem + row * ROWB;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll 4
+        for (int cc = 0; cc < SEG; ++cc) {
+            const int c = part * SEG + cc, n = n0 + c * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + ((c ^ (row & XM)) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < p.N && v[i] > best) { best = v[i]; bi = n + i; }     // strict >: first maximum wins
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        float se = 0.f;
+#pragma unroll 4
+        for (int cc = 0; cc < SEG; ++cc) {
+            const int c = part * SEG + cc, n = n0 + c * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + ((c ^ (row & XM)) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < p.N) se += expf(v[i] - best);
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) se += __shfl_xor(se, o, 64);
+        if (part == 0 && m0 + row < p.M) p.amax[(long)(m0 + row) * tiles_n + tile_n] = make_float4(best, __int_as_float(bi), se, 0.f);
+        return;
+    }
     constexpr int EPC = 16 / (int)sizeof(TS);                                // elements per 16-byte chunk
     const int n_out = (EPI == EPI_SWIGLU && !SPLIT) ? p.N / 2 : p.N;
     const int n0_out = (EPI == EPI_SWIGLU && !SPLIT) ? n0 / 2 : n0;
@@ -418,6 +461,7 @@ inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
+    a.bn_used = BN;
     GemmArgs<TI, TO> aa = a;
     if (!SPLIT && BM == 128 && BN == 128) {          // XCD-aware super-tiles for the large-tile configuration
         const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
@@ -445,7 +489,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
         pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
         pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
-        const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : a.N;
+        const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : (EPI == EPI_ARGMAX ? 4.0 * cdiv(a.N, BN) : a.N);
         pf.bytes_of[pf.n] = SPLIT ? ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
                                   : ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
                                         (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);

@@ -591,7 +591,10 @@ __global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restric
 // pred = argmax (first max), score = max softmax prob = 1 / sum(exp(x - max)), done = pred in {eos, pad};
 // bbox = trunc(sigmoid(W_b h + b) * bbox_size) (common/surya/__init__.py:329); updates the slot state for
 // the next step (next input token = pad if done, kv_len += 1).
-template <typename T>
+// PART = true: `logits` holds float4 partials {max, argmax bits, sum exp(v - max), 0} per (row, column tile) written by the
+// lm_head GEMM's EPI_ARGMAX epilogue (ldl = V = tiles per row); the combination below is the same reduction with one
+// more level: argmax = first maximum over tiles in column order, sum = sum_t s_t * exp(m_t - max).
+template <typename T, bool PART>
 __global__ __launch_bounds__(256) void greedy_head_kernel(const float* __restrict__ logits, long ldl, int V,
                                                           const T* __restrict__ hidden, int H, const T* __restrict__ wb,
                                                           const T* __restrict__ bb, const int* __restrict__ row_slot,
@@ -599,17 +602,25 @@ __global__ __launch_bounds__(256) void greedy_head_kernel(const float* __restric
                                                           float* __restrict__ out_score, int* __restrict__ out_bbox,
                                                           int* __restrict__ next_token, int* __restrict__ kv_len, int len_inc) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* lr = logits + (long)r * ldl;
+    const float* lr = logits + (long)r * ldl * (PART ? 4 : 1);
     __shared__ float smax[4], ssum[4];
     __shared__ int sidx[4];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = tid * 4; c < V; c += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(lr + c);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (PART) {
+        for (int t = tid; t < V; t += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + 4 * t);
+            const int vi = __float_as_int(v.y);
+            if (v.x > best || (v.x == best && vi < bi)) { best = v.x; bi = vi; }
+        }
+    } else {
+        for (int c = tid * 4; c < V; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + c);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (c + i < V && vv[i] > best) { best = vv[i]; bi = c + i; }
+            for (int i = 0; i < 4; ++i)
+                if (c + i < V && vv[i] > best) { best = vv[i]; bi = c + i; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -624,12 +635,19 @@ __global__ __launch_bounds__(256) void greedy_head_kernel(const float* __restric
     for (int w = 1; w < 4; ++w)
         if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
     float se = 0.f;
-    for (int c = tid * 4; c < V; c += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(lr + c);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (PART) {
+        for (int t = tid; t < V; t += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + 4 * t);
+            se += v.z * expf(v.x - best);
+        }
+    } else {
+        for (int c = tid * 4; c < V; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + c);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (c + i < V) se += expf(vv[i] - best);
+            for (int i = 0; i < 4; ++i)
+                if (c + i < V) se += expf(vv[i] - best);
+        }
     }
     se = wave_sum(se);
     if (lane == 0) ssum[wave] = se;

@@ -165,6 +165,7 @@ struct RecModel : RecBase {
     // decoder workspaces
     T *dx, *dh, *dqkv, *dattn, *dmlp, *dlast;
     float* logits;
+    float4* amax;            // greedy-head partials of the lm_head GEMM: [slot row][column tile]
     float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
     float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
@@ -206,6 +207,7 @@ struct RecModel : RecBase {
         size_t o_dmlp = take(Tm * c.dec_inter * sizeof(T));
         size_t o_dlast = take(S * c.dec_hidden * sizeof(T));
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
+        size_t o_amax = take(S * (size_t)cdiv(c.vocab, 32) * sizeof(float4));
         size_t o_rope = take((size_t)c.max_kv_len * (c.dec_head_dim / 2) * sizeof(float2));
         size_t o_part = take((size_t)8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));
         const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
@@ -221,7 +223,7 @@ struct RecModel : RecBase {
             m->tiles_t = (T*)(b + o_tiles); m->ex = (T*)(b + o_ex); m->eh = (T*)(b + o_eh); m->eqkv = (T*)(b + o_eqkv);
             m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
             m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
-            m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits);
+            m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits); m->amax = (float4*)(b + o_amax);
             m->part = (float*)(b + o_part); m->rope_cs = (float2*)(b + o_rope);
             m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
             m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active); m->row_len = (int*)(b + o_rowlen);
@@ -503,12 +505,16 @@ struct RecModel : RecBase {
         const int Hd = c.dec_hidden;
         int rc;
         if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), dlast, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
+        // lm_head with the greedy reduction in its epilogue: logits stay in LDS, the head combines per-tile partials.
         GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
-        if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
+        a.amax = amax;
+        if ((rc = launch_gemm<T, float, EPI_ARGMAX>(a, s))) return rc;
+        const int tiles_n = cdiv(c.vocab, a.bn_used);
         const size_t so = (size_t)step * c.max_slots;
-        hipLaunchKernelGGL(greedy_head_kernel<T>, dim3(rows), dim3(256), 0, s, logits, (long)c.vocab, c.vocab, dlast, Hd,
-                           W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id, c.pad_token_id, (float)c.bbox_size,
-                           out_token + so, out_score + so, out_bbox + so * 6, next_token, kv_len, len_inc);
+        hipLaunchKernelGGL((greedy_head_kernel<T, true>), dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(amax),
+                           (long)tiles_n, tiles_n, dlast, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
+                           c.pad_token_id, (float)c.bbox_size, out_token + so, out_score + so, out_bbox + so * 6, next_token,
+                           kv_len, len_inc);
         last_rows = rows;
         return (int)hipGetLastError();
     }
@@ -642,10 +648,17 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
+    // Test hook: the product path never materialises logits (EPI_ARGMAX above), so they are recomputed here from the
+    // final-norm rows of the last prefill / decode step, which are still in `dlast`, with the same GEMM main loop.
     int copy_last_logits(float* dst, int max_rows, int* rows, hipStream_t s) override {
         const int r = std::min(max_rows, last_rows);
         *rows = r;
-        if (r > 0) SA_HIP(hipMemcpyAsync(dst, logits, (size_t)r * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (r <= 0) return SA_OK;
+        const int Hd = c.dec_hidden;
+        GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, last_rows, c.vocab, Hd};
+        int rc;
+        if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
+        SA_HIP(hipMemcpyAsync(dst, logits, (size_t)r * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
         return SA_OK;
     }
 

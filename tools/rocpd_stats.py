@@ -30,6 +30,31 @@ def main(path):
     for name, n, tot, mn, mx in rows:
         print(f"| `{short(name)}` | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.1f} |")
     print(f"\ntotal kernel time {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches")
+    if "--gaps" in sys.argv:
+        gaps(c, name_col)
+
+
+def gaps(c, name_col, thresh_us=30.0, top=25):
+    """GPU idle time between consecutive dispatches: total, and the largest gaps with the kernels on either side."""
+    q = f"""select d.start, d.end, s.{name_col} from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s
+            on d.kernel_id = s.id order by d.start"""
+    rows = list(c.execute(q))
+    out, idle_small, idle_big, busy_end = [], 0, 0, rows[0][1]
+    for (st, en, name), prev in zip(rows[1:], rows[:-1]):
+        g = st - busy_end
+        if g > 0:
+            if g / 1e3 >= thresh_us:
+                idle_big += g
+                out.append((g, short(prev[2])[:60], short(name)[:60], (st - rows[0][0]) / 1e6))
+            else:
+                idle_small += g
+        busy_end = max(busy_end, en)
+    span = rows[-1][1] - rows[0][0]
+    print(f"\nspan {span / 1e6:.2f} ms; idle in gaps < {thresh_us:.0f} us: {idle_small / 1e6:.2f} ms; idle in gaps >= {thresh_us:.0f} us: "
+          f"{idle_big / 1e6:.2f} ms ({len(out)} gaps)")
+    print("\n| gap us | at ms | after kernel | before kernel |\n|---|---|---|---|")
+    for g, a, b, t in sorted(out, reverse=True)[:top]:
+        print(f"| {g / 1e3:.1f} | {t:.1f} | `{a}` | `{b}` |")
 
 
 if __name__ == "__main__":
