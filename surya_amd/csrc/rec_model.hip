@@ -21,6 +21,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "decode_attn.h"
+#include "attn_mfma.h"
 
 namespace sa {
 
@@ -291,6 +292,24 @@ struct RecModel : RecBase {
                   hipStream_t s) {
         if (n_tiles <= 0) return SA_OK;
         dim3 grid(n_tiles, heads), block(256);
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            // bf16: matrix-core kernel (attn_mfma.h); SURYA_AMD_ATTN=valu keeps the vector-ALU kernel for A/B runs
+            static const bool valu = [] { const char* e = getenv("SURYA_AMD_ATTN"); return e && e[0] == 'v'; }();
+            if (!valu) {
+#define SA_ATTN_M(DD)                                                                                                    \
+    hipLaunchKernelGGL((attn_mfma_kernel<DD>), grid, dim3(128), 0, s, q, k, v, o, sg, q_row, q_head, k_row, k_head, o_row, \
+                       o_head, group, causal, scale)
+                switch (D) {
+                    case 32: SA_ATTN_M(32); break;
+                    case 64: SA_ATTN_M(64); break;
+                    case 80: SA_ATTN_M(80); break;
+                    case 128: SA_ATTN_M(128); break;
+                    default: return SA_ERR_UNSUPPORTED;
+                }
+#undef SA_ATTN_M
+                return (int)hipGetLastError();
+            }
+        }
 #define SA_ATTN(DD)                                                                                                    \
     hipLaunchKernelGGL((attn_valu_kernel<T, DD>), grid, block, 0, s, q, k, v, o, sg, q_row, q_head, k_row, k_head, o_row, \
                        o_head, group, causal, scale)
