@@ -94,12 +94,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         // X-slabs and W-slabs through that L2 instead of each pulling its own pair from MALL/HBM (n-fastest order gave ~55
         // distinct slabs per 64 tiles and capped the 128x128 GEMM at ~0.65 PF/s, r01 profile).
         // Tiles are numbered in super-tile order (super-rows of swz_m tile rows, cut into super-columns of swz_n tile
-        // columns, edge super-tiles shrunk to what exists, so only valid tiles are numbered); consecutive runs of 64
+        // columns, edge super-tiles shrunk to what exists, so only valid tiles are numbered); consecutive runs of GRP
         // numbers are dealt to the XCDs round-robin. Every XCD gets the same number of tiles: an earlier version dealt
         // whole super-tiles including the clipped ones, and with N = 1280 (10 tile columns = one full + one quarter
         // super-column) the odd XCDs drew only quarter super-tiles and the launch ran at 63 % (r01 microbench).
         const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        const int idx = ((j >> 6) * 8 + x) * 64 + (j & 63);
+        constexpr int GRP = (BM * BN >= 256 * 256) ? 32 : 64;           // workgroups resident on one XCD (32 CUs x 1 or 2)
+        const int idx = ((j / GRP) * 8 + x) * GRP + (j % GRP);
         const int tiles_m = (p.M + BM - 1) / BM;
         if (idx >= tiles_m * tiles_n) return;
         const int per_row = p.swz_m * tiles_n;                          // tiles in a full super-row
@@ -456,19 +457,20 @@ struct GemmProfiler {
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
-inline int gemm_cfg_id(int BM, int BN) { return (BM == 128 && BN == 128) ? 0 : (BM == 256 ? 1 : 2); }
+inline int gemm_cfg_id(int BM, int BN) { return (BM >= 128 && BN >= 128) ? 0 : (BM == 256 ? 1 : 2); }
 
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
     a.bn_used = BN;
     GemmArgs<TI, TO> aa = a;
-    if (!SPLIT && BM == 128 && BN == 128) {          // XCD-aware super-tiles for the large-tile configuration
+    if (!SPLIT && BM >= 128 && BN >= 128) {          // XCD-aware super-tiles for the large-tile configurations
         const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
-        if (tm * tn >= 512) {
+        constexpr int GRP = (BM * BN >= 256 * 256) ? 32 : 64;
+        if (tm * tn >= 8 * GRP) {
             aa.swz_n = cdiv(tn, cdiv(tn, 8));                 // equal-width super-columns of <= 8 tile columns
-            aa.swz_m = std::max(1, 64 / aa.swz_n);
-            tiles = cdiv(tm * tn, 512) * 512;
+            aa.swz_m = std::max(1, GRP / aa.swz_n);
+            tiles = cdiv(tm * tn, 8 * GRP) * 8 * GRP;
         }
     }
     constexpr size_t out_w = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;
@@ -538,6 +540,17 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     static const int glds = [] { const char* e = getenv("SURYA_AMD_GLDS"); return e ? atoi(e) : 2; }();
+    if constexpr (sizeof(TO) == 2) {
+        // 256x256 tiles (8 waves, 64x128 per wave): the 128x128 tile requests 2/128 bytes per MAC row/column pair from L2 and
+        // saturates the L2->CU path at ~15 TB/s (= the same ceiling a load-only kernel reaches, tools/microbench/wstream.hip),
+        // which caps it near 64 flop/B x 15 TB/s ~ 0.95 PF/s; doubling both tile edges halves that traffic.
+        static const int bigtile = [] { const char* e = getenv("SURYA_AMD_BIGTILE"); return e ? atoi(e) : 1; }();
+        // pick by whole rounds of resident workgroups (256 x 1 per CU vs 512 x 2 per CU, in units of 128x128 tiles of work);
+        // measured throughput ratio of the two kernels on full rounds ~1.17 (r01 microbench)
+        const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
+        const double cost256 = (double)cdivl(t256, 256) * 256 * 4 / 1.17, cost128 = (double)cdivl(big, 512) * 512;
+        if (bigtile && t256 >= 256 && cost256 <= cost128) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
+    }
     if (big >= 256) {
         if (glds == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
         if (glds == 3) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 3>(a, s);
