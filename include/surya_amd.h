@@ -131,6 +131,15 @@ int surya_rec_decode(surya_rec* h, int n_steps, void* stream);
  *   tokens int32 [n_steps*max_slots], scores fp32 [n_steps*max_slots], bboxes int32 [n_steps*max_slots*6]. */
 int surya_rec_read_outputs(surya_rec* h, int n_steps, int32_t* tokens, float* scores, int32_t* bboxes, void* stream);
 
+/* Pipelined pair (the reference blocks on .cpu() after every step, recognition/__init__.py:545-576; here the host may run
+ * one call behind the device): decode_async = surya_rec_decode with its outputs in ring half `ring` (0 or 1,
+ * n_steps <= SA_MAX_STEPS / 2) plus an async copy of that half to pinned host memory and an event; wait_outputs blocks on
+ * that event only (NOT on the stream, so a later decode_async may already be queued) and returns the arrays laid out
+ * like read_outputs. A slot whose line finished inside call n still steps through call n + 1; its KV length is clamped
+ * to max_kv_len - 1 on the device and the caller ignores its outputs. */
+int surya_rec_decode_async(surya_rec* h, int n_steps, int ring, void* stream);
+int surya_rec_wait_outputs(surya_rec* h, int n_steps, int ring, int32_t* tokens, float* scores, int32_t* bboxes);
+
 /* Test hooks (tolerance tests of intermediate tensors):
  *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in
  *                ORIGINAL token order (= get_image_embeddings, common/surya/__init__.py:130-195) to `out`

@@ -85,9 +85,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_id = SPLIT ? (int)blockIdx.x / p.splitk : (int)blockIdx.x;
-    const int ks = SPLIT ? (int)blockIdx.x % p.splitk : 0;       // slices of one tile are adjacent workgroups
-    int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+    int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n, ks = 0;
+    if constexpr (SPLIT) {
+        // The tiles_m workgroups that stream the same (W tile, K slice) must sit on ONE XCD so that slice crosses the fabric
+        // once: workgroup b runs on XCD b % 8, so (tile_n, ks) pairs are dealt round-robin to XCDs and the M-tiles of a pair
+        // take consecutive positions in that XCD's queue. With tile_m slowest the four M-tiles landed on four XCDs and the
+        // split-K GEMMs fetched 2.7x their unique bytes (r01 FETCH_SIZE profile).
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int pair = (j / tiles_m) * 8 + x;
+        if (pair >= tiles_n * p.splitk) return;
+        tile_m = j % tiles_m;
+        tile_n = pair / p.splitk;
+        ks = pair % p.splitk;
+    }
     if (!SPLIT && p.swz_n > 0) {
         // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only). Each XCD has a private 4 MiB L2,
         // so the ~64 workgroups resident on one XCD should form a compact patch of output tiles: they then share a few
@@ -461,7 +472,7 @@ inline int gemm_cfg_id(int BM, int BN) { return (BM >= 128 && BN >= 128) ? 0 : (
 
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
-    int tiles = cdiv(a.M, BM) * cdiv(a.N, BN) * (SPLIT ? a.splitk : 1);
+    int tiles = SPLIT ? cdiv(cdiv(a.N, BN) * a.splitk, 8) * 8 * cdiv(a.M, BM) : cdiv(a.M, BM) * cdiv(a.N, BN);
     a.bn_used = BN;
     GemmArgs<TI, TO> aa = a;
     if (!SPLIT && BM >= 128 && BN >= 128) {          // XCD-aware super-tiles for the large-tile configurations

@@ -560,11 +560,13 @@ __global__ __launch_bounds__(256) void splitk_residual_norm_kernel(const float* 
 template <typename T>
 __global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
                                                               const int* __restrict__ active_slots, const int* __restrict__ kv_len,
-                                                              int* __restrict__ row_len, T* __restrict__ x,
+                                                              int Tmax, int* __restrict__ row_len, T* __restrict__ x,
                                                               const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
     const int a = blockIdx.x, lane = threadIdx.x;
     const int slot = active_slots[a];
-    if (lane == 0) row_len[a] = kv_len[slot];      // compact per-row context length for this step's attention kernels
+    // compact per-row context length for this step's attention kernels; clamped so a slot that keeps stepping after its
+    // line finished (the host learns that one call late) overwrites its last cache row instead of its neighbour's first
+    if (lane == 0) row_len[a] = min(kv_len[slot], Tmax - 1);
     const T* src = table + (long)next_token[slot] * H;
     T* xr = x + (long)a * H;
     float ss = 0.f;

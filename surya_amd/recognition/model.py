@@ -98,6 +98,18 @@ class HipRecModel:
                 "surya_rec_read_outputs")
         return self._tok[:n_steps], self._score[:n_steps], self._bbox[:n_steps]
 
+    def decode_async(self, n_steps: int, ring: int):
+        """Enqueue n_steps (<= SA_MAX_STEPS / 2) decode steps whose outputs land in ring half `ring`; no sync."""
+        L.check(self.lib.surya_rec_decode_async(self.handle, C.c_int(n_steps), C.c_int(ring), self._stream), "surya_rec_decode_async")
+
+    def wait_outputs(self, n_steps: int, ring: int):
+        """Block until the decode_async call on `ring` finished (later calls may still be queued); copies of the outputs."""
+        h = L.SA_MAX_STEPS // 2
+        tok, sc, bb = self._tok[ring * h:], self._score[ring * h:], self._bbox[ring * h:]
+        L.check(self.lib.surya_rec_wait_outputs(self.handle, C.c_int(n_steps), C.c_int(ring), L.np_ptr(tok), L.np_ptr(sc, C.c_float),
+                                                L.np_ptr(bb)), "surya_rec_wait_outputs")
+        return tok[:n_steps], sc[:n_steps], bb[:n_steps]
+
     def set_next_tokens(self, slots, tokens):
         s = np.ascontiguousarray(np.asarray(slots, np.int32))
         t = np.ascontiguousarray(np.asarray(tokens, np.int32))

@@ -309,7 +309,7 @@ class RecognitionPredictor(BasePredictor):
         batch_bboxes = np.zeros((n, overall_max_tokens, 6), np.float32)
         batch_pos = [0] * n
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
-        steps_per_sync = max(1, min(settings.RECOGNITION_STEPS_PER_SYNC, 16))
+        steps_per_sync = max(1, min(settings.RECOGNITION_STEPS_PER_SYNC, 8))
         max_prefill = self.model.c.max_prefill_tokens
 
         def record(p_idx, tok, score, bbox):
@@ -319,8 +319,34 @@ class RecognitionPredictor(BasePredictor):
             batch_pos[p_idx] += 1
             scores[p_idx].append(float(score))
 
-        while self.prompt_queue or self.num_active_slots > 0:
+        def absorb(call):
+            """Host half of one decode call: append its tokens, apply the stop rules (reference :583-595)."""
+            k, ring = call
+            tok, sc, bb = self.model.wait_outputs(k, ring)
+            changed = False
+            for step in range(k):
+                for s, p_idx in self.batch_prompt_mapping.items():
+                    if p_idx is None:
+                        continue
+                    record(p_idx, tok[step, s], sc[step, s], bb[step, s])
+                    toks = predicted_tokens[p_idx]
+                    stop = len(toks) >= batch_max_tokens[p_idx] or detect_repeat_token(toks)
+                    if toks[-1] in (eos, pad) or stop:
+                        self.batch_prompt_mapping[s] = None
+                        changed = True
+            if changed:
+                self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
+
+        # The device runs one decode call ahead of the host: call n + 1 is enqueued before call n's tokens are looked at,
+        # so the bookkeeping above overlaps with GPU work. A line that stops inside call n rides along in call n + 1
+        # (its outputs are dropped: the slot is unmapped by then); new lines are admitted only with nothing in flight.
+        inflight, ring = None, 0
+        while self.prompt_queue or self.num_active_slots > 0 or inflight:
             if (self.num_empty_slots / recognition_batch_size) > self.min_prefill_ratio and self.prompt_queue:
+                if inflight:
+                    absorb(inflight)
+                    inflight = None
+                    continue
                 empty = [k for k, v in self.batch_prompt_mapping.items() if v is None]
                 take, ntok = [], 0
                 while self.prompt_queue and len(take) < len(empty):
@@ -339,22 +365,19 @@ class RecognitionPredictor(BasePredictor):
                         self.batch_prompt_mapping[s] = p.id
                 self.model.set_active([k for k, v in self.batch_prompt_mapping.items() if v is not None])
             else:
-                k = steps_per_sync
-                self.model.decode(k)
-                tok, sc, bb = self.model.read_outputs(k)
-                changed = False
-                for step in range(k):
-                    for s, p_idx in self.batch_prompt_mapping.items():
-                        if p_idx is None:
-                            continue
-                        record(p_idx, tok[step, s], sc[step, s], bb[step, s])
-                        toks = predicted_tokens[p_idx]
-                        stop = len(toks) >= batch_max_tokens[p_idx] or detect_repeat_token(toks)   # reference :583-595
-                        if toks[-1] in (eos, pad) or stop:
-                            self.batch_prompt_mapping[s] = None
-                            changed = True
-                if changed:
-                    self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
+                # steps some active line can still need once the call in flight is done (token budgets are known up front)
+                budget = max((batch_max_tokens[p] - len(predicted_tokens[p]) for p in self.batch_prompt_mapping.values()
+                              if p is not None), default=0) - (inflight[0] if inflight else 0)
+                if budget <= 0 and not inflight and self.num_active_slots > 0:
+                    budget = 1                         # a line admitted with a one-token budget still gets its stop-rule step
+                nxt = None
+                if budget > 0:
+                    nxt = (min(steps_per_sync, budget), ring)
+                    self.model.decode_async(*nxt)
+                    ring ^= 1
+                if inflight:
+                    absorb(inflight)
+                inflight = nxt
         return predicted_tokens, torch.from_numpy(batch_bboxes), scores
 
     def prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:

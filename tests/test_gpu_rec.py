@@ -124,6 +124,38 @@ def test_multi_step_decode_matches_single_steps(hip_lib):
         assert np.allclose(s[k][slots], single[k][1][slots])
 
 
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_pipelined_decode_ring_matches_single_steps(hip_lib, monkeypatch, graph):
+    """decode_async / wait_outputs (two calls in flight, alternating ring halves; plain launches and hipGraph replay)
+    produce the same tokens, scores and boxes as synchronous single steps."""
+    monkeypatch.setenv("SURYA_AMD_GRAPH", graph)
+    cfg, sd, m = build("REC-TINY", torch.float32)
+    tiles, seqs = make_prompts(cfg, GRIDS)
+    slots = list(range(len(seqs)))
+    m.prefill(tiles.cuda(), GRIDS, seqs, slots)
+    m.set_active(slots)
+    single = []
+    for _ in range(12):
+        m.decode(1)
+        t, s, b = m.read_outputs(1)
+        single.append((t[0].copy(), s[0].copy(), b[0].copy()))
+    for rep in range(3):                      # the third repetition replays graphs captured in the second (graph = "1")
+        m.prefill(tiles.cuda(), GRIDS, seqs, slots)
+        m.set_active(slots)
+        got, calls = [], [(4, 0), (3, 1), (4, 0), (1, 1)]
+        m.decode_async(*calls[0])
+        for i, call in enumerate(calls):
+            if i + 1 < len(calls):
+                m.decode_async(*calls[i + 1])          # next call is queued before this one is read
+            t, s, b = m.wait_outputs(*call)
+            got += [(t[k].copy(), s[k].copy(), b[k].copy()) for k in range(call[0])]
+        assert len(got) == 12
+        for k in range(12):
+            assert np.array_equal(got[k][0][slots], single[k][0][slots]), (rep, k)
+            assert np.array_equal(got[k][2][slots], single[k][2][slots]), (rep, k)
+            assert np.allclose(got[k][1][slots], single[k][1][slots])
+
+
 def test_slot_reuse_and_partial_active(hip_lib):
     """Continuous batching: finish some slots, refill them with new prompts while others keep decoding; every line's
     tokens equal the oracle's regardless of admission order."""
