@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--det-size", type=int, default=1024)
     ap.add_argument("--det-steps", type=int, default=5)
     ap.add_argument("--cpu-lines", type=int, default=8)
+    ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     return ap.parse_args()
 
 
@@ -211,6 +212,15 @@ def main():
         tk = torch.tensor([total_tokens], device="cuda", dtype=torch.int64)
         dist.all_reduce(tk)
         total_tokens = int(tk.item())
+
+    if args.host_profile and rank == 0:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        pred.generate(prep, args.batch)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
 
     # ---- roofline: one more pass with every GEMM launch bracketed by HIP events on its stream
     roof = None

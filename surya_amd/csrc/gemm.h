@@ -194,6 +194,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
             wg[i] = reinterpret_cast<const unsigned char*>(p.W + (long)min(n0 + row, p.N - 1) * p.ldw) + c * 16 + (long)kt_begin * 128;
         }
+        // Weight stream cache policy: default. Non-temporal weight loads (aux = 2, compile with -DSA_NT_W=1) were measured
+        // on the decode-regime tiles and LOSE here (small-tile GEMMs 41.7 -> 46.9 ms per recognition step): with 64-row
+        // tiles the four M-tiles of a weight slab run on one XCD and share it through that L2, which nt defeats.
+#ifndef SA_NT_W
+#define SA_NT_W 0
+#endif
+        constexpr int W_AUX = (SA_NT_W && (SPLIT || BM * BN <= 128 * 64)) ? 2 : 0;
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
 #define SA_ISSUE(BUFOFF, KT)                                                                                            \
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                                \
             (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                     \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
-            (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, 0);            \
+            (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, W_AUX);        \
     }
         if constexpr (GLDS == 2) {
             // Two buffers, loop unrolled over both so every LDS offset is an immediate. Tile kt+1 streams into the other
