@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsurya_amd.so")
+LIB_PATH = os.environ.get("SURYA_AMD_LIB") or os.path.join(HERE, "libsurya_amd.so")   # env: A/B builds of the kernels
 
 SA_MAX_STEPS = 16
 DTYPE_F32, DTYPE_BF16 = 0, 1

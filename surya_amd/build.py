@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsurya_amd.so")
 SOURCES = ["rec_model.hip", "det_model.hip"]
-HEADERS = ["common.h", "gemm.h", "kernels.h", "det_kernels.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
 def _stale() -> bool:
@@ -30,13 +30,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    # experiment knobs: extra compiler flags (-DSA_...=1) and an alternative output path, loaded through SURYA_AMD_LIB
+    extra = os.environ.get("SURYA_AMD_CXXFLAGS", "").split()
+    out = os.environ.get("SURYA_AMD_LIB_OUT", LIB)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-           *srcs, "-o", LIB + ".tmp"]
+           *extra, *srcs, "-o", out + ".tmp"]
     if verbose:
         print("[surya_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
