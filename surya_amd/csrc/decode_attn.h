@@ -15,6 +15,15 @@
 
 namespace sa {
 
+// Phase timestamps for tools/microbench/decode_attn2_bench.hip (-DSA_DA_TIMING): workgroup (0, 0), thread 0 records the
+// 100 MHz wall clock at phase boundaries. Compiled out of the product library.
+#ifdef SA_DA_TIMING
+__device__ unsigned long long sa_da_stamps[16];
+#define SA_DA_STAMP(i) if (blockIdx.x == 64 && blockIdx.y == 0 && threadIdx.x == 0) sa_da_stamps[i] = wall_clock64();
+#else
+#define SA_DA_STAMP(i)
+#endif
+
 template <typename T, int D, int MAXG>
 __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __restrict__ qkv_part, int S, const T* __restrict__ qkv_bias,
                                                                T* __restrict__ out, T* __restrict__ kc, T* __restrict__ vc,
@@ -36,6 +45,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
     float* xrow = P + MAXG * KT;                             // [(MAXG + 2) * D]
     float* hstat = xrow + (MAXG + 2) * D;                    // [3][MAXG]: running max, running sum, rescale factor
 
+    SA_DA_STAMP(0)
     const int G = nq / nkv;
     const int a = blockIdx.x, kvh = blockIdx.y;
     const int slot = active_slots[a];
@@ -65,6 +75,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
         }
     };
     fetch_tile(0);
+    SA_DA_STAMP(1)
 
     // ---- prologue: q/k/v of this row (split-K slabs + bias), all loads issued before the first wait
     const int qkv_dim = (nq + 2 * nkv) * D;
@@ -92,8 +103,10 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
     }
     for (int i = tid; i < (32 - G) * D; i += 256) qT[G * D + i] = T(0);              // zero the padding heads of the q operand
     if (tid < 3 * MAXG) hstat[tid] = (tid < MAXG) ? -INFINITY : 0.f;
+    SA_DA_STAMP(2)
     stash_tile();
     __syncthreads();
+    SA_DA_STAMP(3)
     // RoPE (decoder/__init__.py:60-84, cos/sin rounded to the storage dtype): q -> qT (scaled), k -> cache + tile, v -> cache + tile
     T* knew_dst = kc + (((long)slot * nkv + kvh) * Tmax + len) * D;
     T* vnew_dst = vc + (((long)slot * nkv + kvh) * Tmax + len) * D;
@@ -122,6 +135,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
         if (new_tile == 0) Ty<T>::st(reinterpret_cast<T*>(Vs + new_row * ROWB) + i, val);
     }
     __syncthreads();
+    SA_DA_STAMP(4)
 
     // ---- per-thread output accumulator: thread (h, d4) for tid < G * D / 4
     const int oh = tid / (D / 4), od = (tid % (D / 4)) * 4;
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
             }
         }
         __syncthreads();
+        SA_DA_STAMP(5)
         // ---- softmax over the tile, one wave per head (waves take heads w, w + 4, ...)
         for (int h = wave; h < G; h += 4) {
             float mx = -INFINITY;
@@ -196,24 +211,286 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const float* __re
             }
         }
         __syncthreads();
+        SA_DA_STAMP(6)
         // ---- O = alpha * O + P . V on the VALU
         if (tid < G * (D / 4)) {
             const float alpha = hstat[2 * MAXG + oh];
 #pragma unroll
             for (int e = 0; e < 4; ++e) oacc[e] *= alpha;
-            for (int j = 0; j < nk; ++j) {
-                const float pj = P[oh * KT + j];
-                float v4[4];
-                load4(reinterpret_cast<const T*>(Vs + j * ROWB) + od, v4);
-                oacc[0] += pj * v4[0]; oacc[1] += pj * v4[1]; oacc[2] += pj * v4[2]; oacc[3] += pj * v4[3];
+            // 8 keys per trip so their LDS reads are in flight together (one key per trip cost a full LDS round trip per
+            // key, ~100 cycles x 100 keys); keys in [nk, nk8) have P = exp(-inf) = 0 and V rows that are clamped duplicates
+            // of a real row, so they add exact zeros.
+            const int nk8 = (nk + 7) & ~7;
+            for (int j0 = 0; j0 < nk8; j0 += 8) {
+                float pj[8], v4[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    pj[u] = P[oh * KT + j0 + u];
+                    load4(reinterpret_cast<const T*>(Vs + (j0 + u) * ROWB) + od, v4[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    oacc[0] += pj[u] * v4[u][0]; oacc[1] += pj[u] * v4[u][1]; oacc[2] += pj[u] * v4[u][2]; oacc[3] += pj[u] * v4[u][3];
+                }
             }
         }
         __syncthreads();
+        SA_DA_STAMP(7)
     }
     if (tid < G * (D / 4)) {
         const float inv = 1.0f / hstat[MAXG + oh];
         store4(out + (long)a * nq * D + (long)(kvh * G + oh) * D + od, oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
     }
+    SA_DA_STAMP(8)
+}
+
+// Third version (bf16): the phase timers of the second version (tools/microbench/decode_attn2_bench.hip -DSA_DA_TIMING)
+// showed 6.2 of its 12.8 us in three barrier-separated compute phases (scores 1.8, tile softmax 1.8, VALU P.V 2.6) and
+// 4.2 us waiting for a K/V fetch that always moved 128 rows per (slot, head). Here:
+//   * K/V rows go global -> LDS directly (global_load_lds, swizzle on the source address, no staging registers, no stash
+//     phase), and only rows up to the context length rounded to a 16-key MFMA step are requested;
+//   * wave w owns keys [32w, 32w + 32) of each 128-key tile and runs its OWN flash-attention state for them:
+//     S^T = K q^T on MFMA (a lane owns one head), per-lane softmax statistics, the exp() registers are the P fragment,
+//     O^T += V^T P^T on MFMA with ds_read_b64_tr_b16 V^T fragments (same recipe as attn_mfma.h) -- no barrier and no LDS
+//     traffic between scores and P.V;
+//   * one split-KV combine of the four waves' (max, sum, O) through LDS at the end.
+template <int D, int MAXG>
+__global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __restrict__ qkv_part, int S, const bf16_t* __restrict__ qkv_bias,
+                                                                bf16_t* __restrict__ out, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                                const int* __restrict__ active_slots, const int* __restrict__ row_len,
+                                                                const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
+                                                                float scale) {
+    typedef bf16_t T;
+    constexpr int CPR = D / 8;                               // 16-byte chunks per K/V row
+    constexpr int ROWB = D * 2;                              // bytes per K/V row
+    constexpr int KT = 128;                                  // keys per LDS tile: 32 per wave
+    constexpr int RPI = 1024 / ROWB;                         // rows moved by one global_load_lds (64 lanes x 16 B)
+    constexpr int XM = CPR >= 16 ? 15 : CPR - 1;             // XOR mask of the K-tile chunk swizzle
+    constexpr int NKK = D / 16, NDB = (D + 31) / 32;
+    constexpr int CW = D + 4;                                // floats per (wave, head) record of the final combine: O[D], max, sum
+    static_assert(D % 32 == 0 && D <= 128 && MAXG <= 32 && 1024 % ROWB == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;                                // [KT][ROWB], chunk c of row r at c ^ (r & XM)
+    unsigned char* Vs = Ks + KT * ROWB;                      // [KT][ROWB], linear
+    T* qT = reinterpret_cast<T*>(Vs + KT * ROWB);            // [32][D] q heads (rows >= G are zero)
+    float* xrow = reinterpret_cast<float*>(qT + 32 * D);     // [(MAXG + 2) * D]
+    float* comb = reinterpret_cast<float*>(qT);              // [4][MAXG][CW], aliases qT + xrow after the key loop
+
+    SA_DA_STAMP(0)
+    const int G = nq / nkv;
+    const int a = blockIdx.x, kvh = blockIdx.y;
+    const int slot = active_slots[a];
+    const int len = row_len[a];                              // cached tokens; the new token sits at index len
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = len + 1;
+    const unsigned char* kb = reinterpret_cast<const unsigned char*>(kc + ((long)slot * nkv + kvh) * Tmax * D);
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vc + ((long)slot * nkv + kvh) * Tmax * D);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // rows of tile `base` that a 16-key MFMA step can touch get finite data (cached rows, clamped duplicates past len);
+    // groups of RPI rows are dealt to the four waves
+    auto issue_tile = [&](int base) {
+        const int rows = min(KT, (total - base + 15) & ~15);
+        const int ngroups = (rows + RPI - 1) / RPI;
+        for (int g = wave; g < ngroups; g += 4) {
+            const int r = g * RPI + lane / CPR, pc = lane % CPR;
+            const long j = min(base + r, max(len - 1, 0));
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + j * ROWB + ((pc ^ (r & XM)) << 4)), (lptr_t)(Ks + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + j * ROWB + (pc << 4)), (lptr_t)(Vs + g * 1024), 16, 0, 0);
+        }
+    };
+    issue_tile(0);
+    SA_DA_STAMP(1)
+
+    // ---- prologue: q/k/v of this row (split-K slabs + bias), all loads issued before the first wait
+    const int qkv_dim = (nq + 2 * nkv) * D;
+    const int Mrows = gridDim.x;
+    const int half = D / 2;
+    const float2 csn = rope_cs[(long)len * half + (tid % half)];
+    constexpr int NI = ((MAXG + 2) * D + 255) / 256;
+    const int n_items = (G + 2) * D;
+    float p8[NI][8], bias_v[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int it = min(tid + k * 256, n_items - 1);
+        const int hh = it / D, i = it % D;
+        const int col = (hh < G ? (kvh * G + hh) * D : (hh == G ? (nq + kvh) * D : (nq + nkv + kvh) * D)) + i;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) p8[k][sidx] = qkv_part[((long)min(sidx, S - 1) * Mrows + a) * qkv_dim + col];
+        bias_v[k] = Ty<T>::ld(qkv_bias + col);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        float val = bias_v[k];
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) val += (sidx < S) ? p8[k][sidx] : 0.f;
+        if (tid + k * 256 < n_items) xrow[tid + k * 256] = Ty<T>::rnd(val);
+    }
+    for (int i = tid; i < (32 - G) * D; i += 256) qT[G * D + i] = T(0);              // zero the padding heads of the q operand
+    SA_DA_STAMP(2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA rows of tile 0 (not tracked by the compiler)
+    __syncthreads();
+    SA_DA_STAMP(3)
+    // RoPE (decoder/__init__.py:60-84, cos/sin rounded to the storage dtype): q -> qT (scaled), k -> cache + tile, v -> cache + tile
+    T* knew_dst = kc + (((long)slot * nkv + kvh) * Tmax + len) * D;
+    T* vnew_dst = vc + (((long)slot * nkv + kvh) * Tmax + len) * D;
+    const int new_tile = len / KT, new_row = len % KT;       // where the new token's row lives among the tiles
+    auto kput = [&](int e, float v) {
+        const int c = e / 8, w = e % 8;
+        Ty<T>::st(reinterpret_cast<T*>(Ks + new_row * ROWB + ((c ^ (new_row & XM)) << 4)) + w, v);
+    };
+    for (int it = tid; it < (G + 1) * half; it += 256) {
+        const int i = it % half, hh = it / half;
+        const float cs = csn.x, sn = csn.y;
+        const float x1 = xrow[hh * D + i], x2 = xrow[hh * D + i + half];
+        const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
+        if (hh < G) {
+            Ty<T>::st(qT + hh * D + i, y1 * scale); Ty<T>::st(qT + hh * D + i + half, y2 * scale);
+        } else {
+            Ty<T>::st(knew_dst + i, y1); Ty<T>::st(knew_dst + i + half, y2);
+            if (new_tile == 0) { kput(i, y1); kput(i + half, y2); }
+        }
+    }
+    for (int i = tid; i < D; i += 256) {
+        const float val = xrow[(G + 1) * D + i];
+        Ty<T>::st(vnew_dst + i, val);
+        if (new_tile == 0) Ty<T>::st(reinterpret_cast<T*>(Vs + new_row * ROWB) + i, val);
+    }
+    __syncthreads();
+    SA_DA_STAMP(4)
+
+    // ---- per-wave flash attention over keys [32 * wave, 32 * wave + 32) of every tile
+    const int hl = lane & 31, h = lane >> 5;                 // this lane's head (column of S^T) and K-half
+    u32x4 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+        qf[kk] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(qT) + hl * ROWB + ((kk * 2 + h) << 4));
+    f32x16 oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int tr_off = (((lane & 15) >> 2) + h * 4) * D + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;   // elements, see attn_mfma.h
+    const int n_tiles = (total + KT - 1) / KT;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int base = t * KT, nk = min(KT, total - base);
+        if (t > 0) {
+            __syncthreads();                                 // every wave is done with the previous tile
+            issue_tile(base);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (new_tile == t) {                             // the new token's row falls into this tile
+                for (int i = tid; i < D; i += 256) Ty<T>::st(reinterpret_cast<T*>(Vs + new_row * ROWB) + i, xrow[(G + 1) * D + i]);
+                for (int it = tid; it < half; it += 256) {
+                    const float cs = csn.x, sn = csn.y;      // it % half == tid % half
+                    const float x1 = xrow[G * D + it], x2 = xrow[G * D + it + half];
+                    kput(it, Ty<T>::rnd(x1 * cs - x2 * sn)); kput(it + half, Ty<T>::rnd(x2 * cs + x1 * sn));
+                }
+                __syncthreads();
+            }
+        }
+        const int k0 = wave * 32;
+        if (k0 < nk) {                                       // wave-uniform
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const int krow = k0 + hl;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * ROWB + (((kk * 2 + h) ^ (krow & XM)) << 4));
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sacc, 0, 0, 0);
+            }
+            float bm = -INFINITY;                            // register 4g + r = key k0 + 8g + 4h + r
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = (k0 + g * 8 + h * 4 + r < nk) ? sacc[4 * g + r] : -INFINITY;
+                    sacc[4 * g + r] = sv;
+                    bm = fmaxf(bm, sv);
+                }
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));          // finite: key k0 is visible
+            const float mnew = fmaxf(mrun, bm);
+            const float alpha = __expf(mrun - mnew);         // exp(-inf) = 0 on the first tile
+            mrun = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(sacc[r] - mnew);
+                sacc[r] = pv;
+                psum += pv;
+            }
+            lrun = lrun * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (k0 + st * 16 < nk) {                     // wave-uniform; rows of a started 16-key step hold finite data
+                    u32x4 pf;
+                    pf[0] = pack2(sacc[8 * st + 0], sacc[8 * st + 1]);
+                    pf[1] = pack2(sacc[8 * st + 2], sacc[8 * st + 3]);
+                    pf[2] = pack2(sacc[8 * st + 4], sacc[8 * st + 5]);
+                    pf[3] = pack2(sacc[8 * st + 6], sacc[8 * st + 7]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vs) + (k0 + st * 16) * D + db * 32 + tr_off;
+                        typedef short s16x4_t __attribute__((ext_vector_type(4)));
+                        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * D));
+                        const s16x8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf),
+                                                                           oacc[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    SA_DA_STAMP(5)
+    // ---- split-KV combine of the four waves
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+    __syncthreads();                                         // qT / xrow are dead: comb aliases them
+    if (hl < G) {
+        float* rec = comb + (wave * MAXG + hl) * CW;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(rec + db * 32 + g * 8 + h * 4) =
+                    make_float4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+        if (h == 0) { rec[D] = mrun; rec[D + 1] = ltot; }
+    }
+    __syncthreads();
+    SA_DA_STAMP(6)
+    if (tid < G * (D / 4)) {
+        const int oh = tid / (D / 4), od = (tid % (D / 4)) * 4;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mx = fmaxf(mx, comb[(w * MAXG + oh) * CW + D]);
+        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* rec = comb + (w * MAXG + oh) * CW;
+            const float e = (rec[D] == -INFINITY) ? 0.f : __expf(rec[D] - mx);       // waves past the context hold (-inf, 0, 0)
+            const float4 o4 = *reinterpret_cast<const float4*>(rec + od);
+            num[0] += e * o4.x; num[1] += e * o4.y; num[2] += e * o4.z; num[3] += e * o4.w;
+            den += e * rec[D + 1];
+        }
+        const float inv = 1.0f / den;
+        store4(out + (long)a * nq * D + (long)(kvh * G + oh) * D + od, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+    }
+    SA_DA_STAMP(7)
+    SA_DA_STAMP(8)
+}
+
+template <int D, int MAXG>
+static inline size_t decode_attn_flash_lds() {
+    const size_t q_x = (size_t)32 * D * 2 + (size_t)(MAXG + 2) * D * 4, comb = (size_t)4 * MAXG * (D + 4) * 4;
+    return (size_t)2 * 128 * D * 2 + (q_x > comb ? q_x : comb) + 64;
 }
 
 template <typename T, int D, int MAXG>

@@ -502,7 +502,33 @@ struct RecModel : RecBase {
         hipLaunchKernelGGL(kern, grid, block, lds, s, part, S, WD(l, SA_RD_QKV_B), dattn, kc, vc, active_dev, row_len, rope_cs, nq, \
                            nkv, c.max_kv_len, scale);                                                                        \
     }
-            if (attn_v1) {
+            static const bool attn_v2 = [] { const char* e = getenv("SURYA_AMD_DECODE_ATTN"); return e && e[0] == '2'; }();
+#define SA_DEC3(DD, GG)                                                                                                      \
+    {                                                                                                                        \
+        auto kern = decode_attn_flash_kernel<DD, GG>;                                                                        \
+        const size_t lds = decode_attn_flash_lds<DD, GG>();                                                                  \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                 \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, part, S, WD(l, SA_RD_QKV_B), dattn, kc, vc, active_dev, row_len, rope_cs, nq, \
+                           nkv, c.max_kv_len, scale);                                                                        \
+    }
+            bool done3 = false;
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (!attn_v1 && !attn_v2) {              // bf16 default: per-wave flash kernel (decode_attn.h, third version)
+                    done3 = true;
+                    if (d == 128 && G <= 5) SA_DEC3(128, 5)
+                    else if (d == 128 && G <= 8) SA_DEC3(128, 8)
+                    else if (d == 64 && G <= 8) SA_DEC3(64, 8)
+                    else if (d == 32 && G <= 8) SA_DEC3(32, 8)
+                    else done3 = false;
+                }
+            }
+#undef SA_DEC3
+            if (done3) {
+            } else if (attn_v1) {
                 if (d == 128 && G <= 5) SA_DEC1(128, 5);
                 else if (d == 128) SA_DEC1(128, 8);
                 else if (d == 64) SA_DEC1(64, 8);
