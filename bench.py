@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--det-steps", type=int, default=5)
     ap.add_argument("--cpu-lines", type=int, default=8)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="smoke test of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo)")
     return ap.parse_args()
 
 
@@ -82,7 +85,7 @@ def read_profile(lib, L):
     n = 4
     launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
     L.check(lib.surya_prof_read(n, launches, ms, fl, by), "surya_prof_read")
-    names = ["gemm_nt 128x128 (encoder + prefill GEMMs)", "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)",
+    names = ["gemm_nt 128x128 / 256x256 (encoder + prefill GEMMs, lm_head)", "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)",
              "gemm_nt small tiles", "conv_gemm (implicit-GEMM convolutions, NHWC)"]
     return [{"kernel": names[i], "launches": launches[i], "ms": ms[i], "tflops": (fl[i] / ms[i] / 1e9) if ms[i] else 0.0,
              "gbs": (by[i] / ms[i] / 1e6) if ms[i] else 0.0} for i in range(n) if launches[i]]
@@ -152,11 +155,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); the product path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
     if args.steps_per_sync:
         os.environ["RECOGNITION_STEPS_PER_SYNC"] = str(args.steps_per_sync)

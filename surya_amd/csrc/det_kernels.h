@@ -254,6 +254,71 @@ __global__ void dwconv_kernel(const T* __restrict__ in, const T* __restrict__ w,
     for (int i = 0; i < V; i += 4) store4(o + i, acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
 }
 
+// Register-blocked variant for the shapes the detector uses (K = 3 / 5, stride 1 / 2): one thread = TX consecutive output
+// pixels of a row x 16 bytes of channels. The plain kernel above reads every input vector K*K times through L1/L2 (the
+// L2->CU path, not HBM, was its limit: 142 us average per launch in the r01 profile); here a loaded input column serves
+// up to K outputs from registers. Accumulation order per output is unchanged (ky outer, kx inner).
+template <typename T, int K, int S, int TX>
+__global__ __launch_bounds__(256) void dwconv_tx_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias,
+                                                        T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pad, int act) {
+    constexpr int V = Ty<T>::V16;
+    constexpr int NIN = (TX - 1) * S + K;            // input columns feeding TX outputs
+    const int cv = C / V, wx = (Wo + TX - 1) / TX;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Ho * wx * cv) return;
+    const int c0 = (int)(idx % cv) * V;
+    const long t = idx / cv;
+    const int ox0 = (int)(t % wx) * TX, oy = (int)((t / wx) % Ho), b = (int)(t / ((long)wx * Ho));
+    float acc[TX][V];
+    if (bias) {
+        float bv[V];
+        unpack16(*reinterpret_cast<const uint4*>(bias + c0), bv, (T*)nullptr);
+#pragma unroll
+        for (int o = 0; o < TX; ++o)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[o][i] = bv[i];
+    } else {
+#pragma unroll
+        for (int o = 0; o < TX; ++o)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[o][i] = 0.f;
+    }
+    const int ix0 = ox0 * S - pad;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S + ky - pad;
+        if (iy < 0 || iy >= H) continue;
+        const T* row = in + ((long)b * H + iy) * W * C + c0;
+        float xin[NIN][V];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int ix = ix0 + j;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (ix >= 0 && ix < W) raw = *reinterpret_cast<const uint4*>(row + (long)ix * C);
+            unpack16(raw, xin[j], (T*)nullptr);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            float wv[V];
+            unpack16(*reinterpret_cast<const uint4*>(w + (long)(ky * K + kx) * C + c0), wv, (T*)nullptr);
+#pragma unroll
+            for (int o = 0; o < TX; ++o)
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[o][i] += xin[o * S + kx][i] * wv[i];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < TX; ++o) {
+        if (ox0 + o >= Wo) break;
+        float r[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = act == ACT_HSWISH ? hardswish_f(acc[o][i]) : (act == ACT_RELU ? fmaxf(acc[o][i], 0.f) : acc[o][i]);
+        T* op = out + (((long)b * Ho + oy) * Wo + ox0 + o) * C + c0;
+#pragma unroll
+        for (int i = 0; i < V; i += 4) store4(op + i, r[i], r[i + 1], r[i + 2], r[i + 3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Grouped 1x1 convolution with group size GD in == GD out (LiteMLA aggreg[1], encoderdecoder.py:317):
 // out[p, g*GD + o] = sum_i in[p, g*GD + i] * w[g*GD + o][i]. Workgroup = 8 pixels x one group (GD <= 32 lanes each).
