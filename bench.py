@@ -81,6 +81,18 @@ def cpu_baseline(cfg, sd, prep, n_lines, max_tokens):
                       f"{sum(len(t) for t in toks)} tokens in {dt:.1f}s"}
 
 
+def traffic_for(kernel):
+    """HBM-side bytes per launch of the bucket from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this same
+    command (gfx950 read correction applied), recorded in profiles/hbm_traffic.json by tools/rocpd_pmc.py --json; None if
+    that file has no entry (PMC passes cannot run inside the timed process)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
 def read_profile(lib, L):
     n = 4
     launches = (C.c_int * n)(); ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
@@ -241,8 +253,14 @@ def main():
         dom = max(cats, key=lambda c: c["ms"])
         mfma_bound = dom["kernel"].startswith("gemm_nt 128")
         ach, peak, unit = (dom["tflops"], PEAK_BF16_TFLOPS, "TFLOP/s") if mfma_bound else (dom["gbs"], PEAK_HBM_GBS, "GB/s")
+        null_ms = C.c_double()
+        L.check(lib.surya_prof_event_overhead(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(null_ms)), "surya_prof_event_overhead")
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
-                "unit": unit, "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic_for(dom["kernel"]),
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                # an event pair around an EMPTY kernel costs this much: rocprofv3's begin->end duration of the same launches
+                # lies between avg_launch_ms - event_pair_null_ms and avg_launch_ms
+                "event_pair_null_ms": round(null_ms.value, 4),
                 "launches_per_step": dom["launches"],
                 "all_gemm_configs": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in cats]}
 

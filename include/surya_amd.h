@@ -213,6 +213,8 @@ int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float*
  * ---------------------------------------------------------------------------------------------------------- */
 int surya_prof_enable(int on);
 int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes);
+/* Median event-pair time (ms) around an empty kernel on `stream`: the fixed cost inside every per-launch figure above. */
+int surya_prof_event_overhead(void* stream, double* ms);
 
 #ifdef __cplusplus
 }

@@ -901,6 +901,32 @@ int surya_prof_enable(int on) {
     return SA_OK;
 }
 
+__global__ void prof_null_kernel() {}
+
+// Median hipEvent-pair time around an EMPTY one-workgroup kernel, launched back to back like the profiled GEMMs: what an
+// event pair costs by itself (dispatch latency + minimal kernel), so a reader can reconcile bench.py's event-bracketed
+// per-launch times with rocprofv3's begin->end kernel durations for microsecond-scale kernels.
+int surya_prof_event_overhead(void* stream, double* ms) {
+    if (!ms) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int N = 201;
+    hipEvent_t ev[2 * N];
+    for (auto& e : ev) SA_HIP(hipEventCreate(&e));
+    for (int i = 0; i < 32; ++i) hipLaunchKernelGGL(prof_null_kernel, dim3(1), dim3(64), 0, s);
+    for (int i = 0; i < N; ++i) {
+        SA_HIP(hipEventRecord(ev[2 * i], s));
+        hipLaunchKernelGGL(prof_null_kernel, dim3(1), dim3(64), 0, s);
+        SA_HIP(hipEventRecord(ev[2 * i + 1], s));
+    }
+    SA_HIP(hipStreamSynchronize(s));
+    std::vector<float> t(N);
+    for (int i = 0; i < N; ++i) SA_HIP(hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    std::sort(t.begin(), t.end());
+    *ms = t[N / 2];
+    return SA_OK;
+}
+
 int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes) {
     GemmProfiler& pf = gemm_profiler();
     if (!launches || !ms || !flops || !bytes || max_cfg < GemmProfiler::NCFG) return SA_ERR_ARG;

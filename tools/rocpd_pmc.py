@@ -29,8 +29,37 @@ def short(name):
     return name[:100]
 
 
+def bucket(name):
+    """bench.py's profiler buckets (gemm_cfg_id in surya_amd/csrc/gemm.h) from the mangled kernel name."""
+    m = re.search(r"gemm_nt_kernelI..Li(\d+)ELi(\d+)E", name)
+    if m:
+        bm, bn = int(m.group(1)), int(m.group(2))
+        if bm >= 128 and bn >= 128:
+            return "gemm_nt 128x128 / 256x256 (encoder + prefill GEMMs, lm_head)"
+        return "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)" if bm == 256 else "gemm_nt small tiles"
+    return "conv_gemm (implicit-GEMM convolutions, NHWC)" if "conv_gemm_kernel" in name else None
+
+
+def as_json(rows):
+    """{bucket: HBM-side bytes per launch} = (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the bucket / its dispatches."""
+    import json
+    tot, n = {}, {}
+    for name, ctr, cnt, mean, total, dur in rows:
+        b = bucket(name)
+        if b is None:
+            continue
+        tot[b] = tot.get(b, 0.0) + total * 1024 * (2 if ctr == "FETCH_SIZE" else 1)
+        if ctr == "FETCH_SIZE":
+            n[b] = n.get(b, 0) + cnt
+    print(json.dumps({b: round(tot[b] / n[b]) for b in tot if n.get(b)}, indent=1))
+
+
 def main(paths):
+    js = "--json" in paths
+    paths = [p for p in paths if p != "--json"]
     rows = [r for p in paths for r in load(p)]
+    if js:
+        return as_json(rows)
     rows.sort(key=lambda r: -r[4])
     print("| kernel | counter | dispatches | mean KiB / dispatch | x2 (gfx950 read correction) MB | total MB | mean us (under PMC) |")
     print("|---|---|---|---|---|---|---|")
