@@ -117,6 +117,15 @@ int surya_rec_plan_encoder(const surya_rec_config* cfg, const int32_t* grid_hw, 
 int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, const int32_t* input_ids,
                       const int32_t* seq_offsets, const int32_t* slot_ids, int n_seqs, void* stream);
 
+/* Look-ahead encoding (no counterpart in the reference, which encodes inside the prefill call, common/surya/__init__.py:
+ * 130-195): run the vision encoder for the images of the NEXT prompts on the library's own low-priority stream (after
+ * the work already queued on `stream`, which produced `tiles`), concurrently with decode steps on `stream`. The merged
+ * image embeddings stay inside the handle; a later surya_rec_prefill with tiles == NULL consumes them front to back
+ * (its images must be the next ones in the order given here; grid_hw is still required). At most one look-ahead batch is
+ * outstanding: SA_ERR_STATE while the previous one has unconsumed images, SA_ERR_SHAPE above max_prefill_tokens image
+ * tokens. Enqueue only. */
+int surya_rec_encode_ahead(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* stream);
+
 /* Set the list of slots that take part in decode steps (host bookkeeping of batch_prompt_mapping,
  * recognition/__init__.py:125-136). */
 int surya_rec_set_active(surya_rec* h, const int32_t* slots, int n_active, void* stream);

@@ -204,6 +204,16 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ q,
 // = inverse window permutation (encoder/__init__.py:669-670) + 2-D learned position embedding
 // (common/surya/__init__.py:233-272,193) + masked_scatter into the <IMAGE> positions (:214-225).
 // Rounding follows the reference: (h + w) -> T, feature + that -> T.
+// dst[dst_row[r]] = src[r] (rows of H elements): image embeddings encoded ahead -> their <IMAGE> positions of the packed prompt.
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, const int* __restrict__ dst_row, T* __restrict__ dst, int H) {
+    const int r = blockIdx.x;
+    const T* s = src + (long)r * H;
+    T* d = dst + (long)dst_row[r] * H;
+    for (int c = threadIdx.x * Ty<T>::V16; c < H; c += blockDim.x * Ty<T>::V16)
+        *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(s + c);
+}
+
 template <typename T>
 __global__ void scatter_image_kernel(const T* __restrict__ merged, const T* __restrict__ hemb, const T* __restrict__ wemb,
                                      const int* __restrict__ dst_row, const int* __restrict__ hidx, const int* __restrict__ widx,

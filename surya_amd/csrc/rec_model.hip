@@ -145,6 +145,7 @@ struct RecBase {
     virtual ~RecBase() {}
     virtual int prefill(const float*, const int32_t*, int, const int32_t*, const int32_t*, const int32_t*, int, hipStream_t) = 0;
     virtual int set_active(const int32_t*, int, hipStream_t) = 0;
+    virtual int encode_ahead(const float*, const int32_t*, int, hipStream_t) = 0;
     virtual int decode(int, hipStream_t) = 0;
     virtual int read_outputs(int, int32_t*, float*, int32_t*, hipStream_t) = 0;
     virtual int decode_async(int, int, hipStream_t) = 0;
@@ -162,7 +163,12 @@ struct RecModel : RecBase {
     std::vector<const void*> w;
     char* arena = nullptr;
     size_t arena_bytes = 0;
-    Stager st, st_small;
+    Stager st, st_small, st_enc;                         // st_enc: plans of the look-ahead encoder (its own stream)
+    hipStream_t estream = nullptr;                       // low-priority stream of the look-ahead encoder
+    hipEvent_t ev_ahead_in = nullptr, ev_ahead_done = nullptr, ev_ahead_free = nullptr;
+    T* emb_ahead = nullptr;                              // [max_prefill_tokens][dec_hidden] image embeddings encoded ahead
+    long ahead_tokens = 0, ahead_consumed = 0;
+    bool ahead_free_recorded = false;
     // encoder workspaces
     T *tiles_t, *ex, *eh, *eqkv, *emlp, *emh, *emerged;
     // decoder workspaces
@@ -210,6 +216,7 @@ struct RecModel : RecBase {
         size_t o_dattn = take(Tm * c.dec_heads * c.dec_head_dim * sizeof(T));
         size_t o_dmlp = take(Tm * c.dec_inter * sizeof(T));
         size_t o_dlast = take(S * c.dec_hidden * sizeof(T));
+        size_t o_ahead = take(Tm * c.dec_hidden * sizeof(T));
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
         size_t o_amax = take(S * (size_t)cdiv(c.vocab, 32) * sizeof(float4));
         size_t o_rope = take((size_t)c.max_kv_len * (c.dec_head_dim / 2) * sizeof(float2));
@@ -227,7 +234,7 @@ struct RecModel : RecBase {
             m->tiles_t = (T*)(b + o_tiles); m->ex = (T*)(b + o_ex); m->eh = (T*)(b + o_eh); m->eqkv = (T*)(b + o_eqkv);
             m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
             m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
-            m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->logits = (float*)(b + o_logits); m->amax = (float4*)(b + o_amax);
+            m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->emb_ahead = (T*)(b + o_ahead); m->logits = (float*)(b + o_logits); m->amax = (float4*)(b + o_amax);
             m->part = (float*)(b + o_part); m->rope_cs = (float2*)(b + o_rope);
             m->kcache = (T*)(b + o_k); m->vcache = (T*)(b + o_v);
             m->kv_len = (int*)(b + o_kvlen); m->next_token = (int*)(b + o_next); m->active_dev = (int*)(b + o_active); m->row_len = (int*)(b + o_rowlen);
@@ -260,6 +267,18 @@ struct RecModel : RecBase {
         if (rc) return rc;
         rc = st_small.init((size_t)c.max_slots * 4 * sizeof(int) + 4096);
         if (rc) return rc;
+        rc = st_enc.init((Pm * 8 + (size_t)c.max_slots * 64) * sizeof(int) + (1 << 20));
+        if (rc) return rc;
+        {   // the look-ahead encoder runs beside the decode steps: lowest priority, so decode kernels get CUs first
+            int least = 0, greatest = 0;
+            SA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            // (confining the encoder to a CU mask instead -- 128 / 192 / 224 CUs, prefix or strided -- was measured and is
+            // slower than priority alone: 2599-2719 vs 2799 lines/s on 1024 lines, r01)
+            SA_HIP(hipStreamCreateWithPriority(&estream, hipStreamNonBlocking, least));
+            SA_HIP(hipEventCreateWithFlags(&ev_ahead_in, hipEventDisableTiming));
+            SA_HIP(hipEventCreateWithFlags(&ev_ahead_done, hipEventDisableTiming));
+            SA_HIP(hipEventCreateWithFlags(&ev_ahead_free, hipEventDisableTiming));
+        }
         SA_HIP(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
         SA_HIP(hipEventCreateWithFlags(&gev_in, hipEventDisableTiming));
         SA_HIP(hipEventCreateWithFlags(&gev_out, hipEventDisableTiming));
@@ -278,7 +297,9 @@ struct RecModel : RecBase {
         if (gev_in) (void)hipEventDestroy(gev_in);
         if (gev_out) (void)hipEventDestroy(gev_out);
         for (auto e : ev_ring) if (e) (void)hipEventDestroy(e);
-        st.destroy(); st_small.destroy();
+        st.destroy(); st_small.destroy(); st_enc.destroy();
+        if (estream) (void)hipStreamDestroy(estream);
+        for (hipEvent_t e : {ev_ahead_in, ev_ahead_done, ev_ahead_free}) if (e) (void)hipEventDestroy(e);
         if (arena) (void)hipFree(arena);
         if (out_host) (void)hipHostFree(out_host);
     }
@@ -335,6 +356,10 @@ struct RecModel : RecBase {
     // Vision encoder for images [0, n) whose tiles start at `tiles`; merged tokens (original order index g)
     // are written to dst + dst_rows[g] * dec_hidden. Chunks on image boundaries when P exceeds max_patches.
     int encode(const float* tiles, const int32_t* grid_hw, int n, const std::vector<int>& dst_rows, T* dst, hipStream_t s) {
+        return encode(tiles, grid_hw, n, dst_rows, dst, s, st);
+    }
+    int encode(const float* tiles, const int32_t* grid_hw, int n, const std::vector<int>& dst_rows, T* dst, hipStream_t s,
+               Stager& st) {
         const int unit = c.merge * c.merge, He = c.enc_hidden, D = He / c.enc_heads;
         int i0 = 0;
         long patch_base = 0, tok_base = 0;
@@ -426,6 +451,29 @@ struct RecModel : RecBase {
         std::vector<int> ident(ntok);
         for (long i = 0; i < ntok; ++i) ident[i] = (int)i;
         return encode(tiles, grid_hw, n, ident, reinterpret_cast<T*>(out), s);
+    }
+
+    // Look-ahead encoding: the vision encoder needs no KV slots, so the images of the NEXT lines in the queue are encoded on
+    // a second (low-priority) stream while the current lines decode -- the decode phase is a chain of short latency-bound
+    // kernels that leaves most of the chip idle (two bench processes on one GPU: 3149 vs 2727 lines/s, r01). The embeddings
+    // land in emb_ahead in image order; prefill(tiles = NULL, ...) consumes them front to back.
+    int encode_ahead(const float* tiles, const int32_t* grid_hw, int n, hipStream_t s) override {
+        if (c.enc_out_hidden != c.dec_hidden) return SA_ERR_SHAPE;
+        if (ahead_consumed != ahead_tokens) return SA_ERR_STATE;         // previous look-ahead not fully consumed
+        long ntok = 0;
+        for (int i = 0; i < n; ++i) ntok += (long)grid_hw[2 * i] * grid_hw[2 * i + 1] / (c.merge * c.merge);
+        if (ntok > std::max(c.max_prefill_tokens, c.max_slots)) return SA_ERR_SHAPE;
+        std::vector<int> ident(ntok);
+        for (long i = 0; i < ntok; ++i) ident[i] = (int)i;
+        SA_HIP(hipEventRecord(ev_ahead_in, s));                          // tiles were produced on the caller's stream
+        SA_HIP(hipStreamWaitEvent(estream, ev_ahead_in, 0));
+        if (ahead_free_recorded) SA_HIP(hipStreamWaitEvent(estream, ev_ahead_free, 0));   // last consumer of emb_ahead is done
+        int rc = encode(tiles, grid_hw, n, ident, emb_ahead, estream, st_enc);
+        if (rc) return rc;
+        SA_HIP(hipEventRecord(ev_ahead_done, estream));
+        ahead_tokens = ntok;
+        ahead_consumed = 0;
+        return SA_OK;
     }
 
     // ------------------------------------------------------------------------------------------ decoder
@@ -619,7 +667,22 @@ struct RecModel : RecBase {
             if ((rc = st.flush(s))) return rc;
             hipLaunchKernelGGL(embed_tokens_kernel<T>, dim3(Ttot), dim3(128), 0, s, W(SA_RW_TOK_EMBED), d_ids, dx, c.dec_hidden);
         }
-        if (n_images > 0 && (rc = encode(tiles, grid_hw, n_images, img_pos, dx, s))) return rc;
+        if (n_images > 0 && tiles) {
+            if ((rc = encode(tiles, grid_hw, n_images, img_pos, dx, s))) return rc;
+        } else if (n_images > 0) {
+            // embeddings were encoded ahead (encode_ahead): take the next ntok rows of emb_ahead
+            if (ahead_consumed + ntok > ahead_tokens) return SA_ERR_STATE;
+            st.begin();
+            const int* d_img = st.put(img_pos);
+            if (!d_img) return SA_ERR_NOMEM;
+            if ((rc = st.flush(s))) return rc;
+            SA_HIP(hipStreamWaitEvent(s, ev_ahead_done, 0));
+            hipLaunchKernelGGL(scatter_rows_kernel<T>, dim3((unsigned)ntok), dim3(128), 0, s, emb_ahead + ahead_consumed * c.dec_hidden,
+                               d_img, dx, c.dec_hidden);
+            ahead_consumed += ntok;
+            SA_HIP(hipEventRecord(ev_ahead_free, s));
+            ahead_free_recorded = true;
+        }
         st.begin();
         const int* d_tok_slot = st.put(tok_slot);
         const int* d_tok_pos = st.put(tok_pos);
@@ -848,8 +911,12 @@ int surya_rec_plan_encoder(const surya_rec_config* cfg, const int32_t* grid_hw, 
 
 int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, const int32_t* input_ids,
                       const int32_t* seq_offsets, const int32_t* slot_ids, int n_seqs, void* stream) {
-    if (!h || !input_ids || !seq_offsets || !slot_ids || (n_images > 0 && (!tiles || !grid_hw))) return SA_ERR_ARG;
+    if (!h || !input_ids || !seq_offsets || !slot_ids || (n_images > 0 && !grid_hw)) return SA_ERR_ARG;   // tiles == NULL: look-ahead mode
     return h->impl->prefill(tiles, grid_hw, n_images, input_ids, seq_offsets, slot_ids, n_seqs, (hipStream_t)stream);
+}
+int surya_rec_encode_ahead(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* stream) {
+    if (!h || !tiles || !grid_hw || n_images <= 0) return SA_ERR_ARG;
+    return h->impl->encode_ahead(tiles, grid_hw, n_images, (hipStream_t)stream);
 }
 int surya_rec_set_active(surya_rec* h, const int32_t* slots, int n_active, void* stream) {
     if (!h || (n_active > 0 && !slots)) return SA_ERR_ARG;

@@ -70,7 +70,8 @@ class HipRecModel:
 
     # ---------------------------------------------------------------------------------------------- calls
     def prefill(self, tiles: torch.Tensor, grid_hw, input_ids: Sequence[Sequence[int]], slot_ids: Sequence[int]):
-        """tiles: cuda fp32 [P, patch_dim] (or None); grid_hw: [n_images, 2]; input_ids: per-sequence prompt ids."""
+        """tiles: cuda fp32 [P, patch_dim], or None to consume embeddings queued by encode_ahead; grid_hw: [n_images, 2];
+        input_ids: per-sequence prompt ids."""
         torch.cuda.set_device(self.device)
         grid = np.ascontiguousarray(np.asarray(grid_hw, np.int32).reshape(-1, 2))
         offs = np.zeros(len(input_ids) + 1, np.int32)
@@ -83,6 +84,16 @@ class HipRecModel:
         L.check(self.lib.surya_rec_prefill(self.handle, L.ptr(tiles), L.np_ptr(grid), C.c_int(len(grid)), L.np_ptr(flat),
                                            L.np_ptr(offs), L.np_ptr(slots), C.c_int(len(slots)), self._stream),
                 "surya_rec_prefill")
+
+    def encode_ahead(self, tiles: torch.Tensor, grid_hw):
+        """Encode the images of the next prompts on the library's low-priority stream (overlaps with decode steps); the
+        following prefill(None, ...) calls consume the embeddings in this order."""
+        torch.cuda.set_device(self.device)
+        grid = np.ascontiguousarray(np.asarray(grid_hw, np.int32).reshape(-1, 2))
+        assert tiles.is_cuda and tiles.dtype == torch.float32 and tiles.is_contiguous()
+        assert tiles.shape[0] == int((grid[:, 0] * grid[:, 1]).sum()) and tiles.shape[1] == self.cfg.encoder.patch_dim
+        L.check(self.lib.surya_rec_encode_ahead(self.handle, L.ptr(tiles), L.np_ptr(grid), C.c_int(len(grid)), self._stream),
+                "surya_rec_encode_ahead")
 
     def set_active(self, slots: Sequence[int]):
         a = np.ascontiguousarray(np.asarray(slots, np.int32))

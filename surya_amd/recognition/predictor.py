@@ -337,6 +337,26 @@ class RecognitionPredictor(BasePredictor):
             if changed:
                 self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
 
+        # Look-ahead encoding (RECOGNITION_ENCODE_AHEAD, default on): the vision encoder of the next up-to-batch-size queued
+        # lines runs on the model's second stream while the current lines decode; prefill then only scatters the finished
+        # embeddings and runs the decoder over the prompts. Scheduling decisions (which lines, which slots, when) are unchanged.
+        look_ahead = settings.RECOGNITION_ENCODE_AHEAD
+        ahead = deque()
+        ahead_cap = max(self.model.c.max_prefill_tokens, self.model.c.max_slots)
+        merge2 = self.model.cfg.encoder.spatial_merge_size ** 2
+
+        def encode_ahead():
+            cand, ntok_img = [], 0
+            for p in self.prompt_queue:
+                t = int(grids[p.id][0]) * int(grids[p.id][1]) // merge2
+                if len(cand) >= recognition_batch_size or (cand and ntok_img + t > ahead_cap):
+                    break
+                cand.append(p.id)
+                ntok_img += t
+            a_, b_ = int(tile_offs[cand[0]]), int(tile_offs[cand[-1] + 1])
+            self.model.encode_ahead(tiles[a_:b_], [grids[i] for i in cand])
+            ahead.extend(cand)
+
         # The device runs one decode call ahead of the host: call n + 1 is enqueued before call n's tokens are looked at,
         # so the bookkeeping above overlaps with GPU work. A line that stops inside call n rides along in call n + 1
         # (its outputs are dropped: the slot is unmapped by then); new lines are admitted only with nothing in flight.
@@ -348,8 +368,10 @@ class RecognitionPredictor(BasePredictor):
                     inflight = None
                     continue
                 empty = [k for k, v in self.batch_prompt_mapping.items() if v is None]
+                if look_ahead and not ahead:
+                    encode_ahead()                     # nothing encoded yet (first batch): the prefill below waits for it
                 take, ntok = [], 0
-                while self.prompt_queue and len(take) < len(empty):
+                while self.prompt_queue and len(take) < len(empty) and (not look_ahead or len(take) < len(ahead)):
                     L_ = len(prompt_ids[self.prompt_queue[0].id])
                     if take and ntok + L_ > max_prefill:
                         break
@@ -357,7 +379,14 @@ class RecognitionPredictor(BasePredictor):
                     ntok += L_
                 slots = empty[: len(take)]
                 a, b = int(tile_offs[take[0].id]), int(tile_offs[take[-1].id + 1])   # queue order == id order
-                self.model.prefill(tiles[a:b], [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
+                if look_ahead:
+                    for p in take:
+                        assert ahead.popleft() == p.id
+                    self.model.prefill(None, [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
+                    if not ahead and self.prompt_queue:
+                        encode_ahead()                 # the next lines' encoder pass runs beside the decode steps below
+                else:
+                    self.model.prefill(tiles[a:b], [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
                 tok, sc, bb = self.model.read_outputs(1)
                 for p, s in zip(take, slots):
                     record(p.id, tok[0, s], sc[0, s], bb[0, s])

@@ -43,6 +43,7 @@ class Settings:
         self.RECOGNITION_PAD_VALUE: int = _env("RECOGNITION_PAD_VALUE", int, 255)
         # this implementation only
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
+        self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
         self.SURYA_AMD_REC_CONFIG: str = _env("SURYA_AMD_REC_CONFIG", str, "REC-FULL")
         self.SURYA_AMD_DET_CONFIG: str = _env("SURYA_AMD_DET_CONFIG", str, "DET-DEFAULT")
 
