@@ -156,6 +156,46 @@ def test_pipelined_decode_ring_matches_single_steps(hip_lib, monkeypatch, graph)
             assert np.allclose(got[k][1][slots], single[k][1][slots])
 
 
+def test_encode_ahead_equals_inline_encode(hip_lib):
+    """surya_rec_encode_ahead + prefill(tiles=NULL), consumed in two pieces while decode steps run in between, gives the
+    same first tokens / scores / boxes and the same following decode steps as prefill with inline encoding; a second
+    look-ahead before the first is consumed is refused (SA_ERR_STATE)."""
+    from surya_amd._lib import SuryaAmdError
+    cfg, sd, m = build("REC-TINY", torch.float32)
+    tiles, seqs = make_prompts(cfg, GRIDS)
+    tiles = tiles.cuda()
+    slots = list(range(len(seqs)))
+    m.prefill(tiles, GRIDS, seqs, slots)
+    t0, s0, b0 = (x[0].copy() for x in m.read_outputs(1))
+    m.set_active(slots)
+    m.decode(3)
+    ref = [x.copy() for x in m.read_outputs(3)]
+
+    patches = [h * w for h, w in GRIDS]
+    cut = 4                                           # first prefill takes 4 lines, the second the remaining 2
+    m.encode_ahead(tiles, GRIDS)
+    with pytest.raises(SuryaAmdError, match="SA_ERR_STATE"):
+        m.encode_ahead(tiles, GRIDS)
+    m.prefill(None, GRIDS[:cut], seqs[:cut], slots[:cut])
+    ta, sa, ba = (x[0].copy() for x in m.read_outputs(1))
+    m.set_active(slots[:cut])
+    m.decode(3)
+    first = [x.copy() for x in m.read_outputs(3)]
+    m.prefill(None, GRIDS[cut:], seqs[cut:], slots[cut:])
+    tb, sb, bb = (x[0].copy() for x in m.read_outputs(1))
+    m.set_active(slots[cut:])
+    m.decode(3)
+    second = [x.copy() for x in m.read_outputs(3)]
+    assert sum(patches) == tiles.shape[0]
+    for part, sl, (tt, ss, bx) in ((first, slots[:cut], (ta, sa, ba)), (second, slots[cut:], (tb, sb, bb))):
+        assert np.array_equal(tt[sl], t0[sl]) and np.array_equal(bx[sl], b0[sl]) and np.allclose(ss[sl], s0[sl])
+        for k in range(3):
+            assert np.array_equal(part[0][k][sl], ref[0][k][sl])
+            assert np.array_equal(part[2][k][sl], ref[2][k][sl])
+            assert np.allclose(part[1][k][sl], ref[1][k][sl])
+    m.encode_ahead(tiles, GRIDS)                      # fully consumed: the next look-ahead is accepted
+
+
 def test_slot_reuse_and_partial_active(hip_lib):
     """Continuous batching: finish some slots, refill them with new prompts while others keep decoding; every line's
     tokens equal the oracle's regardless of admission order."""
