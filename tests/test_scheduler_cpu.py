@@ -1,0 +1,168 @@
+"""CPU: the predictor's device loop (continuous batching + pipelined decode calls + look-ahead encoding) against a fake
+model that implements the HipRecModel surface and ENFORCES the C-ABI contracts of include/surya_amd.h:
+
+  * outputs of decode_async(n, ring) are only readable through wait_outputs(n, ring), each call exactly once, and a ring
+    half is not reused before it was read;
+  * at most two calls in flight; prefill only with nothing in flight;
+  * encode_ahead refuses while earlier look-ahead images are unconsumed; prefill(tiles=None) consumes them in order;
+  * a slot that is not active is never stepped; a finished line's extra steps are legal but their outputs must be ignored.
+
+Every line has a scripted token stream (EOS at a scripted length, or endless), so the expected output is known exactly:
+the reference's stop rules (recognition/__init__.py:583-595: eos / pad, max_tokens, detect_repeat_token) applied to it.
+"""
+from collections import deque
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from surya_amd.recognition.postprocess import detect_repeat_token
+from surya_amd.settings import settings
+
+EOS, PAD, NOP = 1, 0, 3
+H = 8                      # ring half = SA_MAX_STEPS / 2
+
+
+def script(line, t):
+    """Token t (0 = the prefill token) of line `line`: distinct values, EOS at a per-line length (some lines never stop)."""
+    stop = [5, 0, 11, None, 2, 17, None, 9, 1, 30][line % 10]
+    if stop is not None and t >= stop:
+        return EOS
+    return 100 + (line * 37 + t * 11) % 9000
+
+
+class FakeModel:
+    def __init__(self, max_slots, look_ahead_capacity=10 ** 9):
+        self.max_slots = max_slots
+        self.c = SimpleNamespace(max_prefill_tokens=10 ** 6, max_slots=max_slots)
+        self.cfg = SimpleNamespace(encoder=SimpleNamespace(spatial_merge_size=2))
+        self.slot_line, self.slot_pos = {}, {}
+        self.active = []
+        self.inflight = deque()            # (n, ring, outputs)
+        self.ring_busy = [False, False]
+        self.ahead = deque()
+        self.grid_of = {}
+        self.prefill_out = None
+        self.stats = dict(decode_calls=0, steps=0, wasted_slot_steps=0, encode_ahead=0, prefills=0)
+
+    # -- look-ahead encoder
+    def encode_ahead(self, tiles, grid_hw):
+        assert not self.ahead, "SA_ERR_STATE: previous look-ahead not consumed"
+        assert tiles.shape[0] == sum(h * w for h, w in grid_hw)
+        self.ahead.extend(int(tiles[off, 0]) for off in np.cumsum([0] + [h * w for h, w in grid_hw])[:-1])
+        self.stats["encode_ahead"] += 1
+
+    def prefill(self, tiles, grid_hw, input_ids, slot_ids):
+        assert not self.inflight, "prefill while decode calls are in flight"
+        assert len(grid_hw) == len(input_ids) == len(slot_ids) > 0
+        lines = [ids[0] - 1000 for ids in input_ids]                   # the test encodes the line id in the prompt
+        if tiles is None:
+            for ln in lines:
+                assert self.ahead and self.ahead.popleft() == ln, "look-ahead images consumed out of order"
+        else:
+            assert tiles.shape[0] == sum(h * w for h, w in grid_hw)
+        tok = np.zeros((1, self.max_slots), np.int32); sc = np.zeros((1, self.max_slots), np.float32)
+        bb = np.zeros((1, self.max_slots, 6), np.int32)
+        for ln, s in zip(lines, slot_ids):
+            assert 0 <= s < self.max_slots and s not in self.active
+            self.slot_line[s], self.slot_pos[s] = ln, 1
+            tok[0, s], sc[0, s], bb[0, s] = script(ln, 0), 0.5, ln
+        self.prefill_out = (tok, sc, bb)
+        self.stats["prefills"] += 1
+
+    def read_outputs(self, n):
+        assert n == 1 and self.prefill_out is not None
+        out, self.prefill_out = self.prefill_out, None
+        return out
+
+    def set_active(self, slots):
+        assert len(set(slots)) == len(slots) and all(s in self.slot_line for s in slots)
+        self.active = list(slots)
+
+    def decode_async(self, n, ring):
+        assert 1 <= n <= H and ring in (0, 1) and not self.ring_busy[ring], "ring half reused before it was read"
+        assert len(self.inflight) < 2 and self.active
+        tok = np.full((n, self.max_slots), -7, np.int32); sc = np.zeros((n, self.max_slots), np.float32)
+        bb = np.zeros((n, self.max_slots, 6), np.int32)
+        for k in range(n):
+            for s in self.active:
+                ln = self.slot_line[s]
+                tok[k, s], sc[k, s], bb[k, s] = script(ln, self.slot_pos[s]), 0.25, ln
+                self.slot_pos[s] += 1
+        self.ring_busy[ring] = True
+        self.inflight.append((n, ring, (tok, sc, bb)))
+        self.stats["decode_calls"] += 1
+        self.stats["steps"] += n
+
+    def wait_outputs(self, n, ring):
+        assert self.inflight and self.inflight[0][:2] == (n, ring), "outputs read out of order"
+        _, _, out = self.inflight.popleft()
+        self.ring_busy[ring] = False
+        return out
+
+
+def expected(line, max_tokens):
+    toks = [script(line, 0)]
+    if toks[0] in (EOS, NOP):
+        return toks
+    t = 1
+    while True:
+        toks.append(script(line, t)); t += 1
+        if toks[-1] in (EOS, PAD) or len(toks) >= max_tokens or detect_repeat_token(toks):
+            return toks
+
+
+def make(n_lines, max_tokens, slots):
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionPrompt
+    pred = object.__new__(RecognitionPredictor)
+    pred.prompt_queue, pred.batch_prompt_mapping = deque(), None
+    pred.model = FakeModel(slots)
+    pred.processor = SimpleNamespace(eos_token_id=EOS, pad_token_id=PAD, no_output_token=NOP)
+    grids = [(2, 2 + 2 * (i % 3)) for i in range(n_lines)]
+    offs = np.cumsum([0] + [h * w for h, w in grids])
+    tiles = np.zeros((offs[-1], 3), np.float32)
+    for i in range(n_lines):
+        tiles[offs[i]:offs[i + 1], 0] = i                               # the fake reads the line id back from the tiles
+    prep = {"prompts": [RecognitionPrompt(i, "ocr_with_boxes", None, None, True) for i in range(n_lines)],
+            "max_tokens": {i: (max_tokens if i % 7 else max(1, max_tokens // 2)) for i in range(n_lines)},
+            "tiles": tiles, "tile_offs": offs, "grids": grids, "prompt_ids": [[1000 + i, 5, 6] for i in range(n_lines)]}
+    return pred, prep
+
+
+@pytest.mark.parametrize("n_lines,max_tokens,slots,sps,ahead", [(23, 12, 4, 4, True), (23, 12, 4, 3, False), (9, 40, 16, 8, True),
+                                                                 (40, 6, 7, 1, True), (5, 1, 2, 4, True), (64, 20, 8, 4, True)])
+def test_device_loop_matches_scripted_streams(n_lines, max_tokens, slots, sps, ahead):
+    old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD)
+    settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = sps, ahead
+    try:
+        pred, prep = make(n_lines, max_tokens, slots)
+        toks, boxes, scores = pred.generate(prep, slots)
+    finally:
+        settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
+    m = pred.model
+    assert not m.inflight and not m.ahead and m.prefill_out is None
+    for i in range(n_lines):
+        exp = expected(i, prep["max_tokens"][i])
+        assert toks[i] == exp, (i, toks[i], exp)
+        assert len(scores[i]) == len(exp)
+        assert (boxes[i, :len(exp), 0].numpy() == i).all()             # every recorded box came from this line's slot
+    assert (m.stats["encode_ahead"] > 0) == ahead
+
+
+def test_no_speculative_call_when_budgets_are_known():
+    """All lines run to max_tokens (no EOS): the loop issues exactly ceil((max_tokens - 1) / steps) calls per batch, the
+    last one trimmed to the remaining budget -- no step beyond what some line needs."""
+    old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD)
+    settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = 4, True
+    try:
+        pred, prep = make(8, 11, 8)
+        prep["prompt_ids"] = [[1000 + 3 + 10 * i, 5] for i in range(8)]      # lines 3, 13, 23, ...: scripted never to stop
+        prep["max_tokens"] = {i: 11 for i in range(8)}
+        offs = prep["tile_offs"]
+        for i in range(8):
+            prep["tiles"][offs[i]:offs[i + 1], 0] = 3 + 10 * i
+        toks, _, _ = pred.generate(prep, 8)
+    finally:
+        settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
+    assert all(len(t) == 11 for t in toks)
+    assert pred.model.stats["steps"] == 10 and pred.model.stats["decode_calls"] == 3      # 4 + 4 + 2
