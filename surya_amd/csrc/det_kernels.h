@@ -32,7 +32,9 @@ struct ConvArgs {
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, act;
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+// CIN64: Cin is a multiple of the K-tile (64 bf16 / 32 fp32 elements), so a K-tile never straddles two filter taps: the
+// tap and its (ky, kx) are scalars computed once per K-tile instead of two integer divisions per staged chunk.
+template <typename T, int BM, int BN, int WM, int WN, bool CIN64 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<T>::KE, V = Ty<T>::V16;
@@ -80,10 +82,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
 #define SA_CFETCH(XR, WR, KT)                                                                                   \
     {                                                                                                           \
         const int kbase_ = (KT) * KE;                                                                           \
+        int tap_u = 0, ci_u = 0, ky_u = 0, kx_u = 0;                                                            \
+        if constexpr (CIN64) {                                                                                  \
+            tap_u = kbase_ / p.Cin; ci_u = kbase_ - tap_u * p.Cin;                                              \
+            ky_u = tap_u / p.KW; kx_u = tap_u - ky_u * p.KW;                                                    \
+        }                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                       \
-            const int k0 = kbase_ + xc[i];                                                                      \
-            const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;                                                  \
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;                                                    \
+            int tap, ci, ky, kx;                                                                                \
+            if constexpr (CIN64) {                                                                              \
+                tap = tap_u; ci = ci_u + xc[i]; ky = ky_u; kx = kx_u;                                           \
+            } else {                                                                                            \
+                const int k0 = kbase_ + xc[i];                                                                  \
+                tap = k0 / p.Cin; ci = k0 - tap * p.Cin;                                                        \
+                ky = tap / p.KW; kx = tap - ky * p.KW;                                                          \
+            }                                                                                                   \
             const int iy = xiy[i] + ky, ix = xix[i] + kx;                                                       \
             const bool ok = (tap < ntaps) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);                    \
             const long off = ok ? ((((long)xb[i] * p.H + iy) * p.W + ix) * p.Cin + ci) : 0;                     \
@@ -102,22 +114,48 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
         _Pragma("unroll") for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(b_ + wdst[i]) = WR[i];   \
     }
     const int frow = lane & 31, fch = lane >> 5;
-#define SA_CCOMPUTE(CURP)                                                                                      \
+#define SA_CFRAGS(XF, WF, KK)                                                                                  \
     {                                                                                                          \
-        const unsigned char* cur_ = (CURP);                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                     \
-            u32x4 xf[FM], wf[FN];                                                                              \
-            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                   \
-                const int row = wm * WTM + i * 32 + frow;                                                      \
-                xf[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                   \
-                const int row = wn * WTN + j * 32 + frow;                                                      \
-                wf[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + (((kk * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                     \
-                _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<T>::run(acc[j][i], wf[j], xf[i]);          \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                       \
+            const int row = wm * WTM + i * 32 + frow;                                                          \
+            XF[i] = *reinterpret_cast<const u32x4*>(cur_ + row * 128 + ((((KK) * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
         }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                       \
+            const int row = wn * WTN + j * 32 + frow;                                                          \
+            WF[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + ((((KK) * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
+        }                                                                                                      \
+    }
+#define SA_CMFMAS(XF, WF)                                  \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j)         \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<T>::run(acc[j][i], WF[j], XF[i]);
+#define SA_CSGB_PAIRS()                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < (FM + FN < FM * FN ? FM + FN : FM * FN); ++i_) {            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+    }                                                                                                   \
+    if constexpr (FM * FN > FM + FN) __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - FM - FN, 0); \
+    if constexpr (FM + FN > FM * FN) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN - FM * FN, 0);
+    // fragment reads of K-step kk+1 interleaved with the MFMAs of step kk, as in gemm.h (bf16; the fp32 Mfma is 4 instructions
+    // per tile, so there the pattern only fixes the order of the first of each four)
+#define SA_CCOMPUTE(CURP)                                  \
+    {                                                      \
+        const unsigned char* cur_ = (CURP);                \
+        u32x4 xfa[FM], wfa[FN], xfb[FM], wfb[FN];          \
+        SA_CFRAGS(xfa, wfa, 0);                            \
+        SA_CFRAGS(xfb, wfb, 1);                            \
+        SA_CMFMAS(xfa, wfa);                               \
+        SA_CFRAGS(xfa, wfa, 2);                            \
+        SA_CMFMAS(xfb, wfb);                               \
+        SA_CFRAGS(xfb, wfb, 3);                            \
+        SA_CMFMAS(xfa, wfa);                               \
+        SA_CMFMAS(xfb, wfb);                               \
+        if constexpr (sizeof(T) == 2) {                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0); \
+            SA_CSGB_PAIRS();                               \
+            SA_CSGB_PAIRS();                               \
+            SA_CSGB_PAIRS();                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0); \
+        }                                                  \
     }
     const int last = nk - 1;
     SA_CFETCH(xr0, wr0, 0);
@@ -144,6 +182,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
 #undef SA_CFETCH
 #undef SA_CSTASH
 #undef SA_CCOMPUTE
+#undef SA_CFRAGS
+#undef SA_CMFMAS
+#undef SA_CSGB_PAIRS
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WTM + i * 32 + (lane & 31);
@@ -180,12 +221,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool CIN64 = false>
 static inline int launch_conv_cfg(const ConvArgs<T>& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
     constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
-    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
+    auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, CIN64>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -209,9 +250,12 @@ template <typename T>
 static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
     if (a.Cin % Ty<T>::V16 != 0 || a.Kpad % Ty<T>::KE != 0 || a.Cout % 4 != 0) return SA_ERR_SHAPE;
     const long M = (long)a.B * a.Ho * a.Wo;
-    if (a.Cout >= 128 && cdivl(M, 128) * cdiv(a.Cout, 128) >= 256) return launch_conv_cfg<T, 128, 128, 2, 2>(a, s);
-    if (a.Cout >= 64 && cdivl(M, 128) * cdiv(a.Cout, 64) >= 128) return launch_conv_cfg<T, 128, 64, 4, 1>(a, s);
-    if (a.Cout >= 64) return launch_conv_cfg<T, 64, 64, 2, 2>(a, s);
+    const bool cin64 = a.Cin % Ty<T>::KE == 0;       // K-tiles aligned with filter taps: scalar tap arithmetic
+    if (a.Cout >= 128 && cdivl(M, 128) * cdiv(a.Cout, 128) >= 256)
+        return cin64 ? launch_conv_cfg<T, 128, 128, 2, 2, true>(a, s) : launch_conv_cfg<T, 128, 128, 2, 2>(a, s);
+    if (a.Cout >= 64 && cdivl(M, 128) * cdiv(a.Cout, 64) >= 128)
+        return cin64 ? launch_conv_cfg<T, 128, 64, 4, 1, true>(a, s) : launch_conv_cfg<T, 128, 64, 4, 1>(a, s);
+    if (a.Cout >= 64) return cin64 ? launch_conv_cfg<T, 64, 64, 2, 2, true>(a, s) : launch_conv_cfg<T, 64, 64, 2, 2>(a, s);
     return launch_conv_cfg<T, 128, 32, 4, 1>(a, s);
 }
 
