@@ -26,7 +26,7 @@
 
 namespace sa {
 
-enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6 };
+enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6, EPI_ROPE = 7 };
 
 template <typename TI, typename TO>
 struct GemmArgs {
@@ -43,6 +43,11 @@ struct GemmArgs {
     // per (row, tile column) goes to amax[m * cdiv(N, bn_used) + tile_n]; the launcher reports the tile width it chose.
     float4* amax = nullptr;
     mutable int bn_used = 0;
+    // EPI_ROPE (vision qkv projection): rotary embedding of the q and k columns (n < rope_cols) in the epilogue. The weight
+    // rows of every head are stored PAIR-INTERLEAVED (new column 2j = old j, 2j + 1 = old j + D/2), so the lane that owns
+    // four consecutive columns holds two complete rotate_half pairs; rope[m * (D/2) + j] = (cos, sin) of token m, pair j.
+    const float2* rope = nullptr;
+    int rope_cols = 0, rope_D = 0;
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -408,6 +413,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                     } else if constexpr (EPI == EPI_RELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                }
+                if constexpr (EPI == EPI_ROPE && !SPLIT) {
+                    const int n = min(n0 + ncol, p.N - 4);
+                    if (n < p.rope_cols) {
+                        // reference order (encoder/__init__.py:188-199): the projection output is rounded to the storage
+                        // dtype, rotated in fp32, rounded once more (the store below)
+                        const int m = min(m0 + row, p.M - 1), j = (n % p.rope_D) >> 1, half = p.rope_D >> 1;
+                        const float4 cs = *reinterpret_cast<const float4*>(p.rope + (long)m * half + j);   // (cos j, sin j, cos j+1, sin j+1)
+                        const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
+                        v[0] = x0 * cs.x - x1 * cs.y; v[1] = x1 * cs.x + x0 * cs.y;
+                        v[2] = x2 * cs.z - x3 * cs.w; v[3] = x3 * cs.z + x2 * cs.w;
                     }
                 }
                 if constexpr (EPI == EPI_SWIGLU && !SPLIT) {

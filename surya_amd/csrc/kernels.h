@@ -61,31 +61,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, l
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Vision 2-D RoPE in place on the q and k parts of qkv [P, 3*H] (apply_rotary_pos_emb_vision,
-// encoder/__init__.py:188-199). Per patch the angle vector (length D/2) is [pos_h*f | pos_w*f], f = inv_freq[D/4],
-// duplicated to D (:633); rotate_half pairs element i with i + D/2. fp32 math.
-template <typename T>
-__global__ void rope_vision_kernel(T* __restrict__ qkv, const int* __restrict__ pos_hw, const float* __restrict__ inv_freq,
-                                   int P, int H, int heads, int D) {
-    const int p = blockIdx.x;
+// Vision 2-D RoPE of the q and k parts of qkv [P, 3*H] (apply_rotary_pos_emb_vision, encoder/__init__.py:188-199). Per patch
+// the angle vector (length D/2) is [pos_h*f | pos_w*f], f = inv_freq[D/4], duplicated to D (:633); rotate_half pairs element
+// i with i + D/2; fp32 math. The rotation itself happens in the qkv GEMM's epilogue (EPI_ROPE, gemm.h); this kernel builds its
+// (cos, sin) table tab[p * D/2 + i] once per encoder pass (the first version ran a separate in-place kernel per layer:
+// 8 x 165 us per recognition step).
+__global__ void rope_vision_table_kernel(const int* __restrict__ pos_hw, const float* __restrict__ inv_freq, float2* __restrict__ tab,
+                                         int P, int D) {
     const int half = D / 2, quarter = D / 4;
-    const float ph = (float)pos_hw[2 * p], pw = (float)pos_hw[2 * p + 1];
-    T* base = qkv + (long)p * 3 * H;
-    __shared__ float cs_t[128], sn_t[128];
-    for (int i = threadIdx.x; i < half; i += blockDim.x) {
-        const float ang = (i < quarter) ? ph * inv_freq[i] : pw * inv_freq[i - quarter];
-        sincosf(ang, &sn_t[i], &cs_t[i]);
-    }
-    __syncthreads();
-    // items: (q|k, head, i < half)
-    for (int it = threadIdx.x; it < 2 * heads * half; it += blockDim.x) {
-        const int i = it % half, hh = (it / half) % heads, which = it / (half * heads);
-        const float sn = sn_t[i], cs = cs_t[i];
-        T* v = base + (long)which * H + hh * D;
-        const float x1 = Ty<T>::ld(v + i), x2 = Ty<T>::ld(v + i + half);
-        Ty<T>::st(v + i, x1 * cs - x2 * sn);
-        Ty<T>::st(v + i + half, x2 * cs + x1 * sn);
-    }
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)P * half) return;
+    const int p = (int)(idx / half), i = (int)(idx % half);
+    const float ang = (i < quarter) ? (float)pos_hw[2 * p] * inv_freq[i] : (float)pos_hw[2 * p + 1] * inv_freq[i - quarter];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    tab[idx] = make_float2(cs, sn);
 }
 
 // ---------------------------------------------------------------------------------------------------

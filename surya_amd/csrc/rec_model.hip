@@ -174,6 +174,7 @@ struct RecModel : RecBase {
     // decoder workspaces
     T *dx, *dh, *dqkv, *dattn, *dmlp, *dlast;
     float* logits;
+    float2* erope;           // [max_patches][enc head_dim / 2] (cos, sin) of the vision rotary embedding
     float4* amax;            // greedy-head partials of the lm_head GEMM: [slot row][column tile]
     float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
     float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
@@ -209,6 +210,7 @@ struct RecModel : RecBase {
         size_t o_eqkv = take(Pm * 3 * c.enc_hidden * sizeof(T));
         size_t o_emlp = take(Pm * c.enc_inter_pad * sizeof(T));
         size_t o_emh = take(Pm * c.enc_hidden * sizeof(T));                 // [P/unit, unit*He]
+        size_t o_erope = take(Pm * (size_t)(c.enc_hidden / c.enc_heads / 2) * sizeof(float2));
         size_t o_emerged = take(Pm / unit * c.enc_out_hidden * sizeof(T));
         size_t o_dx = take(Tm * c.dec_hidden * sizeof(T));
         size_t o_dh = take(Tm * c.dec_hidden * sizeof(T));
@@ -232,7 +234,7 @@ struct RecModel : RecBase {
         if (m) {
             char* b = m->arena;
             m->tiles_t = (T*)(b + o_tiles); m->ex = (T*)(b + o_ex); m->eh = (T*)(b + o_eh); m->eqkv = (T*)(b + o_eqkv);
-            m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged);
+            m->emlp = (T*)(b + o_emlp); m->emh = (T*)(b + o_emh); m->emerged = (T*)(b + o_emerged); m->erope = (float2*)(b + o_erope);
             m->dx = (T*)(b + o_dx); m->dh = (T*)(b + o_dh); m->dqkv = (T*)(b + o_dqkv); m->dattn = (T*)(b + o_dattn);
             m->dmlp = (T*)(b + o_dmlp); m->dlast = (T*)(b + o_dlast); m->emb_ahead = (T*)(b + o_ahead); m->logits = (float*)(b + o_logits); m->amax = (float4*)(b + o_amax);
             m->part = (float*)(b + o_part); m->rope_cs = (float2*)(b + o_rope);
@@ -409,12 +411,15 @@ struct RecModel : RecBase {
             if ((rc = gemm<EPI_BIAS>(tiles_t, c.patch_dim_pad, W(SA_RW_PATCH), c.patch_dim_pad, ex, He, nullptr, nullptr, 0, Pi,
                                      He, c.patch_dim_pad, s))) return rc;
             const float scale = 1.0f / sqrtf((float)D);
+            hipLaunchKernelGGL(rope_vision_table_kernel, dim3((unsigned)cdivl((long)Pi * (D / 2), 256)), dim3(256), 0, s, d_pos,
+                               reinterpret_cast<const float*>(w[SA_RW_ENC_INVFREQ]), erope, Pi, D);
             for (int l = 0; l < c.enc_depth; ++l) {
                 if ((rc = rmsnorm(ex, He, WE(l, SA_RE_NORM1), eh, He, nullptr, Pi, He, c.enc_eps, s))) return rc;
-                if ((rc = gemm<EPI_BIAS>(eh, He, WE(l, SA_RE_QKV_W), He, eqkv, 3 * He, WE(l, SA_RE_QKV_B), nullptr, 0, Pi,
-                                         3 * He, He, s))) return rc;
-                hipLaunchKernelGGL(rope_vision_kernel<T>, dim3(Pi), dim3(256), 0, s, eqkv, d_pos,
-                                   reinterpret_cast<const float*>(w[SA_RW_ENC_INVFREQ]), Pi, He, c.enc_heads, D);
+                {   // qkv projection with the 2-D rotary embedding of q and k in its epilogue (pair-interleaved weight rows)
+                    GemmArgs<T, T> a{eh, He, WE(l, SA_RE_QKV_W), He, eqkv, 3 * He, WE(l, SA_RE_QKV_B), nullptr, 0, Pi, 3 * He, He};
+                    a.rope = erope; a.rope_cols = 2 * He; a.rope_D = D;
+                    if ((rc = launch_gemm<T, T, EPI_ROPE>(a, s))) return rc;
+                }
                 const bool fullatt = (c.fullatt_mask >> l) & 1u;
                 const AttnSegs& sg = fullatt ? d_full : d_win;
                 const int nt = (int)(fullatt ? full.tile_seg.size() : win.tile_seg.size());

@@ -41,6 +41,18 @@ def _interleave(g: torch.Tensor, u: torch.Tensor, rows_pad: int) -> torch.Tensor
     return out
 
 
+def _pair_interleave_qk(t: torch.Tensor, heads: int, d: int) -> torch.Tensor:
+    """Vision qkv projection rows [q | k | v], each [heads, d]: inside every q and k head move the rotate_half partners
+    (j, j + d/2) next to each other (new row 2j = old j, 2j + 1 = old j + d/2) so the GEMM's EPI_ROPE epilogue finds a
+    complete pair inside one lane's four consecutive output columns. q.k dot products are invariant to this common
+    permutation of the head dim; v rows stay as they are."""
+    hd = heads * d
+    perm = torch.stack([torch.arange(d // 2), torch.arange(d // 2) + d // 2], 1).reshape(-1)        # [0, d/2, 1, d/2+1, ...]
+    idx = torch.arange(3 * hd).reshape(3, heads, d)
+    idx[:2] = idx[:2][..., perm]
+    return t[idx.reshape(-1)]
+
+
 def repack_rec_weights(cfg: RecConfig, sd: Dict[str, torch.Tensor], dtype: torch.dtype, device) -> List[torch.Tensor]:
     e, d = cfg.encoder, cfg.decoder
     He = e.hidden_size
@@ -76,8 +88,8 @@ def repack_rec_weights(cfg: RecConfig, sd: Dict[str, torch.Tensor], dtype: torch
         p = f"vision_encoder.blocks.{l}."
         b = L.RW_GLOBALS + l * L.RE_COUNT
         put(b + L.RE_NORM1, f(p + "norm1.weight"))
-        put(b + L.RE_QKV_W, f(p + "attn.qkv.weight"))
-        put(b + L.RE_QKV_B, f(p + "attn.qkv.bias"))
+        put(b + L.RE_QKV_W, _pair_interleave_qk(f(p + "attn.qkv.weight"), e.num_heads, e.head_dim))
+        put(b + L.RE_QKV_B, _pair_interleave_qk(f(p + "attn.qkv.bias"), e.num_heads, e.head_dim))
         put(b + L.RE_PROJ_W, f(p + "attn.proj.weight"))
         put(b + L.RE_PROJ_B, f(p + "attn.proj.bias"))
         put(b + L.RE_NORM2, f(p + "norm2.weight"))
