@@ -122,7 +122,7 @@ struct DetModel : DetBase {
                 }
                 case SA_DET_CLASSIFY: {
                     const long HWl = (long)op.hin * op.win, P = (long)B * HWl;
-                    hipLaunchKernelGGL(classify_sigmoid_kernel<T>, dim3((unsigned)cdivl(P, 128)), dim3(128), 0, s, bufs[op.in0],
+                    hipLaunchKernelGGL(classify_sigmoid_kernel<T>, dim3((unsigned)cdivl(P, 16)), dim3(256), 0, s, bufs[op.in0],
                                        WT(op.w_idx), WT(op.b_idx), planes, P, HWl, op.cin, op.cout);
                     if (lowres)
                         SA_HIP(hipMemcpyAsync(lowres, planes, (size_t)P * op.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
