@@ -97,7 +97,7 @@ struct DetModel : DetBase {
                 }
                 case SA_DET_GROUPED1X1: {
                     const long P = (long)B * op.hin * op.win;
-                    hipLaunchKernelGGL(grouped1x1_kernel<T>, dim3((unsigned)cdivl(P, 8), op.cin / op.p0), dim3(256), 0, s, bufs[op.in0],
+                    hipLaunchKernelGGL(grouped1x1_kernel<T>, dim3((unsigned)cdivl(P, 64), op.cin / op.p0), dim3(256), 0, s, bufs[op.in0],
                                        WT(op.w_idx), bufs[op.out], P, op.cin, op.p0);
                     break;
                 }
