@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--steps-per-sync", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-det", action="store_true", help="skip the detection leg (pages/s)")
+    ap.add_argument("--det-only", action="store_true", help="profiling aid: run only the detection leg and print its object")
     ap.add_argument("--det-config", default="DET-DEFAULT")
     ap.add_argument("--det-pages", type=int, default=16)
     ap.add_argument("--det-size", type=int, default=1024)
@@ -177,6 +178,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+    if args.det_only:
+        print(json.dumps(bench_det(args, local_rank, world, rank, lambda: None)), flush=True)
+        return
     os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
     if args.steps_per_sync:
         os.environ["RECOGNITION_STEPS_PER_SYNC"] = str(args.steps_per_sync)

@@ -407,26 +407,38 @@ __global__ __launch_bounds__(256) void grouped1x1_kernel(const T* __restrict__ i
 //   kv = relu(K)^T [V | 1]  (dim x dim+1),  out = relu(Q) kv,  out[:, :dim] / (out[:, dim] + eps)
 // One workgroup per (image, head). Heads [0, heads_a) read q|k|v from `qa` (the qkv conv), the rest from `qb` (the
 // multi-scale aggregation) -- the reference's channel concat (:349) is never materialised. dim <= 32.
+// Two launches so the work spreads over the chip (one workgroup per (image, head) walking all H*W pixels alone took 183 us
+// on 256 workgroups): litemla_kv_kernel reduces 256-pixel chunks to partial kv matrices, litemla_out_kernel sums a head's
+// partials in chunk order (deterministic) and writes 256 pixels per workgroup.
+constexpr int LITEMLA_CHUNK = 256;
+constexpr int LITEMLA_KV = 32 * 33;                          // floats per (image, head, chunk) partial
+
 template <typename T, int DIM>
-__global__ __launch_bounds__(256) void litemla_kernel(const T* __restrict__ qa, const T* __restrict__ qb, T* __restrict__ out,
-                                                      int HW, int heads_a, int heads, float eps) {
+__global__ __launch_bounds__(256) void litemla_kv_kernel(const T* __restrict__ qa, const T* __restrict__ qb, float* __restrict__ kvp,
+                                                         int HW, int heads_a, int heads) {
     constexpr int dim = DIM;
     __shared__ float ks[64 * 32];
     __shared__ float vs[64 * 33];
-    __shared__ float kv[32 * 33];
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, h = blockIdx.y, ch = blockIdx.z, nch = gridDim.z, tid = threadIdx.x;
     const int Ca = heads_a * 3 * dim, Cb = (heads - heads_a) * 3 * dim;
     const T* src = h < heads_a ? qa + (long)b * HW * Ca + h * 3 * dim : qb + (long)b * HW * Cb + (h - heads_a) * 3 * dim;
     const int C = h < heads_a ? Ca : Cb;
     const int d1 = dim + 1, npair = dim * d1;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};        // pairs tid, tid+256, ... (dim 32: 1056 pairs -> <= 5 per thread)
-    for (int n0 = 0; n0 < HW; n0 += 64) {
-        const int nn = min(64, HW - n0);
-        for (int i = tid; i < nn * dim; i += 256) {
-            const int n = i / dim, c = i % dim;
+    const int n_end = min(HW, (ch + 1) * LITEMLA_CHUNK);
+    for (int n0 = ch * LITEMLA_CHUNK; n0 < n_end; n0 += 64) {
+        const int nn = min(64, n_end - n0);
+        // 16-byte loads: the q|k|v tensor is 200 MB per call at 1024^2 x 16 pages, so this kernel is HBM-bound once the
+        // staging stops issuing 2-byte loads (first version: 1.3 TB/s)
+        constexpr int V = Ty<T>::V16, CPP = dim / V;            // 16-byte chunks of k (and of v) per pixel
+        for (int i = tid; i < nn * CPP; i += 256) {
+            const int n = i / CPP, c = (i % CPP) * V;
             const T* row = src + (long)(n0 + n) * C;
-            ks[n * 32 + c] = fmaxf(Ty<T>::ld(row + dim + c), 0.f);
-            vs[n * 33 + c] = Ty<T>::ld(row + 2 * dim + c);
+            float kx[V], vx[V];
+            unpack16(*reinterpret_cast<const uint4*>(row + dim + c), kx, (T*)nullptr);
+            unpack16(*reinterpret_cast<const uint4*>(row + 2 * dim + c), vx, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { ks[n * 32 + c + e] = fmaxf(kx[e], 0.f); vs[n * 33 + c + e] = vx[e]; }
             if (c == 0) vs[n * 33 + dim] = 1.f;
         }
         __syncthreads();
@@ -442,18 +454,45 @@ __global__ __launch_bounds__(256) void litemla_kernel(const T* __restrict__ qa, 
         }
         __syncthreads();
     }
+    float* dst = kvp + (((long)b * heads + h) * nch + ch) * LITEMLA_KV;
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
         const int pr = tid + r * 256;
-        if (pr < npair) kv[(pr / d1) * 33 + (pr % d1)] = acc[r];
+        if (pr < npair) dst[(pr / d1) * 33 + (pr % d1)] = acc[r];
+    }
+}
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void litemla_out_kernel(const T* __restrict__ qa, const T* __restrict__ qb, const float* __restrict__ kvp,
+                                                          T* __restrict__ out, int HW, int heads_a, int heads, float eps) {
+    constexpr int dim = DIM;
+    __shared__ float kv[32 * 33];
+    const int b = blockIdx.x, h = blockIdx.y, ch = blockIdx.z, nch = gridDim.z, tid = threadIdx.x;
+    const int Ca = heads_a * 3 * dim, Cb = (heads - heads_a) * 3 * dim;
+    const T* src = h < heads_a ? qa + (long)b * HW * Ca + h * 3 * dim : qb + (long)b * HW * Cb + (h - heads_a) * 3 * dim;
+    const int C = h < heads_a ? Ca : Cb;
+    const int d1 = dim + 1, npair = dim * d1;
+    const float* part = kvp + ((long)b * heads + h) * nch * LITEMLA_KV;
+    for (int pr = tid; pr < npair; pr += 256) {
+        const int e = (pr / d1) * 33 + (pr % d1);
+        float a = 0.f;
+        for (int c = 0; c < nch; ++c) a += part[(long)c * LITEMLA_KV + e];
+        kv[e] = a;
     }
     __syncthreads();
     const int Cout = heads * dim;
-    for (int n = tid; n < HW; n += 256) {
+    const int n = ch * LITEMLA_CHUNK + tid;
+    if (n < HW) {
         const T* row = src + (long)n * C;
         float q[DIM];
+        constexpr int V = Ty<T>::V16;
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) q[i] = fmaxf(Ty<T>::ld(row + i), 0.f);
+        for (int i = 0; i < DIM; i += V) {
+            float t[V];
+            unpack16(*reinterpret_cast<const uint4*>(row + i), t, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) q[i + e] = fmaxf(t[e], 0.f);
+        }
         float den = 0.f;                       // the appended ones-column of v: sum_i q_i * sum_n k_ni
 #pragma unroll
         for (int i = 0; i < DIM; ++i) den += q[i] * kv[i * 33 + DIM];

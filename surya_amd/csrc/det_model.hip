@@ -24,6 +24,7 @@ struct DetModel : DetBase {
     std::vector<size_t> buf_elems;       // per image
     std::vector<T*> bufs;
     float* planes = nullptr;             // [max_batch, labels, H/4, W/4] fp32
+    float* kvp = nullptr;                // LiteMLA partial kv matrices [max_batch, heads, chunks, 32*33] fp32
     char* arena = nullptr;
     int max_batch = 0, H = 0, W = 0, labels = 0, in_cp = 8;
 
@@ -38,10 +39,17 @@ struct DetModel : DetBase {
         for (int i = 0; i < n_bufs; ++i) { offs[i] = total; total += ((buf_elems[i] * max_batch * sizeof(T)) + 255) & ~(size_t)255; }
         const size_t planes_off = total;
         total += (size_t)max_batch * labels * (H / 4) * (W / 4) * sizeof(float) + 256;
+        const size_t kvp_off = total;
+        size_t kv_floats = 0;
+        for (const surya_det_op& op : ops)
+            if (op.type == SA_DET_LITEMLA)
+                kv_floats = std::max(kv_floats, (size_t)max_batch * (op.cout / op.p0) * cdiv(op.hin * op.win, LITEMLA_CHUNK) * LITEMLA_KV);
+        total += kv_floats * sizeof(float) + 256;
         SA_HIP(hipMalloc((void**)&arena, total));
         bufs.resize(n_bufs);
         for (int i = 0; i < n_bufs; ++i) bufs[i] = reinterpret_cast<T*>(arena + offs[i]);
         planes = reinterpret_cast<float*>(arena + planes_off);
+        kvp = reinterpret_cast<float*>(arena + kvp_off);
         return SA_OK;
     }
     ~DetModel() override { if (arena) (void)hipFree(arena); }
@@ -103,15 +111,18 @@ struct DetModel : DetBase {
                 }
                 case SA_DET_LITEMLA: {
                     const int HW = op.hin * op.win, heads = op.cout / op.p0, heads_a = heads / 2;
-                    dim3 grid(B, heads);
-                    if (op.p0 == 32)
-                        hipLaunchKernelGGL((litemla_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], bufs[op.out], HW,
-                                           heads_a, heads, 1e-5f);
-                    else if (op.p0 == 16)
-                        hipLaunchKernelGGL((litemla_kernel<T, 16>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], bufs[op.out], HW,
-                                           heads_a, heads, 1e-5f);
-                    else
+                    dim3 grid(B, heads, cdiv(HW, LITEMLA_CHUNK));
+                    if (op.p0 == 32) {
+                        hipLaunchKernelGGL((litemla_kv_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, HW, heads_a, heads);
+                        hipLaunchKernelGGL((litemla_out_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, bufs[op.out],
+                                           HW, heads_a, heads, 1e-5f);
+                    } else if (op.p0 == 16) {
+                        hipLaunchKernelGGL((litemla_kv_kernel<T, 16>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, HW, heads_a, heads);
+                        hipLaunchKernelGGL((litemla_out_kernel<T, 16>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, bufs[op.out],
+                                           HW, heads_a, heads, 1e-5f);
+                    } else {
                         return SA_ERR_UNSUPPORTED;
+                    }
                     break;
                 }
                 case SA_DET_UPCAT: {

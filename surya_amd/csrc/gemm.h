@@ -591,6 +591,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if (!force_bn) {
                 // measured at M = 256 (tools/microbench/gemm_shapes.py): lm_head-sized N -> 128x64 tiles; everything else -> 64x64
                 // direct-to-LDS variants: gate|up 15.5 us vs 18.4 with register staging, lm_head 82.6 us vs 88.3
+                // (a 256x128 tile for lm_head -- every weight byte streamed once instead of twice -- was measured: 95.6 vs 93.4 ms
+                // per recognition step, one workgroup per CU hides less latency than two 128x128 ones)
                 if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
                 return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
             }
