@@ -516,7 +516,9 @@ struct RecModel : RecBase {
         return rc;
     }
     int reduce_residual_norm(int S, int M, const T* wnorm, T* y, hipStream_t s) {
-        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(256), 0, s, part, S, M, dx, (const T*)nullptr,
+        const int threads = cdiv(c.dec_hidden / 4, 64) * 64;         // one 4-element chunk per thread
+        if (threads > 1024 || c.dec_hidden % 4) return SA_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(threads), 0, s, part, S, M, dx, (const T*)nullptr,
                            wnorm, y, c.dec_hidden, c.dec_eps);
         return (int)hipGetLastError();
     }
