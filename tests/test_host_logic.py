@@ -171,3 +171,54 @@ def test_split_image_and_packing():
     parts, heights = split_image(img, 1024)
     assert [p.size for p in parts] == [(300, 1024)] * 3 and heights == [1024, 1024, 452]
     assert get_total_splits((300, 2500), 1024) == 3 and get_total_splits((300, 1400), 1024) == 1
+
+
+def test_pair_interleave_keeps_qk_dot_products():
+    """Vision qkv rows are stored with every q / k head pair-interleaved for the GEMM's RoPE epilogue; rotate_half on the
+    original layout and the adjacent-pair rotation on the permuted layout give the same q.k scores, v is untouched."""
+    import torch
+    from surya_amd.recognition.weights import _pair_interleave_qk
+    heads, d, n = 3, 16, 5
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(n, 3 * heads * d, generator=g, dtype=torch.float64)
+    ang = torch.randn(n, d // 2, generator=g, dtype=torch.float64)
+    cos, sin = ang.cos(), ang.sin()
+
+    def rot_ref(x):                                   # rotate_half pairs element i with i + d/2
+        x = x.reshape(n, heads, d)
+        x1, x2 = x[..., : d // 2], x[..., d // 2:]
+        return torch.cat([x1 * cos[:, None] - x2 * sin[:, None], x2 * cos[:, None] + x1 * sin[:, None]], -1)
+
+    def rot_pairs(x):                                 # permuted layout: (2j, 2j + 1) = old (j, j + d/2)
+        x = x.reshape(n, heads, d // 2, 2)
+        a, b = x[..., 0], x[..., 1]
+        return torch.stack([a * cos[:, None] - b * sin[:, None], b * cos[:, None] + a * sin[:, None]], -1).reshape(n, heads, d)
+
+    hd = heads * d
+    perm_cols = _pair_interleave_qk(torch.arange(3 * hd), heads, d)
+    p = qkv[:, perm_cols]                             # what the GEMM with permuted weight rows produces
+    assert torch.equal(p[:, 2 * hd:], qkv[:, 2 * hd:])
+    q_ref, k_ref = rot_ref(qkv[:, :hd]), rot_ref(qkv[:, hd:2 * hd])
+    q_new, k_new = rot_pairs(p[:, :hd]), rot_pairs(p[:, hd:2 * hd])
+    s_ref = torch.einsum("ihd,jhd->hij", q_ref, k_ref)
+    s_new = torch.einsum("ihd,jhd->hij", q_new, k_new)
+    assert torch.allclose(s_ref, s_new, atol=1e-12)
+
+
+def test_pmc_bucket_names_match_bench():
+    """tools/rocpd_pmc.py maps mangled kernel names to the bucket labels bench.py prints (profiles/hbm_traffic.json keys)."""
+    import importlib.util, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rocpd_pmc", os.path.join(root, "tools", "rocpd_pmc.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    bench_src = open(os.path.join(root, "bench.py")).read()
+    for name in ("_ZN2sa14gemm_nt_kernelIttLi64ELi64ELi2ELi2ELi0ELb1ELi4EEEvNS_8GemmArgsIT_T0_EE.kd",
+                 "_ZN2sa14gemm_nt_kernelIttLi256ELi256ELi4ELi2ELi3ELb0ELi2EEEvNS_8GemmArgsIT_T0_EE.kd",
+                 "_ZN2sa14gemm_nt_kernelItfLi128ELi128ELi2ELi2ELi6ELb0ELi2EEEvNS_8GemmArgsIT_T0_EE.kd",
+                 "_ZN2sa16conv_gemm_kernelItLi128ELi128ELi2ELi2ELb1EEEvNS_8ConvArgsIT_EE.kd"):
+        b = mod.bucket(name)
+        assert b is not None and b in bench_src, (name, b)
+    assert mod.bucket("_ZN2sa14rmsnorm_kernelItEEvPKT_lS3_PS1_lPKiiif.kd") is None
+    import json
+    keys = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json"))).keys()
+    assert all(k in bench_src for k in keys)
