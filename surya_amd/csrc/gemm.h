@@ -2,21 +2,28 @@
 //
 // Both operands are K-contiguous (activations row-major, weights in nn.Linear layout), so both MFMA
 // fragments are 16-byte `ds_read_b128` reads of the same LDS geometry. Tiles are expressed in 128-byte
-// K-rows: 64 bf16 or 32 fp32 elements, which makes the bf16 path (v_mfma_f32_16x16x32_bf16) and the exact
-// fp32 path (4 x v_mfma_f32_16x16x4_f32 per 16-byte chunk, k-permuted identically on both operands) share
+// K-rows: 64 bf16 or 32 fp32 elements, which makes the bf16 path (v_mfma_f32_32x32x16_bf16) and the exact
+// fp32 path (4 x v_mfma_f32_32x32x2_f32 per 16-byte chunk, k-permuted identically on both operands) share
 // every address computation.
 //
-// The weight fragment is the FIRST MFMA operand, so the 16x16 result is D[n][m]: a lane owns 4 CONSECUTIVE
+// The weight fragment is the FIRST MFMA operand, so the 32x32 result is D[n][m]: a lane owns 4 CONSECUTIVE
 // output columns n of one row m -> 8/16-byte stores, float4 bias loads, and the (gate, up) pairs of the
-// interleaved SwiGLU weight land in one lane.
+// interleaved SwiGLU weight / the rotate_half pairs of the pair-interleaved vision q,k rows land in one lane.
 //
-// Pipeline: K-tiles are fetched TWO tiles ahead into alternating register sets and written to a double-buffered,
-// XOR-swizzled LDS image one iteration before use (one barrier per K-tile). The first version fetched one tile
-// ahead and was global-latency-bound (0.9-1.4 us per K-iteration at M=256: r01 profile).
+// Staging, two generations (template parameter GLDS):
+//   GLDS = 0  K-tiles are fetched TWO tiles ahead into alternating register sets and written to a double-buffered,
+//             XOR-swizzled LDS image one iteration before use (one barrier per K-tile); kept for tile shapes whose
+//             staging does not divide into whole 8-row groups per wave.
+//   GLDS >= 2 global_load_lds_dwordx4 moves 8 tile rows per instruction straight into LDS (swizzle on the source
+//             address): 2 stages unrolled for the big tiles, a ring of GLDS stages with raw s_barrier + vmcnt(N) for the
+//             split-K decode tiles.
+// Main loop: the ds_read_b128 fragment reads of K-step kk+1 are interleaved with the MFMAs of step kk.
 //
-// Tile menu: 128x128 (4 waves 2x2) for large problems; "tall" 256x64 / 256x32 (8 waves stacked in M) for the
-// decode regime M <= 256, where a block covers every row so each weight byte is fetched from HBM exactly once
-// and X is re-read from L2 only N/BN times.
+// Tile menu (launch_gemm): 256x256 (8 waves 4x2, 64x128 per wave) when whole rounds of 256 workgroups are cheaper than
+// rounds of 512 128x128 tiles; 128x128 (4 waves 2x2); 64x64 / 128x64 / 64x32 for the decode regime M <= 256 (many light
+// workgroups beat tall 256-row tiles there, tools/microbench); split-K for the skinny decode projections.
+// Epilogues: bias / residual / GELU / SwiGLU / Hardswish / ReLU / greedy-argmax partials / vision RoPE, staged through LDS
+// into coalesced 16-byte row stores.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -645,8 +652,9 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || !a.part) return SA_ERR_SHAPE;
     const int nk = a.K / Ty<TI>::KE;
     // 64x64 tiles (4 M-tiles at M = 256) beat the tall 256-row tiles for these skinny projections: many light
-    // workgroups (32 KiB LDS, 4-5 per CU) hide the per-iteration load latency better than few heavy ones
-    // (tools/microbench/gemm_shapes.py: unsplit 64x64 11 us vs tall 16 us for qkv at M = 256).
+    // workgroups hide the per-iteration load latency better than few heavy ones (tools/microbench/gemm_shapes.py:
+    // unsplit 64x64 11 us vs tall 16 us for qkv at M = 256). Default: 64x64 with a 4-stage direct-to-LDS ring
+    // (mode 4006464) and ~256 workgroups; the other modes are kept for A/B runs.
     static const int mode = [] { const char* e = getenv("SURYA_AMD_SPLIT_TILE"); return e ? atoi(e) : 4006464; }();
     static const int target = [] { const char* e = getenv("SURYA_AMD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
     if (mode == 6464) {
