@@ -116,6 +116,13 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.save(golden_rec("REC-TINY", "eager"), os.path.join(GOLD, "rec_tiny_eager.pt"))
     torch.save(golden_rec("REC-TINY", "sdpa"), os.path.join(GOLD, "rec_tiny_sdpa.pt"))
+    small = golden_rec("REC-SMALL", "eager")        # FULL's op mix (encoder head_dim 80, GQA 5:1, odd intermediate) at ~1/30 the weights
+    lg = small.pop("logits")                         # [steps, B, V]: keep the top 32 per row + logsumexp (fixture size)
+    tk = torch.topk(lg, 32, dim=-1)
+    small["logits_top"] = {"values": tk.values.clone(), "indices": tk.indices.clone()}
+    small["logits_lse"] = torch.logsumexp(lg, -1)
+    small["logits_absmax"] = lg.abs().amax(-1)
+    torch.save(small, os.path.join(GOLD, "rec_small_eager.pt"))
     torch.save(golden_det("DET-TINY", 128, 2), os.path.join(GOLD, "det_tiny.pt"))
     torch.save(golden_processor(), os.path.join(GOLD, "processor_tiles.pt"))
     for f in sorted(os.listdir(GOLD)):

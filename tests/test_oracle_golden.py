@@ -37,6 +37,30 @@ def test_rec_oracle_matches_reference(attn):
         assert torch.equal(logits[s].argmax(-1), g["tokens"][s])          # token ids bit-exact
 
 
+def test_rec_small_oracle_matches_reference():
+    """REC-SMALL (FULL's op mix: encoder head_dim 80, GQA 5:1, odd MLP width): image embeddings, the reference's top-32
+    logits per step (values at the same vocabulary indices), logsumexp and greedy tokens."""
+    g = torch.load(os.path.join(GOLD, "rec_small_eager.pt"))
+    cfg = rec_config(g["config"])
+    sd = make_rec_weights(cfg, 0)
+    grids = [tuple(x) for x in g["grids"]]
+    tiles, seqs = make_prompts(cfg, grids, seed=g["seed"])
+    thw = [(1, h, w) for h, w in grids]
+    emb = ro.image_embeddings(sd, cfg, tiles, thw)
+    assert (emb - g["image_embeddings"]).abs().max().item() <= 2e-5 * g["image_embeddings"].abs().max().item()
+    ids, am, pos = left_pad_batch(cfg, seqs)
+    om = ro.OracleRecModel(cfg, sd, cfg.image_token_id)
+    steps = g["tokens"].shape[0]
+    logits = ro.teacher_forced_logits(om, ids, tiles, thw, am, pos, [g["tokens"][:, b].tolist() for b in range(len(seqs))],
+                                      cfg.pad_token_id)
+    for s in range(steps):
+        tol = 1e-4 * float(g["logits_absmax"][s].max())
+        got_top = torch.gather(logits[s], -1, g["logits_top"]["indices"][s])
+        assert (got_top - g["logits_top"]["values"][s]).abs().max().item() <= tol, s
+        assert (torch.logsumexp(logits[s], -1) - g["logits_lse"][s]).abs().max().item() <= tol, s
+        assert torch.equal(logits[s].argmax(-1), g["tokens"][s])          # token ids bit-exact
+
+
 def test_rec_oracle_greedy_loop_and_boxes_match_reference():
     g = torch.load(os.path.join(GOLD, "rec_tiny_eager.pt"))
     cfg = rec_config(g["config"])
