@@ -31,3 +31,97 @@ def test_live_rec_small_head_dim_80_and_gqa():
     assert (lm - out.lm_logits).abs().max().item() <= 1e-4 * out.lm_logits.abs().max().item()
     assert (bb - out.bbox_logits).abs().max().item() <= 1e-5
     assert torch.equal(lm.argmax(-1), out.lm_logits.argmax(-1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Host logic of the predictors against the reference's own functions on randomised inputs.
+# These reference modules are plain Python; they import through oracle/ref_shim like the model modules above.
+
+def _ref(modname):
+    """Import a reference submodule WITHOUT running its package __init__ (surya/recognition/__init__.py imports names that
+    transformers 5.x no longer has): the package is registered as a bare namespace pointing at the reference directory."""
+    import importlib, os, sys, types
+    ref_shim.install()
+    pkg = modname.rsplit(".", 1)[0]
+    if pkg not in sys.modules and pkg != "surya":
+        importlib.import_module("surya")
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(ref_shim.REFERENCE_ROOT, *pkg.split("."))]
+        sys.modules[pkg] = m
+    return importlib.import_module(modname)
+
+
+def test_live_detect_repeat_token_random_streams():
+    import random
+    ru = _ref("surya.recognition.util")
+    from surya_amd.recognition.postprocess import detect_repeat_token
+    rng = random.Random(3)
+    for _ in range(4000):
+        n = rng.randint(0, 90)
+        vocab = rng.choice([1, 2, 3, 5, 8, 50])
+        toks = [rng.randrange(vocab) for _ in range(n)]
+        if rng.random() < 0.5 and n > 10:                       # plant a periodic tail
+            period = rng.randint(1, 6)
+            tail = [rng.randrange(vocab) for _ in range(period)]
+            toks = toks[: rng.randint(0, 20)] + tail * rng.randint(3, 30)
+        assert detect_repeat_token(toks) == bool(ru.detect_repeat_token(toks)), toks
+
+
+def test_live_prediction_to_polygon_batch_random():
+    import numpy as np
+    ru = _ref("surya.recognition.util")
+    from surya_amd.recognition.postprocess import prediction_to_polygon_batch
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        n, t = int(rng.integers(1, 6)), int(rng.integers(1, 12))
+        pred = rng.integers(0, 1025, size=(n, t, 6)).astype(np.float32)
+        sizes = [(int(rng.integers(20, 400)), int(rng.integers(20, 1200))) for _ in range(n)]
+        ref = ru.prediction_to_polygon_batch(torch.from_numpy(pred.copy()), sizes, 1025, 512).numpy()
+        got = prediction_to_polygon_batch(pred, sizes, 1025, 512)
+        assert np.array_equal(got, ref)
+
+
+def test_live_math_tag_cleaning_and_unwrap():
+    import random
+    ru = _ref("surya.recognition.util")
+    from surya_amd.recognition import postprocess as pp
+    rng = random.Random(11)
+    pieces = ["<math>", "</math>", '<math display="block">', "x^2", " ", "a", "\\frac{1}{2}", "<b>", "</b>", "text", "\\(", "\\)",
+              "<br>", "$", "1 + 1", "<math display='inline'>", "\n"]
+    for _ in range(3000):
+        s = "".join(rng.choice(pieces) for _ in range(rng.randint(0, 12)))
+        assert pp.clean_math_tags(s) == ru.clean_math_tags(s), s
+        assert pp.unwrap_math(s) == ru.unwrap_math(s), s
+
+
+def test_live_clean_close_polygons_random():
+    import random
+    ru = _ref("surya.recognition.util")
+    from surya_amd.recognition.postprocess import clean_close_polygons
+    rng = random.Random(17)
+    for _ in range(500):
+        polys = []
+        for _ in range(rng.randint(0, 8)):
+            x, y = rng.randint(0, 100), rng.randint(0, 50)
+            w, h = rng.choice([0, 1, 2, 5, 30]), rng.choice([0, 1, 3, 12])
+            polys.append([[x, y], [x + w, y], [x + w, y + h], [x, y + h]])
+            if rng.random() < 0.4:                               # near-duplicate of the previous box
+                polys.append([[px + rng.choice([0, 0, 1]), py] for px, py in polys[-1]])
+        assert clean_close_polygons([[[float(a), float(b)] for a, b in p] for p in polys]) == \
+               ru.clean_close_polygons([[[a, b] for a, b in p] for p in polys])
+
+
+def test_live_detection_split_rules():
+    from PIL import Image
+    du = _ref("surya.detection.util")
+    from surya_amd.detection.predictor import get_total_splits, split_image
+    import numpy as np
+    for w, h in [(800, 600), (1000, 1400), (1000, 1401), (700, 3000), (333, 5001), (1200, 1200)]:
+        for height in (512, 1024, 1200):
+            assert get_total_splits((w, h), height) == du.get_total_splits((w, h), height)
+            img = Image.fromarray((np.arange(w * h * 3, dtype=np.uint32) % 251).astype(np.uint8).reshape(h, w, 3))
+            ours, ours_h = split_image(img, height)
+            ref, ref_h = du.split_image(img, height)
+            assert ours_h == ref_h and len(ours) == len(ref)
+            for a, b in zip(ours, ref):
+                assert a.size == b.size and np.array_equal(np.asarray(a), np.asarray(b))
