@@ -125,3 +125,60 @@ def test_live_detection_split_rules():
             assert ours_h == ref_h and len(ours) == len(ref)
             for a, b in zip(ours, ref):
                 assert a.size == b.size and np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_live_fix_unbalanced_tags_and_words_from_chars():
+    import random
+    rp = _ref("surya.recognition.postprocessing")
+    ru = _ref("surya.recognition.util")
+    rs = _ref("surya.recognition.schema")
+    rpoly = _ref("surya.common.polygon")
+    from surya_amd.recognition import postprocess as pp
+    from surya_amd.recognition.schema import TextChar
+    from surya_amd.common.geometry import PolygonBox
+    special = {"formatting": ["<b>", "</b>", "<i>", "</i>", "<u>", "</u>", "<sup>", "</sup>", "<br>"],
+               "math_external": ["<math>", "</math>"], "system": ["<S>"]}
+    rng = random.Random(23)
+    texts = ["a", "b", " ", "<b>", "</b>", "<i>", "</i>", "<math>", "</math>", "<br>", "<br/>", "<sup>", "</sup>", "<x>", "W", "é",
+             '<math display="block">', "<u/>"]
+
+    def poly(x):
+        return [[x, 2.0], [x + 7.0, 2.0], [x + 7.0, 14.0], [x, 14.0]]
+
+    for _ in range(600):
+        n = rng.randint(0, 14)
+        items = [(rng.choice(texts), rng.random() < 0.8, float(8 * i + rng.randint(0, 3))) for i in range(n)]
+        ours = [TextChar(text=t, confidence=0.5, polygon=poly(x), bbox_valid=v) for t, v, x in items]
+        refs = [rs.TextChar(text=t, confidence=0.5, polygon=poly(x), bbox_valid=v) for t, v, x in items]
+        a = pp.fix_unbalanced_tags(list(ours), special)
+        b = rp.fix_unbalanced_tags(list(refs), special)
+        assert [(c.text, c.bbox_valid, c.polygon) for c in a] == [(c.text, c.bbox_valid, c.polygon) for c in b]
+        line = [[0.0, 0.0], [8.0 * n + 20, 0.0], [8.0 * n + 20, 16.0], [0.0, 16.0]]
+        wa = pp.words_from_chars(ours, PolygonBox(polygon=line))
+        wb = ru.words_from_chars(refs, rpoly.PolygonBox(polygon=line))
+        assert [(w.text, w.polygon, w.bbox_valid) for w in wa] == [(w.text, w.polygon, w.bbox_valid) for w in wb]
+
+
+def test_live_polygon_box_semantics_random():
+    import random
+    rpoly = _ref("surya.common.polygon")
+    from surya_amd.common.geometry import PolygonBox
+    rng = random.Random(29)
+
+    def rnd_poly():
+        x, y = rng.uniform(0, 200), rng.uniform(0, 100)
+        w, h = rng.uniform(1, 80), rng.uniform(1, 40)
+        return [[x, y], [x + w, y + rng.uniform(-2, 2)], [x + w, y + h], [x, y + h + rng.uniform(-2, 2)]]
+
+    for _ in range(400):
+        pa, pb = rnd_poly(), rnd_poly()
+        a, b = PolygonBox(polygon=[list(p) for p in pa]), PolygonBox(polygon=[list(p) for p in pb])
+        ra, rb = rpoly.PolygonBox(polygon=[list(p) for p in pa]), rpoly.PolygonBox(polygon=[list(p) for p in pb])
+        assert a.bbox == ra.bbox and a.area == ra.area and a.height == ra.height and a.width == ra.width
+        assert a.intersection_area(b) == ra.intersection_area(rb)
+        assert a.intersection_pct(b) == ra.intersection_pct(rb)
+        assert a.center == ra.center
+        a.merge(b); ra.merge(rb)
+        assert a.polygon == ra.polygon
+        a.rescale((200, 100), (400, 300)); ra.rescale((200, 100), (400, 300))
+        assert a.polygon == ra.polygon
