@@ -80,6 +80,24 @@ def test_gemm_epilogues(hip_lib, dtype, epi):
     assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
 
 
+@pytest.mark.parametrize("epi", [L.EPI_BIAS, L.EPI_RESIDUAL, L.EPI_SWIGLU])
+def test_gemm_256x256_tiles_ragged(hip_lib, epi):
+    """Shape that the launcher sends to the 256x256 tile (16 x 16 tiles = one full round of 256 workgroups beats two rounds of
+    128x128 tiles), ragged in M and N so edge tiles clip rows and columns."""
+    M, N, K = 3990, 4000, 320
+    g = torch.Generator(device="cuda").manual_seed(100 + epi)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g).bfloat16()
+    No = N // 2 if epi == L.EPI_SWIGLU else N
+    res = torch.randn(M, No, device="cuda", generator=g).bfloat16() if epi == L.EPI_RESIDUAL else None
+    out = run_gemm(hip_lib, x, w, b, epi, res)
+    ref = ref_gemm(x, w, b, epi, res)
+    err = (out.float() - ref).abs().max().item()
+    assert not torch.isnan(out.float()).any()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
 def test_gemm_transpose_detecting(hip_lib):
     """A = I against an asymmetric W: catches a swapped C layout (guide rule 16)."""
     K = 64
