@@ -270,3 +270,36 @@ def test_bf16_teacher_forced(hip_lib, cfg_name):
     assert mism == 0, (mism, checked)
     print(f"bf16 teacher-forced {cfg_name}: worst rel logit err {worst:.4f} (reference bf16 path {worst_ref:.4f}), "
           f"argmax checked {checked}, mismatches {mism}")
+
+
+def test_full_vocab_fused_argmax_equals_recomputed_logits(hip_lib):
+    """REC-FULL (V = 81920), 160 rows: the greedy head's token / score come from (max, argmax, sum-exp) partials reduced in
+    the lm_head GEMM's epilogue (128x128 tile for 128 < M <= 256 at this vocabulary size); surya_rec_copy_last_logits
+    recomputes the full fp32 logits with the plain-bias epilogue of the same GEMM. argmax and max-softmax of those logits
+    must reproduce the fused outputs, after the prefill and after decode steps. (Last test of the GPU suite on purpose.)"""
+    from surya_amd.recognition.model import HipRecModel
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    n = 160
+    m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    dtype=torch.bfloat16, max_slots=192, max_kv_len=64, max_patches=8192, max_prefill_tokens=4096)
+    grids = [(2, 2 + 2 * (i % 5)) for i in range(n)]
+    tiles, seqs = make_prompts(cfg, grids, seed=9)
+    slots = list(range(n))
+
+    def check(tok, score):
+        lg = m.last_logits().cpu()
+        assert lg.shape == (n, cfg.decoder.vocab_size)
+        ref_tok = lg.argmax(-1).numpy()
+        assert np.array_equal(np.asarray(tok)[slots], ref_tok)
+        ref_score = torch.softmax(lg, -1).max(-1).values.numpy()
+        live = ~np.isin(ref_tok, [cfg.eos_token_id, cfg.pad_token_id])          # finished rows report score 0
+        assert np.allclose(np.asarray(score)[slots][live], ref_score[live], rtol=2e-3, atol=1e-7)
+
+    m.prefill(tiles.cuda(), grids, seqs, slots)
+    t, s, _ = m.read_outputs(1)
+    check(t[0], s[0])
+    m.set_active(slots)
+    m.decode(2)
+    t, s, _ = m.read_outputs(2)
+    check(t[1], s[1])
