@@ -1,0 +1,166 @@
+"""Generate the BASELINE-configuration fixtures from the REAL reference modules (build container only; takes minutes).
+
+    python oracle/make_golden_full.py [rec8] [rec256] [small256] [det1024]
+
+Like oracle/make_golden.py this imports VikParuchuri/surya @ v0.14.6 from /root/reference through oracle/ref_shim and
+loads the seeded synthetic weights into the reference's own nn.Modules. What it records is the bench's own workload:
+
+  rec_full_bench8.pt    REC-FULL, 8 of bench.py's 256 line crops (spread over the widths), 48 greedy tokens each:
+                        tokens, bbox ints + un-truncated values, scores, the reference's top-32 logits / logsumexp per
+                        step, and the reference's OWN bf16-vs-fp32 logit deviation per step (teacher forced; the
+                        rounding model the bf16 HIP path is held to)
+  rec_full_bench256.pt  REC-FULL, all 256 bench crops in one left-padded batch: prefill + 3 decode steps (M = 256 tiles,
+                        split-K with 4 M-tiles, the 128x128 fused-argmax lm_head) -- tokens, bbox ints, top-8 logits
+  rec_small_256.pt      REC-SMALL, 256 ragged synthetic prompts, 12 steps (same tile paths, deeper)
+  det_default_1024.pt   DET-DEFAULT, one synthetic 1024^2 page: the module's [1, 2, 256, 256] output, the x4 upsample
+                        subsampled, and the reference's own bf16-vs-fp32 deviation
+
+The fixtures travel to the GPU box, where /root/reference does not exist; tests/test_gpu_baseline_parity.py compares
+the HIP path with them, tests/test_oracle_golden.py pins oracle/*.py against them on the CPU.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_shim
+
+ref_shim.install()
+
+from oracle.make_golden import build_reference_rec            # noqa: E402
+from surya_amd.config import rec_config, det_config            # noqa: E402
+from surya_amd.synth import make_rec_weights, make_det_weights, make_pages   # noqa: E402
+from util import bench_line_inputs, make_prompts, left_pad_batch, crop_grid   # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+BENCH8 = [0, 36, 73, 109, 146, 182, 219, 255]     # positions in the widest-first order of bench.py's 256 crops
+
+
+def run_reference(ref, cfg, tiles, grids, seqs, steps, forced=None):
+    """Greedy (or teacher-forced) loop on the reference's SuryaModel: prefill + steps-1 decode calls
+    (recognition/__init__.py:326-352, 398-409 call shapes). Returns per-step logits [steps, B, V] and bbox logits."""
+    from transformers import DynamicCache
+    ids, am, pos = left_pad_batch(cfg, seqs)
+    grid = torch.tensor([(1, h, w) for h, w in grids])
+    dt = next(ref.parameters()).dtype
+    logits, bboxes, tokens = [], [], []
+    with torch.inference_mode():
+        cache = DynamicCache()
+        out = ref(input_ids=ids, image_tiles=tiles.to(dt), grid_thw=grid, attention_mask=am, position_ids=pos,
+                  past_key_values=cache, use_cache=True, logits_to_keep=1, encoder_chunk_size=4096)
+        for step in range(steps):
+            lm, bb = out.lm_logits[:, -1].float(), out.bbox_logits[:, -1].float()
+            logits.append(lm.clone()); bboxes.append(bb.clone())
+            nxt = lm.argmax(-1, keepdim=True) if forced is None else forced[step].reshape(-1, 1)
+            tokens.append(nxt[:, 0].clone())
+            if step + 1 == steps:
+                break
+            am = F.pad(am, (0, 1), value=1)
+            pos = pos[:, -1:] + 1
+            out = ref(input_ids=nxt, attention_mask=am, position_ids=pos, use_cache=True, past_key_values=cache, logits_to_keep=1)
+    return torch.stack(logits), torch.stack(bboxes), torch.stack(tokens)
+
+
+def pack(cfg, lg, bb, tk, topk):
+    t = torch.topk(lg, topk, dim=-1)
+    return {"tokens": tk, "bbox_raw": bb * cfg.bbox_size, "bbox_ints": (bb * cfg.bbox_size).to(torch.long),
+            "scores": torch.softmax(lg, -1).amax(-1), "logits_top": {"values": t.values.clone(), "indices": t.indices.clone()},
+            "logits_lse": torch.logsumexp(lg, -1), "logits_absmax": lg.abs().amax(-1)}
+
+
+def rec8():
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    tiles, grids, seqs = bench_line_inputs(cfg, 256, seed=1234, pick=BENCH8)
+    ref = build_reference_rec(cfg, sd, "eager")
+    t0 = time.time()
+    lg, bb, tk = run_reference(ref, cfg, tiles, grids, seqs, 48)
+    print(f"rec8 fp32 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "REC-FULL", "attn": "eager", "lines": 256, "line_seed": 1234, "pick": BENCH8, "grids": grids,
+         "tiles_sum": float(tiles.double().sum()), **pack(cfg, lg, bb, tk, 32)}
+    t0 = time.time()
+    lgb, _, _ = run_reference(ref.bfloat16(), cfg, tiles, grids, seqs, 48, forced=tk)
+    print(f"rec8 bf16 reference: {time.time() - t0:.1f}s", flush=True)
+    g["bf16_dev"] = (lgb - lg).abs().amax(-1)                 # [steps, B]: the reference's own rounding deviation
+    g["bf16_dev_top"] = (torch.gather(lgb, -1, g["logits_top"]["indices"]) - g["logits_top"]["values"]).abs().amax(-1)
+    torch.save(g, os.path.join(GOLD, "rec_full_bench8.pt"))
+
+
+def rec256():
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    tiles, grids, seqs = bench_line_inputs(cfg, 256, seed=1234)
+    ref = build_reference_rec(cfg, sd, "sdpa")
+    t0 = time.time()
+    lg, bb, tk = run_reference(ref, cfg, tiles, grids, seqs, 4)
+    print(f"rec256 fp32 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "REC-FULL", "attn": "sdpa", "lines": 256, "line_seed": 1234, "grids": grids,
+         "tiles_sum": float(tiles.double().sum()), **pack(cfg, lg, bb, tk, 8)}
+    torch.save(g, os.path.join(GOLD, "rec_full_bench256.pt"))
+
+
+def small256_grids():
+    rng = np.random.default_rng(77)
+    return [crop_grid(64, int(w)) for w in sorted(rng.integers(128, 513, size=256), reverse=True)]
+
+
+def small256():
+    cfg = rec_config("REC-SMALL")
+    sd = make_rec_weights(cfg, 0)
+    grids = small256_grids()
+    tiles, seqs = make_prompts(cfg, grids, seed=11)
+    ref = build_reference_rec(cfg, sd, "sdpa")
+    t0 = time.time()
+    lg, bb, tk = run_reference(ref, cfg, tiles, grids, seqs, 12)
+    print(f"small256 fp32 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "REC-SMALL", "attn": "sdpa", "grids": grids, "seed": 11, **pack(cfg, lg, bb, tk, 8)}
+    lgb, _, _ = run_reference(ref.bfloat16(), cfg, tiles, grids, seqs, 12, forced=tk)
+    g["bf16_dev"] = (lgb - lg).abs().amax(-1)
+    torch.save(g, os.path.join(GOLD, "rec_small_256.pt"))
+
+
+def det1024():
+    from surya.detection.model.config import EfficientViTConfig
+    from surya.detection.model.encoderdecoder import EfficientViTForSemanticSegmentation
+    from oracle.det_oracle import normalise_pages
+    c = det_config("DET-DEFAULT")
+    rc = EfficientViTConfig(widths=c.widths, depths=c.depths, head_dim=c.head_dim,
+                            decoder_layer_hidden_size=c.decoder_layer_hidden_size, decoder_hidden_size=c.decoder_hidden_size,
+                            num_labels=c.num_labels)
+    m = EfficientViTForSemanticSegmentation(rc).eval()
+    m.load_state_dict(make_det_weights(c, 0), strict=True)
+    x = normalise_pages(make_pages(16, 1024, seed=1234)[:1])          # page 0 of bench.py's detection leg
+    with torch.inference_mode():
+        t0 = time.time()
+        out = m(pixel_values=x).logits
+        print(f"det1024 fp32 reference: {time.time() - t0:.1f}s", flush=True)
+        up = F.interpolate(out, size=(1024, 1024), mode="bilinear", align_corners=False)      # detection/__init__.py:121-129
+        t0 = time.time()
+        outb = m.bfloat16()(pixel_values=x.bfloat16()).logits.float()
+        print(f"det1024 bf16 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "DET-DEFAULT", "size": 1024, "pages": 16, "page_seed": 1234, "page": 0, "logits": out.clone(),
+         "upsampled_sample": up[:, :, ::4, ::4].clone(), "bf16_dev": float((outb - out).abs().max()),
+         "bf16_dev_mean": float((outb - out).abs().mean())}
+    torch.save(g, os.path.join(GOLD, "det_default_1024.pt"))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["rec8", "rec256", "small256", "det1024"]
+    for w in which:
+        {"rec8": rec8, "rec256": rec256, "small256": small256, "det1024": det1024}[w]()
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()

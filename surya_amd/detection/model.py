@@ -18,7 +18,7 @@ class DetOpC(C.Structure):
 
 class HipDetModel:
     def __init__(self, cfg: DetConfig, state_dict, *, height: int, width: int, dtype: torch.dtype = torch.bfloat16,
-                 device="cuda:0", max_batch: int = 16):
+                 device="cuda:0", max_batch: int = 16, broadcast_weights: bool = False, process_group=None):
         if not torch.cuda.is_available():
             raise L.SuryaAmdError("HipDetModel needs a GPU (MI355X); there is no CPU fallback")
         if dtype not in (torch.float32, torch.bfloat16):
@@ -31,6 +31,14 @@ class HipDetModel:
         plan = build_det_plan(cfg, state_dict, height, width)
         self.flops_per_image = plan.flops_per_image
         self.weights = [w.to(device=self.device, dtype=dtype).contiguous() for w in plan.weights]
+        if broadcast_weights:             # every rank planned the op list (shapes); the folded weights used are rank 0's
+            from .. import dist as sdist
+            if sdist.world_info(process_group)[1] > 1:
+                cdev = sdist.collective_device(self.device, process_group)
+                tmp = [w.to(cdev) for w in self.weights]
+                sdist.broadcast_tensors(tmp, src=0, group=process_group)
+                for w, t in zip(self.weights, tmp):
+                    w.copy_(t)
         ops = (DetOpC * len(plan.ops))(*[DetOpC(**o) for o in plan.ops])
         table = (C.c_void_p * len(self.weights))(*[w.data_ptr() for w in self.weights])
         bufs = (C.c_size_t * len(plan.buf_elems))(*plan.buf_elems)
@@ -45,6 +53,21 @@ class HipDetModel:
         if h:
             self.lib.surya_det_destroy(h)
             self.handle = None
+
+    @property
+    def config(self):
+        return self.cfg
+
+    def to(self, device_dtype=None):
+        """See HipRecModel.to: same-placement requests are no-ops, anything else needs a new handle."""
+        if device_dtype is None or device_dtype == self.dtype:
+            return self
+        if not isinstance(device_dtype, torch.dtype) and torch.device("cuda:0" if device_dtype == "cuda" else device_dtype) == self.device:
+            return self
+        raise NotImplementedError(f"HipDetModel lives on {self.device} as {self.dtype}; create a new predictor for {device_dtype}")
+
+    def eval(self):
+        return self
 
     def forward(self, pixel_values: torch.Tensor, want_lowres: bool = False):
         """pixel_values cuda fp32 [B,3,H,W] -> heatmaps fp32 [B, labels, H, W] (and [B, labels, H/4, W/4])."""

@@ -76,7 +76,12 @@ class DetectionModelLoader(ModelLoader):
         if dtype is None:
             dtype = torch.bfloat16        # the reference picks fp16 on GPUs (detection/loader.py:31); BASELINE asks bf16
         mb = max_batch or settings.DETECTOR_BATCH_SIZE or DetectionPredictor.default_batch_sizes["cuda"]
-        return HipDetModel(self._cfg, self._sd, height=self._size, width=self._size, dtype=dtype, device=device, max_batch=mb)
+        bw = False
+        if settings.SURYA_AMD_BROADCAST_WEIGHTS:
+            from .. import dist as sdist
+            bw = sdist.world_info()[1] > 1
+        return HipDetModel(self._cfg, self._sd, height=self._size, width=self._size, dtype=dtype, device=device, max_batch=mb,
+                           broadcast_weights=bw)
 
     def processor(self, device=None, dtype=None) -> SegformerImageProcessor:
         return SegformerImageProcessor({"height": self._size, "width": self._size})
@@ -87,7 +92,28 @@ class DetectionPredictor(BasePredictor):
     batch_size = settings.DETECTOR_BATCH_SIZE
     default_batch_sizes = {"cpu": 8, "mps": 8, "cuda": 36, "xla": 18}
 
+    # Multi-GPU: when set, ONE call's pages are dealt over the ranks (a page's strips stay on one rank), each
+    # rank detects + post-processes its pages and the per-page results (boxes only, a few KB) are all-gathered as objects.
+    # Every rank must pass the same pages (checked). Off by default, like RecognitionPredictor.shard_lines.
+    shard_pages: bool = settings.SURYA_AMD_SHARD
+    process_group = None
+
     def __call__(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        if self.shard_pages:
+            from .. import dist as sdist
+            rank, world = sdist.world_info(self.process_group)
+            if world > 1:
+                import zlib
+                dev = sdist.collective_device(self.model.device, self.process_group)
+                sizes = np.asarray([im.size for im in images], np.int64).reshape(-1, 2)
+                probe = b"".join(im.tobytes()[:4096] for im in images[:: max(1, len(images) // 16)])
+                sdist.assert_same_inputs([len(images), zlib.crc32(sizes.tobytes()), zlib.crc32(probe)], self.process_group, dev)
+                mine = sdist.shard_indices(len(images), world, rank)
+                local = self._detect([images[i] for i in mine], batch_size, include_maps) if mine else []
+                return sdist.gather_objects(local, mine, len(images), self.process_group)
+        return self._detect(images, batch_size, include_maps)
+
+    def _detect(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
         gen = self.batch_detection(images, batch_size=batch_size)
         futures = []
         workers = max(1, min(settings.DETECTOR_POSTPROCESSING_CPU_WORKERS, len(images)))

@@ -18,11 +18,35 @@ import numpy as np
 import torch
 
 
-def world_info() -> Tuple[int, int]:
+def world_info(group=None) -> Tuple[int, int]:
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def collective_device(model_device, group=None) -> torch.device:
+    """Where collective buffers must live: the GPU for RCCL ("nccl"), host memory for gloo."""
+    import torch.distributed as dist
+    return torch.device(model_device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def assert_same_inputs(fingerprint: Sequence[int], group=None, device="cpu"):
+    """Sharding a call only makes sense when every rank was handed the SAME inputs (each then recognises its share and
+    all get all results). A job where every rank OCRs its own pages must not come here: compare a fingerprint of the
+    inputs across ranks first and raise on every rank, instead of hanging in a mis-sized all_gather or silently mixing
+    lines of different pages."""
+    import torch.distributed as dist
+    _, world = world_info(group)
+    if world == 1:
+        return
+    mine = torch.tensor(list(fingerprint), dtype=torch.int64, device=device)
+    allf = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allf, mine, group=group)
+    if any(not torch.equal(f, allf[0]) for f in allf):
+        raise RuntimeError("surya_amd: sharded call, but the ranks were given different inputs "
+                           f"(fingerprints {[f.tolist() for f in allf]}); disable sharding (SURYA_AMD_SHARD=0 / "
+                           "predictor.shard_lines = False) when every rank processes its own pages")
 
 
 def shard_indices(n: int, world: int, rank: int) -> List[int]:
@@ -31,11 +55,11 @@ def shard_indices(n: int, world: int, rank: int) -> List[int]:
 
 
 def gather_line_outputs(tokens: Sequence[Sequence[int]], scores: Sequence[Sequence[float]], bboxes: np.ndarray,
-                        local_idx: Sequence[int], n_total: int, max_tokens: int, device="cpu"):
+                        local_idx: Sequence[int], n_total: int, max_tokens: int, device="cpu", group=None):
     """All ranks contribute the outputs of their shard; every rank gets all n_total lines back in global order.
     bboxes: [n_local, max_tokens, 6]. Returns (tokens list, scores list, bboxes [n_total, max_tokens, 6])."""
     import torch.distributed as dist
-    rank, world = world_info()
+    rank, world = world_info(group)
     per_rank = (n_total + world - 1) // world
     rec = torch.zeros((per_rank, max_tokens, 8), dtype=torch.int32)
     lens = torch.zeros((per_rank, 2), dtype=torch.int32)            # (global index + 1, length); 0 = padding row
@@ -52,8 +76,8 @@ def gather_line_outputs(tokens: Sequence[Sequence[int]], scores: Sequence[Sequen
         rec, lens = rec.to(device), lens.to(device)
         all_rec = [torch.empty_like(rec) for _ in range(world)]
         all_lens = [torch.empty_like(lens) for _ in range(world)]
-        dist.all_gather(all_rec, rec)
-        dist.all_gather(all_lens, lens)
+        dist.all_gather(all_rec, rec, group=group)
+        dist.all_gather(all_lens, lens, group=group)
     out_tok: List[List[int]] = [[] for _ in range(n_total)]
     out_sc: List[List[float]] = [[] for _ in range(n_total)]
     out_bb = np.zeros((n_total, max_tokens, 6), np.float32)
@@ -69,11 +93,26 @@ def gather_line_outputs(tokens: Sequence[Sequence[int]], scores: Sequence[Sequen
     return out_tok, out_sc, out_bb
 
 
-def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20):
+def gather_objects(local: list, local_idx: Sequence[int], n_total: int, group=None) -> list:
+    """Small picklable per-item results (detection boxes of a page): every rank gets all n_total back in global order."""
+    import torch.distributed as dist
+    _, world = world_info(group)
+    if world == 1:
+        return list(local)
+    parts = [None] * world
+    dist.all_gather_object(parts, (list(local_idx), list(local)), group=group)
+    out = [None] * n_total
+    for idx, items in parts:
+        for i, it in zip(idx, items):
+            out[i] = it
+    return out
+
+
+def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20, group=None):
     """In-place broadcast of a list of same-device tensors in flat buckets (few large collectives: xGMI links are
     point-to-point, ~153 GB/s each, so bandwidth comes from message size, not from message count)."""
     import torch.distributed as dist
-    _, world = world_info()
+    _, world = world_info(group)
     if world == 1:
         return
     by_dtype = {}
@@ -86,7 +125,7 @@ def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_byte
             if not bucket:
                 return
             flat = torch.cat([t.reshape(-1) for t in bucket])
-            dist.broadcast(flat, src)
+            dist.broadcast(flat, src, group=group)
             off = 0
             for t in bucket:
                 n = t.numel()
@@ -100,3 +139,25 @@ def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_byte
             bucket.append(t)
             size += nb
         flush()
+
+
+def share_weights(weights, device, src: int = 0, group=None, bucket_bytes: int = 256 << 20) -> List[torch.Tensor]:
+    """Weight distribution at start-up (north_star: "RCCL broadcast of weights"): rank `src` repacked the checkpoint into
+    the kernel layout and passes its tensor list; every other rank passes None, learns shapes / dtypes from a broadcast
+    manifest, allocates on `device` and receives the bytes through broadcast_tensors. Returns the list on every rank.
+    One checkpoint read + one repack per node instead of one per GPU; REC-FULL is ~1.35 GB in 6 buckets."""
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    if world == 1:
+        return list(weights)
+    manifest = [[(tuple(t.shape), t.dtype) for t in weights] if rank == src else None]
+    dist.broadcast_object_list(manifest, src=src, group=group)
+    cdev = collective_device(device, group)
+    if rank == src:
+        local = [t.to(cdev) for t in weights]
+    else:
+        local = [torch.empty(shape, dtype=dt, device=cdev) for shape, dt in manifest[0]]
+    broadcast_tensors(local, src=src, bucket_bytes=bucket_bytes, group=group)
+    if rank == src:
+        return list(weights)
+    return [t.to(device) for t in local]

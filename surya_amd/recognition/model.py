@@ -19,7 +19,8 @@ from .weights import repack_rec_weights, pad64
 class HipRecModel:
     def __init__(self, cfg: RecConfig, state_dict, *, image_token_id: int, pad_token_id: int, eos_token_id: int,
                  dtype: torch.dtype = torch.bfloat16, device="cuda:0", max_slots: int = 256, max_kv_len: int = 512,
-                 max_patches: int = 65536, max_prefill_tokens: Optional[int] = None):
+                 max_patches: int = 65536, max_prefill_tokens: Optional[int] = None, broadcast_weights: bool = False,
+                 process_group=None):
         if not torch.cuda.is_available():
             raise L.SuryaAmdError("HipRecModel needs a GPU (MI355X); there is no CPU fallback")
         self.lib = L.lib()
@@ -34,7 +35,14 @@ class HipRecModel:
         self.vocab = d.vocab_size
         if max_prefill_tokens is None:
             max_prefill_tokens = max_slots * 96
-        self.weights = repack_rec_weights(cfg, state_dict, dtype, self.device)   # keeps tensors alive
+        if broadcast_weights:
+            # rank 0 repacks; the other ranks (state_dict may be None there) receive the kernel-layout tensors over RCCL
+            from .. import dist as sdist
+            rank, _ = sdist.world_info(process_group)
+            mine = repack_rec_weights(cfg, state_dict, dtype, self.device) if rank == 0 else None
+            self.weights = sdist.share_weights(mine, self.device, src=0, group=process_group)
+        else:
+            self.weights = repack_rec_weights(cfg, state_dict, dtype, self.device)   # keeps tensors alive
         mask = 0
         for i in e.fullatt_block_indexes:
             mask |= 1 << i
@@ -63,6 +71,30 @@ class HipRecModel:
         if h:
             self.lib.surya_rec_destroy(h)
             self.handle = None
+
+    @property
+    def config(self):
+        """The reference reads `model.config.bbox_size` (recognition/__init__.py:315) and friends off the module."""
+        return self.cfg
+
+    def to(self, device_dtype=None):
+        """BasePredictor.to calls model.to(...) (surya/common/predictor.py:31-35). Weights, KV slots and workspaces of a
+        handle live on the device it was created on, in the dtype it was created with; asking for the same placement is
+        a no-op, anything else needs a new handle (construct a new predictor) -- refuse loudly rather than pretend."""
+        if device_dtype is None:
+            return self
+        want_dev, want_dt = None, None
+        if isinstance(device_dtype, torch.dtype):
+            want_dt = device_dtype
+        else:
+            want_dev = torch.device("cuda:0" if device_dtype == "cuda" else device_dtype)
+        if (want_dt is not None and want_dt != self.dtype) or (want_dev is not None and want_dev != self.device):
+            raise NotImplementedError(f"HipRecModel lives on {self.device} as {self.dtype}; create a new predictor for "
+                                      f"{device_dtype} (the HIP handle owns device memory; there is no CPU path)")
+        return self
+
+    def eval(self):
+        return self
 
     @property
     def _stream(self):

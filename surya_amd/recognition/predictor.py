@@ -7,7 +7,10 @@ Same call signature, class attributes and output schema as the reference
   * prompts are pre-processed once up front (thread pool) and their tiles stay resident in HBM;
   * the continuous-batching policy is the reference's (:539-599: prefill when more than `min_prefill_ratio` of the
     slots are empty, same stop rules), but decode runs `RECOGNITION_STEPS_PER_SYNC` device-resident steps per host
-    round trip. Per-line outputs do not depend on batch composition, so the emitted tokens are the same.
+    round trip. Per-line outputs do not depend on batch composition MATHEMATICALLY (attention and positions are
+    per-sequence); in fp32 mode the emitted tokens are bit-identical to the oracle's. In bf16 the GEMM tile / split-K
+    choice depends on the number of active rows, so a near-tie argmax can flip between batch sizes (bounded in
+    tests/test_gpu_fullsize.py); for a fixed slot count results are bit-reproducible whatever the host pacing.
 There is no CPU fallback: without the HIP library and a GPU, construction raises.
 """
 from __future__ import annotations
@@ -101,27 +104,43 @@ class RecognitionModelLoader(ModelLoader):
                 raw = json.load(f)
             self._cfg = rec_config_from_reference_json(raw)
             self._special_tokens = raw.get("special_ocr_tokens")
-            self._sd = {}
+            self._sd = None if self._receives_weights() else {}
             for fn in sorted(os.listdir(ck)):
-                if fn.endswith(".safetensors"):
+                if fn.endswith(".safetensors") and self._sd is not None:
                     self._sd.update(load_file(os.path.join(ck, fn)))
         else:
             from ..synth import make_rec_weights
             self._cfg = rec_config(ck if isinstance(ck, str) else settings.SURYA_AMD_REC_CONFIG)
-            self._sd = make_rec_weights(self._cfg, 0)
+            self._sd = None if self._receives_weights() else make_rec_weights(self._cfg, 0)
+
+    @staticmethod
+    def _receives_weights() -> bool:
+        """SURYA_AMD_BROADCAST_WEIGHTS with an initialised process group: only rank 0 reads / builds the state dict."""
+        if not settings.SURYA_AMD_BROADCAST_WEIGHTS:
+            return False
+        from .. import dist as sdist
+        rank, world = sdist.world_info()
+        return world > 1 and rank != 0
 
     def tokenizer(self) -> OCRTokenizer:
         self._resolve()
-        math_tok = None
         if isinstance(self.checkpoint, str) and os.path.isdir(self.checkpoint):
-            try:
-                from transformers import Qwen2Tokenizer
-                math_tok = Qwen2Tokenizer.from_pretrained(self.checkpoint)
-            except Exception:
-                math_tok = None
-        if math_tok is None:
-            math_tok = ByteMathTokenizer(self._cfg.qwen_offset)
-        return OCRTokenizer(self._special_tokens, math_tok, reserve_special=self._cfg.num_special_tokens)
+            # Real checkpoint: the id layout is DEFINED by the files (processor/tokenizer.py:224-260) -- the Qwen2 BPE that
+            # ships with it sets qwen_offset, special_ocr_tokens["all"] sets the tag range, exactly len(unique tags) wide.
+            # No placeholder tags, no byte-tokenizer stand-in: either would shift every UTF-16 id silently.
+            from transformers import Qwen2Tokenizer
+            math_tok = Qwen2Tokenizer.from_pretrained(self.checkpoint)      # raises if the vocabulary files are missing
+            if not self._special_tokens or not self._special_tokens.get("all"):
+                raise ValueError(f"{self.checkpoint}/config.json has no special_ocr_tokens; cannot lay out token ids")
+            tok = OCRTokenizer(self._special_tokens, math_tok, reserve_special=0)
+            if tok.vocab_size != self._cfg.decoder.vocab_size:
+                raise ValueError(f"token-id layout mismatch: qwen_offset {tok.qwen_offset} + {tok.num_special} tags + 65536 "
+                                 f"UTF-16 units = {tok.vocab_size}, but decoder.vocab_size = {self._cfg.decoder.vocab_size}")
+            return tok
+        # synthetic configs only: one id per UTF-8 byte stands in for the BPE, and the tag range is padded to the
+        # config's fixed width (a randomly initialised model can emit any id)
+        return OCRTokenizer(self._special_tokens, ByteMathTokenizer(self._cfg.qwen_offset),
+                            reserve_special=self._cfg.num_special_tokens)
 
     def model(self, device=None, dtype=None, **caps) -> HipRecModel:
         self._resolve()
@@ -135,6 +154,9 @@ class RecognitionModelLoader(ModelLoader):
         sysm = tok.system_tokens
         caps.setdefault("max_slots", settings.RECOGNITION_BATCH_SIZE or RecognitionPredictor.default_batch_sizes["cuda"])
         caps.setdefault("max_kv_len", 1536 + 32)
+        if settings.SURYA_AMD_BROADCAST_WEIGHTS:
+            from .. import dist as sdist
+            caps.setdefault("broadcast_weights", sdist.world_info()[1] > 1)
         return HipRecModel(self._cfg, self._sd, image_token_id=sysm["<IMAGE>"], pad_token_id=sysm["<PAD>"],
                            eos_token_id=sysm["</S>"], dtype=dtype, device=device, **caps)
 
@@ -183,6 +205,11 @@ class RecognitionPredictor(BasePredictor):
         TaskNames.ocr_without_boxes: {"needs_bboxes": False, "img_size": (1024, 256), "max_tokens": 224},
         TaskNames.block_without_boxes: {"needs_bboxes": False, "img_size": (1024, 512), "max_tokens": 768},
     }
+
+    # Multi-GPU: when set, ONE call's lines are dealt over the ranks of `process_group` (default group if
+    # None) and the results all-gathered; every rank must pass the same inputs (checked). Off by default.
+    shard_lines: bool = settings.SURYA_AMD_SHARD
+    process_group = None
 
     def __init__(self, checkpoint=None, device=None, dtype=None):
         super().__init__(checkpoint, device, dtype)
@@ -413,13 +440,22 @@ class RecognitionPredictor(BasePredictor):
         return self.generate(self.prepare_lines(flat, math_mode), recognition_batch_size)
 
     def sharded_prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:
-        """One process per GPU (torch.distributed initialised by the caller, e.g. torchrun): every rank holds the same
-        width-sorted line list, recognises the lines dealt to it round-robin and all ranks get all results back through
-        ONE all_gather (surya_amd/dist.py). No collective touches the per-step data path. Single process: plain loop."""
+        """One process per GPU (torch.distributed initialised by the caller, e.g. torchrun), used when `shard_lines` is set:
+        every rank holds the same width-sorted line list (verified with a fingerprint all_gather), pre-processes and
+        recognises only the lines dealt to it round-robin, and all ranks get all results back through ONE all_gather
+        (surya_amd/dist.py). No collective touches the per-step data path. Single process: plain loop."""
         from .. import dist as sdist
-        rank, world = sdist.world_info()
+        import zlib
+        group = self.process_group
+        rank, world = sdist.world_info(group)
         n = len(flat["slices"])
-        if world == 1 or n == 0:
+        if world == 1:
+            return self.prediction_loop(flat, recognition_batch_size, math_mode)
+        dev = sdist.collective_device(self.model.device, group)
+        shapes = np.asarray([s.shape[:2] for s in flat["slices"]], np.int64).reshape(-1, 2)
+        probe = b"".join(np.ascontiguousarray(flat["slices"][i]).tobytes()[:4096] for i in range(0, n, max(1, n // 16)))
+        sdist.assert_same_inputs([n, zlib.crc32(shapes.tobytes()), zlib.crc32(probe)], group, dev)
+        if n == 0:
             return self.prediction_loop(flat, recognition_batch_size, math_mode)
         mine = sdist.shard_indices(n, world, rank)
         local = {k: [flat[k][i] for i in mine] for k in ("slices", "input_text", "task_names")}
@@ -431,7 +467,7 @@ class RecognitionPredictor(BasePredictor):
                 boxes = np.pad(boxes, ((0, 0), (0, max_tokens - boxes.shape[1]), (0, 0)))
         else:
             toks, scores, boxes = [], [], np.zeros((0, max_tokens, 6), np.float32)
-        toks, scores, boxes = sdist.gather_line_outputs(toks, scores, boxes, mine, n, max_tokens, device=self.model.device)
+        toks, scores, boxes = sdist.gather_line_outputs(toks, scores, boxes, mine, n, max_tokens, device=dev, group=group)
         return toks, torch.from_numpy(boxes), scores
 
     # ------------------------------------------------------------------------------------- output assembly
@@ -519,7 +555,8 @@ class RecognitionPredictor(BasePredictor):
         for key in ("slices", "input_text", "task_names"):
             flat[key] = [flat[key][i] for i in order]
 
-        predicted_tokens, batch_bboxes, scores = self.sharded_prediction_loop(flat, recognition_batch_size, math_mode)
+        loop = self.sharded_prediction_loop if self.shard_lines else self.prediction_loop
+        predicted_tokens, batch_bboxes, scores = loop(flat, recognition_batch_size, math_mode)
         bbox_size = self.model.cfg.bbox_size
         sizes = [img.shape for img in flat["slices"]]
         polys = prediction_to_polygon_batch(batch_bboxes.numpy(), sizes, bbox_size, bbox_size // 2)

@@ -96,7 +96,13 @@ class OCRTokenizer:
                 continue
             if in_math:
                 end = text.find("</math>")
-                span = text[:end]              # end == -1 drops the last char, exactly like the reference (:99-101)
+                if end < 0:
+                    # unterminated <math>: the whole remainder is math. The reference slices text[:-1] / text[-1:] here
+                    # (:99-101) and never terminates; a hang in the pre-processing pool is not behaviour worth keeping.
+                    out += self.math_tokenizer(text)["input_ids"]
+                    text = ""
+                    continue
+                span = text[:end]
                 out += self.math_tokenizer(span)["input_ids"]
                 text = text[end:]
                 continue

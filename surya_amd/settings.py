@@ -44,6 +44,12 @@ class Settings:
         # this implementation only
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
+        # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the
+        # same inputs). Off by default: the reference has no collectives, and a torchrun job where every rank OCRs its own
+        # pages must not meet one.
+        self.SURYA_AMD_SHARD: bool = _env("SURYA_AMD_SHARD", bool, False)
+        # rank 0 repacks the weights, the other ranks receive them through one bucketed RCCL broadcast at construction
+        self.SURYA_AMD_BROADCAST_WEIGHTS: bool = _env("SURYA_AMD_BROADCAST_WEIGHTS", bool, False)
         self.SURYA_AMD_REC_CONFIG: str = _env("SURYA_AMD_REC_CONFIG", str, "REC-FULL")
         self.SURYA_AMD_DET_CONFIG: str = _env("SURYA_AMD_DET_CONFIG", str, "DET-DEFAULT")
 

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the N>1 path (sharding, output all_gather, weight broadcast) without GPUs.
-A deterministic stand-in plays the per-rank recogniser; the contract checked is the one of SURVEY 8(e):
-outputs of 2 ranks == outputs of 1 rank for any sharding."""
+The contract checked is the one of SURVEY 8(e): outputs of 2 ranks == outputs of 1 rank for any sharding -- first on the
+collective helpers alone, then on the PRODUCT code path: RecognitionPredictor.sharded_prediction_loop (the real device
+loop, stop rules, shard deal and gather) driven by the scripted fake model of tests/test_scheduler_cpu.py."""
 import os
 import socket
 
@@ -37,6 +38,21 @@ def _worker(rank, world, port, max_tokens, q):
         out.append(sd.gather_line_outputs([l[0] for l in lines], [l[1] for l in lines], bbs, idx, n, max_tokens))
     w = [torch.full((5, 3), float(rank + 1)), torch.arange(7, dtype=torch.int32) * (rank + 1), torch.full((2,), 9.0 * (rank + 1))]
     sd.broadcast_tensors(w, src=0, bucket_bytes=32)           # tiny buckets: exercises the bucketing
+    # start-up weight distribution: only rank 0 holds the repacked list, the others learn shapes from the manifest
+    mine = [torch.arange(12, dtype=torch.float32).reshape(3, 4), torch.ones(5, dtype=torch.bfloat16) * 3] if rank == 0 else None
+    shared = sd.share_weights(mine, "cpu", src=0, bucket_bytes=16)
+    assert [tuple(t.shape) for t in shared] == [(3, 4), (5,)] and shared[1].dtype == torch.bfloat16
+    assert shared[0].flatten().tolist() == list(range(12)) and shared[1].float().tolist() == [3.0] * 5
+    # per-page objects (detection results) come back in global order on every rank
+    objs = sd.gather_objects([{"page": i} for i in sd.shard_indices(5, world, rank)], sd.shard_indices(5, world, rank), 5)
+    assert objs == [{"page": i} for i in range(5)]
+    # ranks that were handed different inputs must fail loudly on EVERY rank, not hang in a mis-sized gather
+    try:
+        sd.assert_same_inputs([7, 1234 + rank, 0])
+        raise AssertionError("fingerprint mismatch went unnoticed")
+    except RuntimeError as e:
+        assert "different inputs" in str(e)
+    sd.assert_same_inputs([7, 1234, 0])
     q.put((rank, out, [t.tolist() for t in w]))
     dist.barrier()
     dist.destroy_process_group()
@@ -72,3 +88,70 @@ def test_shard_is_a_partition():
             parts = [sd.shard_indices(n, world, r) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ------------------------------------------------------------------ the product's sharded loop on two ranks
+def _loop_worker(rank, world, port, n_lines, max_tokens, slots, q):
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_scheduler_cpu as ts
+    from surya_amd.recognition.predictor import RecognitionPrompt
+    from surya_amd.settings import settings
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    settings.RECOGNITION_MAX_TOKENS = max_tokens
+    pred, _ = ts.make(1, max_tokens, slots)
+    pred.model.device = torch.device("cpu")
+    pred.process_group = None
+
+    def prepare_lines(flat, math_mode=True):
+        """Stand-in for the host pre-processing (needs no tokenizer / GPU upload): line id = pixel value of the crop."""
+        ids = [int(s[0, 0, 0]) for s in flat["slices"]]
+        grids = [(2, 2 + 2 * (i % 3)) for i in ids]
+        offs = np.cumsum([0] + [h * w for h, w in grids])
+        tiles = np.zeros((offs[-1], 3), np.float32)
+        for k, i in enumerate(ids):
+            tiles[offs[k]:offs[k + 1], 0] = i
+        return {"prompts": [RecognitionPrompt(k, "ocr_with_boxes", None, None, True) for k in range(len(ids))],
+                "max_tokens": {k: max_tokens for k in range(len(ids))}, "tiles": tiles, "tile_offs": offs, "grids": grids,
+                "prompt_ids": [[1000 + i, 5, 6] for i in ids]}
+
+    pred.prepare_lines = prepare_lines
+    widths = [40 + (i * 7) % 23 for i in range(n_lines)]
+    flat = {"slices": [np.full((8, w, 3), i, np.float32) for i, w in enumerate(widths)], "input_text": [None] * n_lines,
+            "task_names": ["ocr_with_boxes"] * n_lines}
+    toks, boxes, scores = pred.sharded_prediction_loop(flat, slots, True)
+    q.put((rank, toks, boxes.numpy().copy(), scores))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_lines,slots", [(23, 4), (1, 3)])
+def test_sharded_prediction_loop_two_ranks_equal_one(n_lines, slots):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_scheduler_cpu as ts
+    max_tokens = 12
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, n_lines, max_tokens, slots, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, toks, boxes, scores in results:
+        assert len(toks) == n_lines and boxes.shape[0] == n_lines
+        for i in range(n_lines):
+            exp = ts.expected(i, max_tokens)
+            assert toks[i] == exp, (rank, i, toks[i], exp)
+            assert len(scores[i]) == len(exp)
+            assert (boxes[i, :len(exp), 0] == i).all()            # every gathered box row belongs to the right line
+    assert results[0][1] == results[1][1] and np.array_equal(results[0][2], results[1][2])

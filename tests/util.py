@@ -40,3 +40,23 @@ def left_pad_batch(cfg: RecConfig, seqs):
     pos[pos < 0] = 0
     pos = am.long() * pos
     return ids, am.long(), pos
+
+
+def bench_line_inputs(cfg: RecConfig, n: int, seed: int = 1234, pick=None, task: str = "ocr_with_boxes"):
+    """The boundary tensors bench.py feeds the device loop, built on the host without a GPU: surya_amd.synth.make_line_crops
+    (widest first, as RecognitionPredictor orders them) -> scale_to_fit -> SuryaOCRProcessor. Returns
+    (tiles [sum P, 588] fp32 CPU, grids [(gh, gw)], prompt ids) for the lines in `pick` (default: all)."""
+    from surya_amd.recognition.predictor import RecognitionModelLoader, RecognitionPredictor
+    from surya_amd.synth import make_line_crops
+    proc = RecognitionModelLoader({"config": cfg, "state_dict": {}}).processor()
+    crops = make_line_crops(n, seed=seed)
+    crops.sort(key=lambda c: -c.shape[1])
+    pick = list(range(n)) if pick is None else list(pick)
+    size = RecognitionPredictor.tasks[task]["img_size"]
+    tiles, grids, seqs = [], [], []
+    for i in pick:
+        img = proc.scale_to_fit(crops[i].astype(np.float32), size)
+        out = proc([{"task": task, "inputs": [{"type": "image", "image": img, "rotated": False},
+                                              {"type": "text", "text": "", "math": True}]}])
+        tiles.append(out["image_tiles"]); grids.append(tuple(int(x) for x in out["grid_hw"][0])); seqs.append(out["input_ids"][0])
+    return torch.from_numpy(np.concatenate(tiles, 0)), grids, seqs
