@@ -221,6 +221,10 @@ int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float*
  * (2MNK; X + W + C (+R) once each). Arrays need >= 4 entries. Not for use inside timed regions.
  * ---------------------------------------------------------------------------------------------------------- */
 int surya_prof_enable(int on);
+/* Launch-policy knob for A/B measurements inside one process (tools/microbench/decode_sweep.py; keys = the fields of
+ * sa::Tuning in csrc/common.h: "graph", "dual", "split_tile", "gu_tile", ...). Process-wide; results never depend on it
+ * beyond fp rounding order. Returns SA_ERR_ARG for an unknown key. */
+int surya_set_tuning(const char* key, int value);
 int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes);
 /* Median event-pair time (ms) around an empty kernel on `stream`: the fixed cost inside every per-launch figure above. */
 int surya_prof_event_overhead(void* stream, double* ms);

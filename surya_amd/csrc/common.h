@@ -116,6 +116,38 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
 
+// Launch-policy knobs, in ONE place. Defaults are the measured best; surya_set_tuning(key, value) changes
+// them at run time for A/B sweeps inside one process (tools/microbench/decode_sweep.py). Nothing in a launch path reads the
+// environment.
+struct Tuning {
+    int graph = 0;           // decode steps as hipGraph replays (1) or plain launches (0)
+    int dual = 0;            // decode the active rows as two half-batches on two streams (rows >= dual_min)
+    int dual_min = 128;
+    int split_tile = 0;      // decode split-K projections: 0 = 64x64 ring-4, 1 = 128x64, 2 = 128x128
+    int split_target = 256;  // aim at this many workgroups
+    int split_min_kt = 4;    // at least this many 128-byte K-tiles per slice
+    int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
+    int gu_tile = 0;         // decode gate|up (M in (128, 256]): 0 = 64x64, 1 = 128x64, 2 = 128x128
+    int head_tile = 0;       // lm_head at decode: 0 = 128x128, 1 = 256x128
+    int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
+    int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)
+};
+inline Tuning& tuning() { static Tuning t; return t; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember it per device, not per process.
+struct AttrOnce {
+    unsigned long long done = 0;
+    template <typename F> void ensure(F kern, size_t lds) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done |= bit;
+        }
+    }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 

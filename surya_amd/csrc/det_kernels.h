@@ -227,11 +227,8 @@ static inline int launch_conv_cfg(const ConvArgs<T>& a, hipStream_t s) {
     const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
     constexpr size_t lds = (size_t)(BM + BN) * 128 * 2;
     auto kern = conv_gemm_kernel<T, BM, BN, WM, WN, CIN64>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static AttrOnce attr;
+    attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
     const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
     if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
@@ -262,42 +259,6 @@ static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 // Depthwise KxK convolution (NHWC), bias + activation. One thread = one output pixel x 8/4 channels (16 bytes).
 // HBM-bound: reads K*K input vectors per output vector (neighbours hit L1/L2).
-template <typename T>
-__global__ void dwconv_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ out,
-                              int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int act) {
-    constexpr int V = Ty<T>::V16;
-    const int cv = C / V;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)B * Ho * Wo * cv) return;
-    const int c0 = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
-    float acc[V];
-    if (bias) unpack16(*reinterpret_cast<const uint4*>(bias + c0), acc, (T*)nullptr);
-    else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] = 0.f;
-    }
-    for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * stride + ky - pad;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < K; ++kx) {
-            const int ix = ox * stride + kx - pad;
-            if (ix < 0 || ix >= W) continue;
-            float xv[V], wv[V];
-            unpack16(*reinterpret_cast<const uint4*>(in + (((long)b * H + iy) * W + ix) * C + c0), xv, (T*)nullptr);
-            unpack16(*reinterpret_cast<const uint4*>(w + (long)(ky * K + kx) * C + c0), wv, (T*)nullptr);   // weights [K*K][C]
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] += xv[i] * wv[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = act == ACT_HSWISH ? hardswish_f(acc[i]) : (act == ACT_RELU ? fmaxf(acc[i], 0.f) : acc[i]);
-    T* o = out + pix * C + c0;
-#pragma unroll
-    for (int i = 0; i < V; i += 4) store4(o + i, acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
-}
-
 // Register-blocked variant for the shapes the detector uses (K = 3 / 5, stride 1 / 2): one thread = TX consecutive output
 // pixels of a row x 16 bytes of channels. The plain kernel above reads every input vector K*K times through L1/L2 (the
 // L2->CU path, not HBM, was its limit: 142 us average per launch in the r01 profile); here a loaded input column serves

@@ -86,21 +86,17 @@ struct DetModel : DetBase {
                     break;
                 }
                 case SA_DET_DWCONV: {
-                    static const bool dw_plain = [] { const char* e = getenv("SURYA_AMD_DWCONV"); return e && e[0] == '0'; }();
                     constexpr int TX = 4;
                     const long nt = (long)B * op.hout * cdiv(op.wout, TX) * (op.cin / Ty<T>::V16);
 #define SA_DWTX(KK, SS)                                                                                                     \
     hipLaunchKernelGGL((dwconv_tx_kernel<T, KK, SS, TX>), dim3((unsigned)cdivl(nt, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx), \
                        WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.p0, op.act)
-                    if (!dw_plain && op.k == 3 && op.stride == 1) { SA_DWTX(3, 1); break; }
-                    if (!dw_plain && op.k == 3 && op.stride == 2) { SA_DWTX(3, 2); break; }
-                    if (!dw_plain && op.k == 5 && op.stride == 1) { SA_DWTX(5, 1); break; }
-                    if (!dw_plain && op.k == 5 && op.stride == 2) { SA_DWTX(5, 2); break; }
+                    if (op.k == 3 && op.stride == 1) SA_DWTX(3, 1);
+                    else if (op.k == 3 && op.stride == 2) SA_DWTX(3, 2);
+                    else if (op.k == 5 && op.stride == 1) SA_DWTX(5, 1);
+                    else if (op.k == 5 && op.stride == 2) SA_DWTX(5, 2);
+                    else return SA_ERR_UNSUPPORTED;         // EfficientViT-L uses 3x3 (s1, s2) and 5x5 (s1) depthwise convs only
 #undef SA_DWTX
-                    const long n = (long)B * op.hout * op.wout * (op.cin / Ty<T>::V16);
-                    hipLaunchKernelGGL(dwconv_kernel<T>, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx),
-                                       WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.k, op.stride, op.p0,
-                                       op.act);
                     break;
                 }
                 case SA_DET_GROUPED1X1: {

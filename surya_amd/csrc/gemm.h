@@ -554,11 +554,8 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
     constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
     auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS>;
-    static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static AttrOnce attr;           // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
+    attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
     const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
     if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
@@ -589,24 +586,18 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     if (a.M <= 256) {
         if (a.M > 128) {
-            static const int force_bn = [] { const char* e = getenv("SURYA_AMD_TALL_BN"); return e ? atoi(e) : 0; }();
-            if (force_bn == 6464) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);          // experiments (tools/microbench)
-            if (force_bn == 12864) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
-            if (force_bn == 128128) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI>(a, s);
-            // S0xxxxx: direct-to-LDS variants with S stages
-            if (force_bn == 4006464) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 4>(a, s);
-            if (!force_bn) {
-                // measured at M = 256 (tools/microbench/gemm_shapes.py): lm_head-sized N -> 128x64 tiles; everything else -> 64x64
-                // direct-to-LDS variants: gate|up 15.5 us vs 18.4 with register staging, lm_head 82.6 us vs 88.3
-                // (a 256x128 tile for lm_head -- every weight byte streamed once instead of twice -- was measured: 95.6 vs 93.4 ms
-                // per recognition step, one workgroup per CU hides less latency than two 128x128 ones)
-                if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
-                return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
+            // measured at M = 256 (tools/microbench/gemm_shapes.py, decode_sweep.py): lm_head-sized N -> 128x128 tiles; the rest
+            // 64x64 (r01) or 128x64 / 128x128 (fewer L2->CU requests per MAC: 64x64 asks for 210 MB per gate|up launch, 128x64
+            // for 157 MB, 128x128 for 105 MB, against a ~15 TB/s ceiling), all direct-to-LDS
+            if (a.N >= 64 * 512) {
+                if constexpr (EPI == EPI_ARGMAX) {
+                    if (tuning().head_tile == 1) return launch_gemm_cfg<TI, TO, 256, 128, 4, 2, EPI, false, 2>(a, s);
+                }
+                return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
             }
-            const int bn = force_bn;
-            if (bn == 128) return launch_gemm_cfg<TI, TO, 256, 128, 8, 1, EPI>(a, s);
-            if (bn == 64) return launch_gemm_cfg<TI, TO, 256, 64, 8, 1, EPI>(a, s);
-            return launch_gemm_cfg<TI, TO, 256, 32, 8, 1, EPI>(a, s);
+            if (tuning().gu_tile == 2 && a.N >= 128 * 64) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
+            if (tuning().gu_tile == 1 && a.N >= 64 * 64) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI, false, 2>(a, s);
+            return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
         }
         if (a.M > 64) {
             if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);
@@ -617,12 +608,12 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    static const int glds = [] { const char* e = getenv("SURYA_AMD_GLDS"); return e ? atoi(e) : 2; }();
+    const int glds = tuning().glds;
     if constexpr (sizeof(TO) == 2) {
         // 256x256 tiles (8 waves, 64x128 per wave): the 128x128 tile requests 2/128 bytes per MAC row/column pair from L2 and
         // saturates the L2->CU path at ~15 TB/s (= the same ceiling a load-only kernel reaches, tools/microbench/wstream.hip),
         // which caps it near 64 flop/B x 15 TB/s ~ 0.95 PF/s; doubling both tile edges halves that traffic.
-        static const int bigtile = [] { const char* e = getenv("SURYA_AMD_BIGTILE"); return e ? atoi(e) : 1; }();
+        const int bigtile = tuning().bigtile;
         // pick by whole rounds of resident workgroups (256 x 1 per CU vs 512 x 2 per CU, in units of 128x128 tiles of work);
         // measured throughput ratio of the two kernels on full rounds ~1.17 (r01 microbench)
         const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
@@ -640,10 +631,11 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
 // Split-K launch for the decode regime (M <= 256, small N): tiles x splitk workgroups so a skinny GEMM still covers the
 // chip; raw fp32 partial sums go to a.part[splitk][M][N] and the NEXT kernel combines them (launch-boundary reduce).
 // Returns the slice count actually used through a.splitk (caller passes the same struct to the consumer).
-static inline int pick_splitk(int tiles, int nk, int target) {
-    int s = (target + tiles / 2) / tiles;          // aim at ~target workgroups
-    s = std::min(s, nk / 4);                       // keep >= 4 K-tiles per slice (pipeline fill)
-    return std::max(s, 1);
+static inline int pick_splitk(int tiles, int nk) {
+    const Tuning& t = tuning();
+    int s = (t.split_target + tiles / 2) / tiles;          // aim at ~target workgroups
+    s = std::min(s, nk / std::max(1, t.split_min_kt));    // keep enough K-tiles per slice to fill the pipeline
+    return std::max(1, std::min(s, std::min(t.split_max, 8)));      // consumers hold <= 8 slabs in flight
 }
 
 template <typename TI>
@@ -651,25 +643,20 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
     if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || !a.part) return SA_ERR_SHAPE;
     const int nk = a.K / Ty<TI>::KE;
-    // 64x64 tiles (4 M-tiles at M = 256) beat the tall 256-row tiles for these skinny projections: many light
-    // workgroups hide the per-iteration load latency better than few heavy ones (tools/microbench/gemm_shapes.py:
-    // unsplit 64x64 11 us vs tall 16 us for qkv at M = 256). Default: 64x64 with a 4-stage direct-to-LDS ring
-    // (mode 4006464) and ~256 workgroups; the other modes are kept for A/B runs.
-    static const int mode = [] { const char* e = getenv("SURYA_AMD_SPLIT_TILE"); return e ? atoi(e) : 4006464; }();
-    static const int target = [] { const char* e = getenv("SURYA_AMD_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
-    if (mode == 6464) {
-        a.splitk = std::min(pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk, target), 8);
-        return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true>(a, s);
+    // r01: 64x64 tiles with a 4-stage direct-to-LDS ring. r02: 128x64 / 128x128 tiles ask L2 for half / a quarter of the bytes
+    // per MAC (the 64x64 launches sat at the ~15 TB/s L2->CU request ceiling); fewer output tiles are made
+    // up for with more K slices. Small M keeps 64-row tiles.
+    const int mode = a.M > 64 ? tuning().split_tile : 0;
+    if (mode == 2) {
+        a.splitk = pick_splitk(cdiv(a.N, 128) * cdiv(a.M, 128), nk);
+        return launch_gemm_cfg<TI, TI, 128, 128, 2, 2, EPI_BIAS, true, 2>(a, s);
     }
-    if (mode == 2006464 || mode == 4006464) {
-        a.splitk = std::min(pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk, target), 8);
-        return mode == 2006464 ? launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 2>(a, s)
-                               : launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
+    if (mode == 1) {
+        a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 128), nk);
+        return launch_gemm_cfg<TI, TI, 128, 64, 4, 1, EPI_BIAS, true, 3>(a, s);
     }
-    a.splitk = std::min(pick_splitk(cdiv(a.N, 32) * cdiv(a.M, 256), nk, target / 2), 8);
-    if (a.M > 128) return launch_gemm_cfg<TI, TI, 256, 32, 8, 1, EPI_BIAS, true>(a, s);
-    if (a.M > 64) return launch_gemm_cfg<TI, TI, 128, 32, 4, 1, EPI_BIAS, true>(a, s);
-    return launch_gemm_cfg<TI, TI, 64, 32, 2, 1, EPI_BIAS, true>(a, s);
+    a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk);
+    return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
 }
 
 }  // namespace sa

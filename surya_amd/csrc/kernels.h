@@ -232,17 +232,6 @@ __global__ void embed_tokens_kernel(const T* __restrict__ table, const int* __re
     for (int c = threadIdx.x; c < H / Ty<T>::V16; c += blockDim.x) dst[c] = src[c];
 }
 
-// Decode-step embedding: x[a] = table[next_token[active_slots[a]]].
-template <typename T>
-__global__ void embed_slots_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
-                                   const int* __restrict__ active_slots, T* __restrict__ x, int H) {
-    const int a = blockIdx.x;
-    const int id = next_token[active_slots[a]];
-    const uint4* src = reinterpret_cast<const uint4*>(table + (long)id * H);
-    uint4* dst = reinterpret_cast<uint4*>(x + (long)a * H);
-    for (int c = threadIdx.x; c < H / Ty<T>::V16; c += blockDim.x) dst[c] = src[c];
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Decoder RoPE table, built once per model: (cos, sin)(pos * inv_freq[i]) in fp32, then rounded to the storage type
 // exactly where the reference rounds them (Qwen2RotaryEmbedding.forward, decoder/__init__.py:346-361).
@@ -290,224 +279,6 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Decode step attention, one workgroup per (active slot, kv head): RoPE of the new q/k, KV append and
-// single-query GQA attention over the slot's cache in one launch. 16 lanes share a key (16-byte slices of the
-// head dim, coalesced 256-byte rows for D=128 bf16), 16 keys in flight per workgroup, partial softmax states
-// merged through LDS. Replaces cache concat + 4-D mask + SDPA (decoder/__init__.py:193-234, cache.py:57-105).
-// The q/k/v row comes either from a finished qkv buffer or, after a split-K projection, from the fp32 partial slabs
-// (qkv_part[S][M][qkv_dim], summed here with the bias: the launch-boundary reduce of the split-K GEMM).
-// RoPE factors come from a table built once per model: rope_cs[pos][i] = (cos, sin) of pos * inv_freq[i], already rounded
-// to the storage type as the reference does (decoder/__init__.py:361) -- no per-step sincosf.
-template <typename T, int EPL>
-struct RawSlice {                                   // EPL contiguous elements of one K/V row, kept packed in registers
-    static constexpr int NW = (EPL * (int)sizeof(T) + 3) / 4;
-    unsigned int w[NW];
-    __device__ __forceinline__ void load(const T* p) {
-        if constexpr (NW % 4 == 0) {
-#pragma unroll
-            for (int c = 0; c < NW / 4; ++c) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p) + c * 16);
-                w[c * 4] = v[0]; w[c * 4 + 1] = v[1]; w[c * 4 + 2] = v[2]; w[c * 4 + 3] = v[3];
-            }
-        } else if constexpr (NW == 2) {
-            const uint2 v = *reinterpret_cast<const uint2*>(p);
-            w[0] = v.x; w[1] = v.y;
-        } else {
-#pragma unroll
-            for (int c = 0; c < NW; ++c) w[c] = reinterpret_cast<const unsigned int*>(p)[c];
-        }
-    }
-    __device__ __forceinline__ float get(int i) const {          // i is a compile-time constant after unrolling
-        if constexpr (sizeof(T) == 4) return __uint_as_float(w[i]);
-        else return (i & 1) ? __uint_as_float(w[i >> 1] & 0xffff0000u) : __uint_as_float(w[i >> 1] << 16);
-    }
-};
-
-template <typename T, int D, int MAXG>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_part, int S,
-                                                          const T* __restrict__ qkv_bias, T* __restrict__ out,
-                                                          T* __restrict__ kc, T* __restrict__ vc,
-                                                          const int* __restrict__ active_slots, const int* __restrict__ row_len,
-                                                          const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
-                                                          float scale) {
-    constexpr int EPL = D / 16;                 // head-dim elements per lane
-    constexpr int UN = 8;                       // keys per key-group loaded ahead: 128 cached keys in flight per workgroup
-    const int G = nq / nkv;
-    const int a = blockIdx.x, kvh = blockIdx.y;
-    const int slot = active_slots[a];
-    const int len = row_len[a];                 // cached tokens before this step == RoPE position of the new token
-    const int tid = threadIdx.x, kg = tid >> 4, e = tid & 15;
-    __shared__ float qs[MAXG * D];
-    __shared__ float knew[D], vnew[D];
-    __shared__ float mg[4 * MAXG], lg[4 * MAXG];
-    __shared__ float accs[4 * MAXG * D];
-    const T* kb = kc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
-    const T* vb = vc + ((long)slot * nkv + kvh) * Tmax * D + e * EPL;
-    // Cached K/V rows do not depend on this step's projections: start fetching the first UN keys of every key group
-    // BEFORE the q/k/v prologue so their HBM latency overlaps it (the kernel is a chain of dependent memory round trips).
-    RawSlice<T, EPL> kr[UN], vr[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-        const int j = min(kg + 16 * u, max(len - 1, 0));          // clamped: rows >= len are never used
-        if (SA_DBG_VARIANT == 4) { kr[u].load(kb); vr[u].load(vb); continue; }
-        kr[u].load(kb + (long)j * D);
-        vr[u].load(vb + (long)j * D);
-    }
-    // This row's q heads (G), k head and v head of the fused qkv projection -> LDS `xrow` as floats. After a split-K
-    // projection they are the sum of S fp32 slabs + bias. Every load of this phase (all slabs of all of this thread's
-    // columns, the RoPE factors, and the K/V preload above) is issued before the first wait: written as loops with
-    // runtime bounds hipcc waits for each load in turn, and the kernel becomes ~8 dependent memory round trips.
-    const int qkv_dim = (nq + 2 * nkv) * D;
-    const int Mrows = gridDim.x;
-    const int half = D / 2;
-    __shared__ float xrow[(MAXG + 2) * D];
-    const float2 csn = rope_cs[(long)len * half + (tid % half)];     // it % half == tid % half for every item of a thread
-    constexpr int NI = ((MAXG + 2) * D + 255) / 256;
-    const int n_items = (G + 2) * D;
-    float p8[NI][8], bias_v[NI];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const int it = min(tid + k * 256, n_items - 1);      // clamped: out-of-range items reload the last one, unused
-        const int hh = it / D, i = it % D;                   // hh < G: q head; G: k head; G + 1: v head
-        const int col = (hh < G ? (kvh * G + hh) * D : (hh == G ? (nq + kvh) * D : (nq + nkv + kvh) * D)) + i;
-        if (qkv_part) {
-#pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx)             // slab index clamped too: no branches around the loads
-                p8[k][sidx] = (SA_DBG_VARIANT == 2) ? 0.f : qkv_part[((long)min(sidx, S - 1) * Mrows + a) * qkv_dim + col];
-            bias_v[k] = Ty<T>::ld(qkv_bias + col);
-        } else {
-#pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx) p8[k][sidx] = 0.f;
-            bias_v[k] = Ty<T>::ld(qkv + (long)a * qkv_dim + col);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        float val = bias_v[k];
-        if (qkv_part) {
-#pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx) val += (sidx < S) ? p8[k][sidx] : 0.f;
-            val = Ty<T>::rnd(val);
-        }
-        if (tid + k * 256 < n_items) xrow[tid + k * 256] = val;
-    }
-    __syncthreads();
-    for (int it = tid; it < (G + 1) * half; it += 256) {
-        const int i = it % half, hh = it / half;            // hh < G: q head of this group, hh == G: the k head
-        const float cs = csn.x, sn = csn.y;
-        const float x1 = xrow[hh * D + i], x2 = xrow[hh * D + i + half];
-        const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
-        if (hh < G) {
-            qs[hh * D + i] = y1 * scale; qs[hh * D + i + half] = y2 * scale;
-        } else {
-            knew[i] = y1; knew[i + half] = y2;
-            T* dst = kc + (((long)slot * nkv + kvh) * Tmax + len) * D;
-            Ty<T>::st(dst + i, y1); Ty<T>::st(dst + i + half, y2);
-        }
-    }
-    for (int i = tid; i < D; i += 256) {
-        const float val = xrow[(G + 1) * D + i];
-        vnew[i] = val;
-        Ty<T>::st(vc + (((long)slot * nkv + kvh) * Tmax + len) * D + i, val);
-    }
-    __syncthreads();
-    float qreg[MAXG][EPL], acc[MAXG][EPL], m[MAXG], l[MAXG];
-#pragma unroll
-    for (int h = 0; h < MAXG; ++h) {
-        m[h] = -INFINITY; l[h] = 0.f;
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) { acc[h][i] = 0.f; qreg[h][i] = (h < G) ? qs[h * D + e * EPL + i] : 0.f; }
-    }
-    auto accumulate = [&](const float (&kf)[EPL], const float (&vf)[EPL]) {
-#pragma unroll
-        for (int h = 0; h < MAXG; ++h) {
-            if (h < G) {
-                float d = 0.f;
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) d += qreg[h][i] * kf[i];
-                d = row16_sum(d);
-                const float mn = fmaxf(m[h], d);
-                const float al = __expf(m[h] - mn), pj = __expf(d - mn);
-                l[h] = l[h] * al + pj;
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) acc[h][i] = acc[h][i] * al + pj * vf[i];
-                m[h] = mn;
-            }
-        }
-    };
-    // cached keys [0, min(len, 16 * UN)) from the preloaded registers
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-        if (SA_DBG_VARIANT != 1 && kg + 16 * u < len) {                    // uniform within the 16 lanes of a key group
-            float kf[EPL], vf[EPL];
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) { kf[i] = kr[u].get(i); vf[i] = vr[u].get(i); }
-            accumulate(kf, vf);
-        }
-    }
-    // longer contexts: the remaining cached keys, UN/2 per group in flight
-    for (int j0 = kg + 16 * UN; j0 < len; j0 += 16 * (UN / 2)) {
-#pragma unroll
-        for (int u = 0; u < UN / 2; ++u) {
-            const int j = min(j0 + 16 * u, len - 1);
-            kr[u].load(kb + (long)j * D);
-            vr[u].load(vb + (long)j * D);
-        }
-#pragma unroll
-        for (int u = 0; u < UN / 2; ++u) {
-            if (j0 + 16 * u < len) {
-                float kf[EPL], vf[EPL];
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) { kf[i] = kr[u].get(i); vf[i] = vr[u].get(i); }
-                accumulate(kf, vf);
-            }
-        }
-    }
-    // the new token's key/value (position len) from LDS, taken by the key group it falls to
-    if ((len & 15) == kg) {
-        float kf[EPL], vf[EPL];
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) { kf[i] = knew[e * EPL + i]; vf[i] = vnew[e * EPL + i]; }
-        accumulate(kf, vf);
-    }
-    // merge the 4 key groups of each wave with shuffles, then the 4 waves through LDS
-    const int wave = tid >> 6;
-#pragma unroll
-    for (int h = 0; h < MAXG; ++h) {
-        if (h < G) {
-            float mw = fmaxf(m[h], __shfl_xor(m[h], 16, 64));
-            mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
-            const float w = (m[h] == -INFINITY) ? 0.f : __expf(m[h] - mw);
-            float lw = l[h] * w;
-            lw += __shfl_xor(lw, 16, 64); lw += __shfl_xor(lw, 32, 64);
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-                float av = acc[h][i] * w;
-                av += __shfl_xor(av, 16, 64); av += __shfl_xor(av, 32, 64);
-                if ((tid & 48) == 0) accs[(wave * MAXG + h) * D + e * EPL + i] = av;
-            }
-            if ((tid & 63) == 0) { mg[wave * MAXG + h] = mw; lg[wave * MAXG + h] = lw; }
-        }
-    }
-    __syncthreads();
-    for (int it = tid; it < G * D; it += 256) {
-        const int h = it / D, dd = it % D;
-        float M = -INFINITY;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) M = fmaxf(M, mg[g * MAXG + h]);
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float mgv = mg[g * MAXG + h];
-            const float w = (mgv == -INFINITY) ? 0.f : __expf(mgv - M);   // waves that saw no key
-            num += w * accs[(g * MAXG + h) * D + dd];
-            den += w * lg[g * MAXG + h];
-        }
-        Ty<T>::st(out + (long)a * nq * D + (long)(kvh * G + h) * D + dd, num / den);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Launch-boundary reduce of a split-K projection fused with the residual add and the NEXT RMSNorm:
 //   x <- T(x + bias + sum_s part[s])            (what the unsplit GEMM's EPI_RESIDUAL epilogue would have stored)
 //   y <- w * T(x * rsqrt(mean(x^2) + eps))      (Qwen2RMSNorm of the updated residual stream, optional)
@@ -534,7 +305,7 @@ __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float*
         load4(bias + cc, b);
         v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
     }
-    f32x4 p4[8];                                   // all slabs in flight at once (S <= 8), see decode_attn_kernel
+    f32x4 p4[8];                                   // slabs in flight
 #pragma unroll
     for (int s = 0; s < 8; ++s)                    // clamped slab index: unconditional loads, masked below
         p4[s] = *reinterpret_cast<const f32x4*>(part + ((long)min(s, S - 1) * M + row) * H + cc);

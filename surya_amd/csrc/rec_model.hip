@@ -177,7 +177,7 @@ struct RecModel : RecBase {
     float2* erope;           // [max_patches][enc head_dim / 2] (cos, sin) of the vision rotary embedding
     float4* amax;            // greedy-head partials of the lm_head GEMM: [slot row][column tile]
     float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
-    float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
+    float* part;                                         // split-K partial sums, per decode half: [2][8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
     int *kv_len, *next_token, *active_dev, *row_len;
     int* out_token; float* out_score; int* out_bbox;     // [SA_MAX_STEPS][max_slots] (bbox x6)
@@ -188,6 +188,8 @@ struct RecModel : RecBase {
     // hipGraph replay of decode steps: a step is ~113 short launches; captured once per (active rows, steps) and replayed
     // from an internal stream (capture is not allowed on the legacy default stream torch hands us).
     hipStream_t gstream = nullptr;
+    hipStream_t hstream = nullptr;                       // second decode half (Tuning::dual)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     hipEvent_t ev_ring[2] = {nullptr, nullptr};          // outputs of ring half r are in the pinned mirror
     std::map<long, hipGraphExec_t> graphs;
@@ -222,7 +224,7 @@ struct RecModel : RecBase {
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
         size_t o_amax = take(S * (size_t)cdiv(c.vocab, 32) * sizeof(float4));
         size_t o_rope = take((size_t)c.max_kv_len * (c.dec_head_dim / 2) * sizeof(float2));
-        size_t o_part = take((size_t)8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));
+        size_t o_part = take((size_t)2 * 8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));   // x2: decode halves
         const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
         size_t o_k = take(kv_elems * sizeof(T));
         size_t o_v = take(kv_elems * sizeof(T));
@@ -282,20 +284,25 @@ struct RecModel : RecBase {
             SA_HIP(hipEventCreateWithFlags(&ev_ahead_free, hipEventDisableTiming));
         }
         SA_HIP(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
+        SA_HIP(hipStreamCreateWithFlags(&hstream, hipStreamNonBlocking));
+        SA_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        SA_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         SA_HIP(hipEventCreateWithFlags(&gev_in, hipEventDisableTiming));
         SA_HIP(hipEventCreateWithFlags(&gev_out, hipEventDisableTiming));
         for (auto& e : ev_ring) SA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        // hipGraph replay of the decode steps is opt-in (SURYA_AMD_GRAPH=1): with the pipelined decode_async loop the host
+        // hipGraph replay of the decode steps is opt-in (surya_set_tuning("graph", 1)): with the pipelined decode_async loop the host
         // enqueues call n + 1 while call n runs, so plain launches never starve the GPU, and a graph launch of ~450 kernel
         // nodes starts later than the first eager launch does (r01: 101.1 ms/step with graphs, 96.2 ms without).
-        const char* ug = getenv("SURYA_AMD_GRAPH");
-        use_graph = (ug && ug[0] == '1');
+        use_graph = true;                                  // cleared for good if a capture fails
         SA_HIP(hipDeviceSynchronize());
         return SA_OK;
     }
     ~RecModel() override {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         if (gstream) (void)hipStreamDestroy(gstream);
+        if (hstream) (void)hipStreamDestroy(hstream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (gev_in) (void)hipEventDestroy(gev_in);
         if (gev_out) (void)hipEventDestroy(gev_out);
         for (auto e : ev_ring) if (e) (void)hipEventDestroy(e);
@@ -324,9 +331,8 @@ struct RecModel : RecBase {
         if (n_tiles <= 0) return SA_OK;
         dim3 grid(n_tiles, heads), block(256);
         if constexpr (std::is_same<T, bf16_t>::value) {
-            // bf16: matrix-core kernel (attn_mfma.h); SURYA_AMD_ATTN=valu keeps the vector-ALU kernel for A/B runs
-            static const bool valu = [] { const char* e = getenv("SURYA_AMD_ATTN"); return e && e[0] == 'v'; }();
-            if (!valu) {
+            // bf16: matrix-core kernel (attn_mfma.h); the vector-ALU kernel below is the fp32 reference-mode path
+            {
 #define SA_ATTN_M(DD)                                                                                                    \
     hipLaunchKernelGGL((attn_mfma_kernel<DD>), grid, dim3(128), 0, s, q, k, v, o, sg, q_row, q_head, k_row, k_head, o_row, \
                        o_head, group, causal, scale)
@@ -509,121 +515,114 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
-    int splitk_gemm(const T* X, long ldx, const T* Wt, long ldw, int M, int N, int K, int* S, hipStream_t s) {
-        GemmArgs<T, T> a{X, ldx, Wt, ldw, nullptr, 0, nullptr, nullptr, 0, M, N, K, 1, part};
+    int splitk_gemm(const T* X, long ldx, const T* Wt, long ldw, int M, int N, int K, float* part_, int* S, hipStream_t s) {
+        GemmArgs<T, T> a{X, ldx, Wt, ldw, nullptr, 0, nullptr, nullptr, 0, M, N, K, 1, part_};
         int rc = launch_gemm_splitk<T>(a, s);
         *S = a.splitk;
         return rc;
     }
-    int reduce_residual_norm(int S, int M, const T* wnorm, T* y, hipStream_t s) {
+    int reduce_residual_norm(int S, int M, const float* part_, T* x, const T* wnorm, T* y, hipStream_t s) {
         const int threads = cdiv(c.dec_hidden / 4, 64) * 64;         // one 4-element chunk per thread
         if (threads > 1024 || c.dec_hidden % 4) return SA_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(threads), 0, s, part, S, M, dx, (const T*)nullptr,
+        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr,
                            wnorm, y, c.dec_hidden, c.dec_eps);
         return (int)hipGetLastError();
     }
 
-    // One decode step for the M active slots. The three skinny projections (qkv, o, down) run split-K so they cover the
-    // chip; their partial sums are combined by the kernel that needs the result anyway: decode attention (qkv) and a
-    // fused residual-add + next-RMSNorm pass (o, down). Leaves the final-norm output of every row in `dlast`.
-    int decoder_layers_decode(int M, hipStream_t s) {
-        const int Hd = c.dec_hidden, nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim, I = c.dec_inter;
-        const int qkv_d = (nq + 2 * nkv) * d;
-        const float scale = 1.0f / sqrtf((float)d);
-        const size_t layer_kv = (size_t)c.max_slots * nkv * c.max_kv_len * d;
-        const float* inv_freq = reinterpret_cast<const float*>(w[SA_RW_DEC_INVFREQ]);
-        int rc, S = 1;
-        hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(M), dim3(64), 0, s, W(SA_RW_TOK_EMBED), next_token, active_dev, kv_len, c.max_kv_len,
-                           row_len, dx, WD(0, SA_RD_LN1), dh, Hd, c.dec_eps);
-        for (int l = 0; l < c.dec_layers; ++l) {
-            T* kc = kcache + l * layer_kv;
-            T* vc = vcache + l * layer_kv;
-            if ((rc = splitk_gemm(dh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, &S, s))) return rc;
-            dim3 grid(M, nkv), block(256);
-            const int G = nq / nkv;
-            static const bool attn_v1 = [] { const char* e = getenv("SURYA_AMD_DECODE_ATTN"); return e && e[0] == '1'; }();
-#define SA_DEC1(DD, GG)                                                                                                      \
-    hipLaunchKernelGGL((decode_attn_kernel<T, DD, GG>), grid, block, 0, s, (const T*)nullptr, part, S, WD(l, SA_RD_QKV_B), dattn, \
-                       kc, vc, active_dev, row_len, rope_cs, nq, nkv, c.max_kv_len, scale)
-#define SA_DEC2(DD, GG)                                                                                                      \
-    {                                                                                                                        \
-        auto kern = decode_attn_mfma_kernel<T, DD, GG>;                                                                      \
-        const size_t lds = decode_attn_mfma_lds<T, DD, GG>();                                                                \
-        static bool attr_set = false;                                                                                        \
-        if (!attr_set) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                                 \
-        }                                                                                                                    \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, part, S, WD(l, SA_RD_QKV_B), dattn, kc, vc, active_dev, row_len, rope_cs, nq, \
-                           nkv, c.max_kv_len, scale);                                                                        \
-    }
-            static const bool attn_v2 = [] { const char* e = getenv("SURYA_AMD_DECODE_ATTN"); return e && e[0] == '2'; }();
-#define SA_DEC3(DD, GG)                                                                                                      \
-    {                                                                                                                        \
-        auto kern = decode_attn_flash_kernel<DD, GG>;                                                                        \
-        const size_t lds = decode_attn_flash_lds<DD, GG>();                                                                  \
-        static bool attr_set = false;                                                                                        \
-        if (!attr_set) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                                 \
-        }                                                                                                                    \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, part, S, WD(l, SA_RD_QKV_B), dattn, kc, vc, active_dev, row_len, rope_cs, nq, \
-                           nkv, c.max_kv_len, scale);                                                                        \
-    }
-            bool done3 = false;
-            if constexpr (std::is_same<T, bf16_t>::value) {
-                if (!attn_v1 && !attn_v2) {              // bf16 default: per-wave flash kernel (decode_attn.h, third version)
-                    done3 = true;
-                    if (d == 128 && G <= 5) SA_DEC3(128, 5)
-                    else if (d == 128 && G <= 8) SA_DEC3(128, 8)
-                    else if (d == 64 && G <= 8) SA_DEC3(64, 8)
-                    else if (d == 32 && G <= 8) SA_DEC3(32, 8)
-                    else done3 = false;
-                }
-            }
-#undef SA_DEC3
-            if (done3) {
-            } else if (attn_v1) {
-                if (d == 128 && G <= 5) SA_DEC1(128, 5);
-                else if (d == 128) SA_DEC1(128, 8);
-                else if (d == 64) SA_DEC1(64, 8);
-                else if (d == 32) SA_DEC1(32, 8);
-                else return SA_ERR_UNSUPPORTED;
-            } else {
-                if (d == 128 && G <= 5) SA_DEC2(128, 5)
-                else if (d == 128) SA_DEC2(128, 8)
-                else if (d == 64) SA_DEC2(64, 8)
-                else if (d == 32) SA_DEC2(32, 8)
-                else return SA_ERR_UNSUPPORTED;
-            }
-#undef SA_DEC1
-#undef SA_DEC2
-            if ((rc = (int)hipGetLastError())) return rc;
-            if ((rc = splitk_gemm(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, &S, s))) return rc;
-            if ((rc = reduce_residual_norm(S, M, WD(l, SA_RD_LN2), dh, s))) return rc;
-            if ((rc = gemm<EPI_SWIGLU>(dh, Hd, WD(l, SA_RD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
-            if ((rc = splitk_gemm(dmlp, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, &S, s))) return rc;
-            const bool last = (l + 1 == c.dec_layers);
-            if ((rc = reduce_residual_norm(S, M, last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1), last ? dlast : dh, s))) return rc;
-        }
-        return SA_OK;
+    // The rows of one decode step are processed as one or two independent HALVES (contiguous row ranges of the active
+    // list): every per-row buffer is row-major, so a half is a pointer offset plus its own split-K partial workspace and its
+    // own stream. Two halves on two streams interleave on the chip: while one half's kernel drains its tail or waits at a
+    // launch boundary, the other half's kernel has the CUs (the decode chain is ~113 dependent 5-18 us launches per step; two
+    // bench processes sharing one GPU already showed +15 %, r01). Weights are read by both halves within a few tens of
+    // microseconds of each other, i.e. the second read is served by L2 / the 256 MiB Infinity Cache, not HBM.
+    struct Half { int r0, M; float* part; hipStream_t s; };
+
+    int decode_embed(const Half& h) {
+        const int Hd = c.dec_hidden;
+        hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(h.M), dim3(64), 0, h.s, W(SA_RW_TOK_EMBED), next_token, active_dev + h.r0,
+                           kv_len, c.max_kv_len, row_len + h.r0, dx + (size_t)h.r0 * Hd, WD(0, SA_RD_LN1), dh + (size_t)h.r0 * Hd, Hd,
+                           c.dec_eps);
+        return (int)hipGetLastError();
     }
 
-    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s) {
+    // One decoder layer of one decode step for the rows of `h`. The three skinny projections (qkv, o, down) run split-K so
+    // they cover the chip; their partial sums are combined by the kernel that needs the result anyway: decode attention
+    // (qkv) and a fused residual-add + next-RMSNorm pass (o, down). The last layer leaves the final-norm rows in `dlast`.
+    int decode_layer(int l, const Half& h) {
+        const int Hd = c.dec_hidden, nq = c.dec_heads, nkv = c.dec_kv_heads, d = c.dec_head_dim, I = c.dec_inter;
+        const int qkv_d = (nq + 2 * nkv) * d, M = h.M;
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t layer_kv = (size_t)c.max_slots * nkv * c.max_kv_len * d;
+        hipStream_t s = h.s;
+        T* kc = kcache + l * layer_kv;
+        T* vc = vcache + l * layer_kv;
+        T* x = dx + (size_t)h.r0 * Hd;
+        T* hh = dh + (size_t)h.r0 * Hd;
+        T* at = dattn + (size_t)h.r0 * nq * d;
+        T* ml = dmlp + (size_t)h.r0 * I;
+        const int* act = active_dev + h.r0;
+        const int* rl = row_len + h.r0;
+        int rc, S = 1;
+        if ((rc = splitk_gemm(hh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, h.part, &S, s))) return rc;
+        dim3 grid(M, nkv), block(256);
+        const int G = nq / nkv;
+#define SA_DEC_LAUNCH(KERN, LDS)                                                                                            \
+    {                                                                                                                       \
+        auto kern = KERN;                                                                                                   \
+        static AttrOnce attr;                                                                                               \
+        attr.ensure(kern, LDS);                                                                                             \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, h.part, S, WD(l, SA_RD_QKV_B), at, kc, vc, act, rl, rope_cs, nq, nkv,  \
+                           c.max_kv_len, scale);                                                                            \
+    }
+#define SA_DEC_MFMA(DD, GG) SA_DEC_LAUNCH((decode_attn_mfma_kernel<T, DD, GG>), (decode_attn_mfma_lds<T, DD, GG>()))
+#define SA_DEC_FLASH(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()))
+        bool launched = false;
+        if constexpr (std::is_same<T, bf16_t>::value) {      // bf16: per-wave flash kernel (decode_attn.h, third version)
+            launched = true;
+            if (d == 128 && G <= 5) SA_DEC_FLASH(128, 5)
+            else if (d == 128 && G <= 8) SA_DEC_FLASH(128, 8)
+            else if (d == 64 && G <= 8) SA_DEC_FLASH(64, 8)
+            else if (d == 32 && G <= 8) SA_DEC_FLASH(32, 8)
+            else launched = false;
+        }
+        if (!launched) {                                     // fp32 reference mode (and head shapes the flash kernel lacks)
+            if (d == 128 && G <= 5) SA_DEC_MFMA(128, 5)
+            else if (d == 128) SA_DEC_MFMA(128, 8)
+            else if (d == 64) SA_DEC_MFMA(64, 8)
+            else if (d == 32) SA_DEC_MFMA(32, 8)
+            else return SA_ERR_UNSUPPORTED;
+        }
+#undef SA_DEC_FLASH
+#undef SA_DEC_MFMA
+#undef SA_DEC_LAUNCH
+        if ((rc = (int)hipGetLastError())) return rc;
+        if ((rc = splitk_gemm(at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, h.part, &S, s))) return rc;
+        if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s))) return rc;
+        if ((rc = gemm<EPI_SWIGLU>(hh, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
+        if ((rc = splitk_gemm(ml, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, h.part, &S, s))) return rc;
+        const bool last = (l + 1 == c.dec_layers);
+        return reduce_residual_norm(S, M, h.part, x, last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1),
+                                    last ? dlast + (size_t)h.r0 * Hd : hh, s);
+    }
+
+    // r0 > 0 only for decode halves; prefill passes 0.
+    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s, int r0 = 0) {
         const int Hd = c.dec_hidden;
         int rc;
-        if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), dlast, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
+        T* last = dlast + (size_t)r0 * Hd;
+        float4* am = amax + (size_t)r0 * cdiv(c.vocab, 32);
+        if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), last, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
         // lm_head with the greedy reduction in its epilogue: logits stay in LDS, the head combines per-tile partials.
-        GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
-        a.amax = amax;
+        GemmArgs<T, float> a{last, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
+        a.amax = am;
         if ((rc = launch_gemm<T, float, EPI_ARGMAX>(a, s))) return rc;
         const int tiles_n = cdiv(c.vocab, a.bn_used);
         const size_t so = (size_t)step * c.max_slots;
-        hipLaunchKernelGGL((greedy_head_kernel<T, true>), dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(amax),
-                           (long)tiles_n, tiles_n, dlast, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
+        hipLaunchKernelGGL((greedy_head_kernel<T, true>), dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(am),
+                           (long)tiles_n, tiles_n, last, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
                            c.pad_token_id, (float)c.bbox_size, out_token + so, out_score + so, out_bbox + so * 6, next_token,
                            kv_len, len_inc);
-        last_rows = rows;
+        last_rows = r0 + rows;
         return (int)hipGetLastError();
     }
 
@@ -716,9 +715,34 @@ struct RecModel : RecBase {
 
     int decode_eager(int M, int n_steps, int step0, hipStream_t s) {
         int rc;
+        const Tuning& tn = tuning();
+        const size_t part_half = (size_t)8 * c.max_slots * std::max((size_t)(c.dec_heads + 2 * c.dec_kv_heads) * c.dec_head_dim,
+                                                                      (size_t)c.dec_hidden);
+        Half hv[2];
+        int nh = 1;
+        hv[0] = Half{0, M, part, s};
+        if (tn.dual && M >= tn.dual_min && M >= 128) {
+            const int Ma = cdiv(cdiv(M, 2), 64) * 64;            // halves in whole 64-row tiles: 256 -> 128 + 128
+            hv[0].M = Ma;
+            hv[1] = Half{Ma, M - Ma, part + part_half, hstream};
+            nh = 2;
+            SA_HIP(hipEventRecord(ev_fork, s));
+            SA_HIP(hipStreamWaitEvent(hstream, ev_fork, 0));
+        }
+        // launches of the two halves are interleaved layer by layer so neither stream waits for the host to finish with the other
         for (int step = 0; step < n_steps; ++step) {
-            if ((rc = decoder_layers_decode(M, s))) return rc;
-            if ((rc = heads(M, nullptr, active_dev, step0 + step, 1, true, s))) return rc;
+            for (int i = 0; i < nh; ++i)
+                if ((rc = decode_embed(hv[i]))) return rc;
+            for (int l = 0; l < c.dec_layers; ++l)
+                for (int i = 0; i < nh; ++i)
+                    if ((rc = decode_layer(l, hv[i]))) return rc;
+            for (int i = 0; i < nh; ++i)
+                if ((rc = heads(hv[i].M, nullptr, active_dev + hv[i].r0, step0 + step, 1, true, hv[i].s, hv[i].r0))) return rc;
+        }
+        if (nh == 2) {
+            SA_HIP(hipEventRecord(ev_join, hstream));
+            SA_HIP(hipStreamWaitEvent(s, ev_join, 0));
+            last_rows = M;
         }
         return SA_OK;
     }
@@ -759,8 +783,8 @@ struct RecModel : RecBase {
         if (n_steps < 0 || step0 < 0 || step0 + n_steps > SA_MAX_STEPS) return SA_ERR_ARG;
         const int M = n_active;
         if (M == 0 || n_steps == 0) return SA_OK;
-        if (!use_graph || gemm_profiler().enabled) return decode_eager(M, n_steps, step0, s);
-        const long key = ((long)M * 64 + n_steps) * 64 + step0;
+        if (!use_graph || !tuning().graph || gemm_profiler().enabled) return decode_eager(M, n_steps, step0, s);
+        const long key = (((long)M * 64 + n_steps) * 64 + step0) * 2 + (tuning().dual ? 1 : 0);
         auto it = graphs.find(key);
         if (it == graphs.end()) {
             // first sight of this shape runs eagerly (one-time hipFuncSetAttribute calls must not happen inside a capture)
@@ -967,6 +991,18 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
         return out_f32 ? op_gemm_t<bf16_t, float>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s)
                        : op_gemm_t<bf16_t, bf16_t>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s);
     return SA_ERR_UNSUPPORTED;
+}
+
+int surya_set_tuning(const char* key, int value) {
+    if (!key) return SA_ERR_ARG;
+    Tuning& t = tuning();
+    struct { const char* k; int* v; } tab[] = {
+        {"graph", &t.graph}, {"dual", &t.dual}, {"dual_min", &t.dual_min}, {"split_tile", &t.split_tile},
+        {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
+        {"gu_tile", &t.gu_tile}, {"head_tile", &t.head_tile}, {"bigtile", &t.bigtile}, {"glds", &t.glds}};
+    for (auto& e : tab)
+        if (!strcmp(e.k, key)) { *e.v = value; return SA_OK; }
+    return SA_ERR_ARG;
 }
 
 int surya_prof_enable(int on) {

@@ -99,3 +99,61 @@ def test_processor_tiles_match_reference():
     tiles, grid = proc.process_and_tile(g["image"].numpy())
     assert (1,) + tuple(grid) == tuple(g["grid_thw"])
     assert np.array_equal(tiles, g["tiles"].numpy())          # fp64 rescale + fp32 normalise + patch order: bit-exact
+
+
+# ------------------------------------------------------------------ BASELINE-configuration fixtures (make_golden_full.py)
+def _subset_rows(g, rows):
+    return {k: (v[:, rows] if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == g["tokens"].shape[1] else v)
+            for k, v in g.items() if k != "logits_top"} | {
+        "logits_top": {k: v[:, rows] for k, v in g["logits_top"].items()}}
+
+
+def _check_teacher_forced(cfg, sd, g, tiles, grids, seqs, steps, tol_rel=1e-4):
+    ids, am, pos = left_pad_batch(cfg, seqs)
+    om = ro.OracleRecModel(cfg, sd, cfg.image_token_id)
+    thw = [(1, h, w) for h, w in grids]
+    forced = [g["tokens"][:steps, b].tolist() for b in range(len(seqs))]
+    logits = ro.teacher_forced_logits(om, ids, tiles, thw, am, pos, forced, cfg.pad_token_id)
+    for s in range(steps):
+        tol = tol_rel * float(g["logits_absmax"][s].max())
+        got_top = torch.gather(logits[s], -1, g["logits_top"]["indices"][s])
+        assert (got_top - g["logits_top"]["values"][s]).abs().max().item() <= tol, s
+        assert (torch.logsumexp(logits[s], -1) - g["logits_lse"][s]).abs().max().item() <= tol, s
+        assert torch.equal(logits[s].argmax(-1), g["tokens"][s])          # token ids bit-exact
+
+
+def test_rec_full_bench_lines_oracle_matches_reference():
+    """REC-FULL on two of bench.py's own crops (the widest and the narrowest of the 8-line fixture), prefill + 3 steps:
+    the oracle reproduces the reference's top-32 logits, logsumexp and greedy tokens on the benchmark configuration."""
+    from util import bench_line_inputs
+    g = torch.load(os.path.join(GOLD, "rec_full_bench8.pt"))
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    rows = [0, 7]
+    tiles, grids, seqs = bench_line_inputs(cfg, g["lines"], seed=g["line_seed"], pick=[g["pick"][r] for r in rows])
+    assert [tuple(x) for x in grids] == [tuple(g["grids"][r]) for r in rows]
+    _check_teacher_forced(cfg, sd, _subset_rows(g, rows), tiles, grids, seqs, 4)
+
+
+def test_rec_small_256_oracle_matches_reference():
+    g = torch.load(os.path.join(GOLD, "rec_small_256.pt"))
+    cfg = rec_config("REC-SMALL")
+    sd = make_rec_weights(cfg, 0)
+    grids = [tuple(x) for x in g["grids"]]
+    tiles, seqs = make_prompts(cfg, grids, seed=g["seed"])
+    rows = list(range(0, 256, 32))                      # lines are independent: 8 of the 256 pin the oracle
+    offs = np.cumsum([0] + [h * w for h, w in grids])
+    t = torch.cat([tiles[offs[i]:offs[i + 1]] for i in rows])
+    _check_teacher_forced(cfg, sd, _subset_rows(g, rows), t, [grids[i] for i in rows], [seqs[i] for i in rows], 6)
+
+
+def test_det_default_1024_oracle_matches_reference():
+    """DET-DEFAULT on page 0 of bench.py's detection leg at 1024^2: the oracle's output is bit-identical to the module's."""
+    g = torch.load(os.path.join(GOLD, "det_default_1024.pt"))
+    cfg = det_config(g["config"])
+    sd = make_det_weights(cfg, 0)
+    x = do.normalise_pages(make_pages(g["pages"], g["size"], seed=g["page_seed"])[g["page"]:g["page"] + 1])
+    out = do.forward(sd, cfg, x)
+    assert torch.equal(out, g["logits"])
+    up = do.heatmaps(sd, cfg, x)
+    assert torch.equal(up[:, :, ::4, ::4], g["upsampled_sample"])

@@ -1,0 +1,105 @@
+"""Decode-step A/B sweep inside ONE process (one gpurun call): REC-FULL bf16, 256 active slots, bench-shaped prompts.
+
+For every tuning configuration (surya_set_tuning, csrc/common.h sa::Tuning) this re-prefills the same 256 lines, runs
+`--steps` decode steps in calls of 4 (the predictor's steps_per_sync) with the next call enqueued before the previous one is
+read, and reports wall us/step (HIP events around the whole run) plus whether the greedy tokens equal the first
+configuration's (tile / split-K changes re-order fp32 sums, so bf16 argmax near-ties may flip; reported, not asserted).
+
+    python tools/microbench/decode_sweep.py [--steps 32] [--configs all|quick]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--slots", type=int, default=256)
+    ap.add_argument("--configs", default="all")
+    args = ap.parse_args()
+    from surya_amd import _lib as L
+    from surya_amd.config import rec_config
+    from surya_amd.recognition.model import HipRecModel
+    from surya_amd.synth import make_rec_weights
+    from util import make_prompts, crop_grid
+
+    lib = L.lib()
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    n = args.slots
+    m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    dtype=torch.bfloat16, max_slots=n, max_kv_len=64 + args.steps + 40, max_patches=65536, max_prefill_tokens=n * 72)
+    rng = np.random.default_rng(1234)
+    grids = [crop_grid(64, int(w)) for w in sorted(rng.integers(128, 513, size=n), reverse=True)]
+    tiles, seqs = make_prompts(cfg, grids, seed=3)
+    tiles = tiles.cuda().contiguous()
+    slots = list(range(n))
+
+    def setk(**kw):
+        for k, v in kw.items():
+            L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
+
+    base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0)
+    if args.configs == "quick":
+        variants = [dict(), dict(dual=1), dict(split_tile=1, gu_tile=1), dict(split_tile=1, gu_tile=1, dual=1)]
+    else:
+        variants = [dict()]
+        variants += [dict(gu_tile=g) for g in (1, 2)]
+        variants += [dict(split_tile=1, split_min_kt=k) for k in (4, 2)]
+        variants += [dict(split_tile=2, split_min_kt=k, split_target=t) for k, t in ((4, 256), (2, 256), (2, 512))]
+        variants += [dict(split_tile=0, split_target=512)]
+        variants += [dict(head_tile=1)]
+        variants += [dict(dual=1), dict(dual=1, graph=1), dict(graph=1)]
+        variants += [dict(dual=1, gu_tile=1, split_tile=1), dict(dual=1, gu_tile=2, split_tile=2, split_min_kt=2),
+                     dict(dual=1, gu_tile=1, split_tile=1, graph=1), dict(gu_tile=1, split_tile=1), dict(gu_tile=2, split_tile=2, split_min_kt=2),
+                     dict(dual=1, gu_tile=1, split_tile=2, split_min_kt=2), dict(dual=1, gu_tile=1, split_tile=2, split_min_kt=2, head_tile=1)]
+
+    def run(n_steps):
+        m.prefill(tiles, grids, seqs, slots)
+        m.read_outputs(1)
+        m.set_active(slots)
+        toks = []
+        calls = [(min(4, n_steps - i), (i // 4) & 1) for i in range(0, n_steps, 4)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        m.decode_async(*calls[0])
+        for i, call in enumerate(calls):
+            if i + 1 < len(calls):
+                m.decode_async(*calls[i + 1])
+            t, _, _ = m.wait_outputs(*call)
+            toks.append(t[: call[0], :n].copy())
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n_steps, (time.perf_counter() - t0) * 1e6 / n_steps, np.concatenate(toks)
+
+    ref = None
+    print(f"# REC-FULL bf16, {n} active slots, {args.steps} decode steps per run, us/step (event) | us/step (host wall) | tokens == config 0")
+    for v in variants:
+        setk(**{**base, **v})
+        run(8)                                   # warm-up (attribute set, graph capture on 2nd sight)
+        run(8)
+        best = min((run(args.steps) for _ in range(3)), key=lambda r: r[0])
+        if ref is None:
+            ref = best[2]
+        same = float((best[2] == ref).all(axis=0).mean())
+        print(f"{str(v):90s} {best[0]:8.1f} {best[1]:8.1f}   lines identical {same:.3f}", flush=True)
+    setk(**base)
+
+
+if __name__ == "__main__":
+    main()
