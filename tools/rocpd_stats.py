@@ -32,6 +32,32 @@ def main(path):
     print(f"\ntotal kernel time {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches")
     if "--gaps" in sys.argv:
         gaps(c, name_col)
+    if "--by-grid" in sys.argv:
+        by_grid(c, name_col, cols)
+
+
+def by_grid(c, name_col, cols):
+    """Per (kernel, grid size): average duration and average idle gap in front of the dispatch (start - previous end on the
+    device). Separates launches of one template that differ only in shape (qkv / o / down split-K GEMMs)."""
+    gcol = next((x for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
+    if not gcol:
+        print("\n(no grid-size column in this database)")
+        return
+    q = f"""select d.start, d.end, s.{name_col}, d.{gcol} from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s
+            on d.kernel_id = s.id order by d.start"""
+    rows = list(c.execute(q))
+    agg, prev_end = {}, None
+    for st, en, name, grid in rows:
+        k = (short(name)[:90], grid)
+        a = agg.setdefault(k, [0, 0, 0, 0])
+        a[0] += 1; a[1] += en - st
+        if prev_end is not None and st - prev_end < 50_000:          # gaps >= 50 us are host stalls, not launch boundaries
+            a[2] += st - prev_end; a[3] += 1
+        prev_end = en if prev_end is None else max(prev_end, en)
+    print("\n| kernel | grid (threads) | calls | avg us | avg gap before us |")
+    print("|---|---|---|---|---|")
+    for (name, grid), (n, tot, g, gn) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"| `{name}` | {grid} | {n} | {tot / n / 1e3:.2f} | {(g / gn / 1e3) if gn else 0:.2f} |")
 
 
 def gaps(c, name_col, thresh_us=30.0, top=25):
