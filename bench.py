@@ -234,7 +234,46 @@ def bench_det(args, local_rank, world, rank, barrier):
                              "note": "bf16 HIP heat maps of page 0 vs the fp32 oracle on [0, 1] maps"}
     del m
     torch.cuda.empty_cache()
+    if out is not None and world == 1:
+        out["e2e"] = bench_det_e2e(args, cfg, sd, pages, local_rank)
     return out
+
+
+def bench_det_e2e(args, cfg, sd, pages, local_rank):
+    """DetectionPredictor.__call__ wall clock, PIL pages in -> TextDetectionResult out (what benchmark/detection.py:60-62 times):
+    host split / LANCZOS resize / normalise, H2D, forward, heat map -> boxes, result assembly. Device post-processing
+    (surya_det_boxes, the default) and, beside it, the reference layout (maps D2H + host post-processing on a thread pool)."""
+    from PIL import Image
+    from surya_amd.detection.predictor import DetectionPredictor, DetectionModelLoader
+
+    class Loader(DetectionModelLoader):
+        def model(self, device=None, dtype=None, max_batch=None):
+            return super().model(f"cuda:{local_rank}", torch.bfloat16, max_batch=args.det_pages)
+
+    class Pred(DetectionPredictor):
+        model_loader_cls = Loader
+        batch_size = args.det_pages
+
+    pred = Pred(checkpoint={"config": cfg, "state_dict": sd, "size": args.det_size})
+    imgs = [Image.fromarray(p) for p in pages]
+    res = {}
+    for name, dev in (("device_postprocess", True), ("host_postprocess", False)):
+        pred.device_postprocess = dev
+        out = pred(imgs)                                  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            out = pred(imgs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = {"pages_per_s": round(len(imgs) / dt, 1), "ms_per_batch": round(dt * 1e3, 1),
+                     "boxes": sum(len(r.bboxes) for r in out)}
+    res["note"] = (f"{len(imgs)} PIL pages per call, wall clock of DetectionPredictor.__call__ incl. host pre-processing, H2D, forward, "
+                   "heat map -> boxes, result assembly; one process, host threads as configured")
+    del pred
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():

@@ -213,6 +213,20 @@ int surya_det_destroy(surya_det* h);
  * = the model's own output before the predictor-side upsample. Enqueue only. */
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream);
 
+/* Heat map -> text boxes on the device. Replaces detect_boxes (surya/detection/heatmap.py:27-107:
+ * get_dynamic_thresholds :14-24, cv2.connectedComponentsWithStats, per-component cv2.dilate + cv2.minAreaRect + cv2.boxPoints,
+ * corner order, confidence = component max / page max) for `batch` pages at once; what is left for the host is
+ * get_and_clean_boxes' rescale / fit_to_bounds / clean_boxes on a few hundred 4-point boxes (heatmap.py:127-136).
+ * heat: device fp32; the text heat map of page b starts at heat + b * page_stride (floats) and is [height][width]
+ * (width % 4 == 0; values must be non-negative, as sigmoid outputs are). boxes: device fp32 [batch][max_boxes][4][2] (x, y),
+ * clockwise from the corner with the smallest x + y, in heat-map pixels; conf: device fp32 [batch][max_boxes]; count: device
+ * int32 [batch] = boxes of the page in raster order of their first pixel (the order cv2 labels them), or -1 if the page has
+ * more than max_boxes components (nothing else is written for that page). workspace: device, caller-owned,
+ * >= surya_det_boxes_workspace_bytes(...). Enqueue only. */
+size_t surya_det_boxes_workspace_bytes(int batch, int height, int width, int max_boxes);
+int surya_det_boxes(const float* heat, long page_stride, int batch, int height, int width, float text_threshold, float low_text,
+                    int max_boxes, float* boxes, float* conf, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): when enabled every GEMM launch is bracketed by hipEvents on its own
  * stream. surya_prof_read syncs the device and returns, per bucket (0: 128x128 GEMM, 1: tall 256-row GEMM tiles, 2: smaller GEMM tiles,

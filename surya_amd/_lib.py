@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.surya_amd_version.restype = C.c_char_p
         _lib.surya_rec_workspace_bytes.restype = C.c_size_t
+        _lib.surya_det_boxes_workspace_bytes.restype = C.c_size_t
     return _lib
 
 

@@ -9,6 +9,7 @@
 
 #include "../../include/surya_amd.h"
 #include "det_kernels.h"
+#include "det_post.h"
 
 namespace sa {
 
@@ -189,6 +190,17 @@ int surya_det_destroy(surya_det* h) {
     (void)hipDeviceSynchronize();
     delete h;
     return SA_OK;
+}
+
+size_t surya_det_boxes_workspace_bytes(int batch, int height, int width, int max_boxes) {
+    if (batch <= 0 || height <= 0 || width <= 0 || max_boxes <= 0) return 0;
+    return sa::post::post_layout(batch, height, width, max_boxes).total;
+}
+
+int surya_det_boxes(const float* heat, long page_stride, int batch, int height, int width, float text_threshold, float low_text,
+                    int max_boxes, float* boxes, float* conf, int32_t* count, void* workspace, size_t workspace_bytes, void* stream) {
+    return sa::post::post_run(heat, page_stride, batch, height, width, text_threshold, low_text, max_boxes, boxes, conf, count,
+                              workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream) {

@@ -192,6 +192,24 @@ def get_and_clean_boxes(textmap, processor_size, image_size, text_threshold=None
     return clean_boxes(bboxes)
 
 
+def result_from_device_boxes(boxes: np.ndarray, confs: np.ndarray, processor_size, orig_sizes, heat_img=None,
+                             aff_img=None) -> TextDetectionResult:
+    """The host remainder of parallel_get_boxes (surya/detection/heatmap.py:160-184) when detect_boxes ran on the device
+    (surya_det_boxes): PolygonBox construction, rescale / fit_to_bounds / clean_boxes (get_and_clean_boxes :127-136) and the
+    y-expansion, on a few hundred 4-point boxes."""
+    bboxes = [PolygonBox(polygon=b, confidence=float(c)) for b, c in zip(boxes, confs)]
+    for b in bboxes:
+        b.rescale(processor_size, orig_sizes)
+        b.fit_to_bounds([0, 0, orig_sizes[0], orig_sizes[1]])
+    bboxes = clean_boxes(bboxes)
+    for box in bboxes:
+        if box.height < 3 * box.width:
+            box.expand(x_margin=0, y_margin=settings.DETECTOR_BOX_Y_EXPAND_MARGIN)
+            box.fit_to_bounds([0, 0, orig_sizes[0], orig_sizes[1]])
+    return TextDetectionResult(bboxes=bboxes, vertical_lines=[], heatmap=heat_img, affinity_map=aff_img,
+                               image_bbox=[0, 0, orig_sizes[0], orig_sizes[1]])
+
+
 def parallel_get_boxes(preds, orig_sizes, include_maps=False) -> TextDetectionResult:
     heatmap, affinity_map = preds
     heat_img = aff_img = None

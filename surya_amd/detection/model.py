@@ -82,3 +82,51 @@ class HipDetModel:
         L.check(self.lib.surya_det_forward(self.handle, L.ptr(pixel_values), C.c_int(B), L.ptr(heat), L.ptr(low), stream),
                 "surya_det_forward")
         return (heat, low) if want_lowres else heat
+
+
+class HipDetPost:
+    """Heat map -> boxes on the device (surya_det_boxes, csrc/det_post.h): thresholds, 4-connected labelling, per-component
+    dilation + minimum-area rectangle and confidences for all pages of a batch in a handful of launches; only the corner
+    arrays come back to the host. No CPU fallback: this IS detect_boxes of the product path (surya/detection/heatmap.py:27-107)."""
+
+    def __init__(self, device="cuda:0", max_boxes: int = 4096):
+        if not torch.cuda.is_available():
+            raise L.SuryaAmdError("HipDetPost needs a GPU (MI355X); there is no CPU fallback")
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self.max_boxes = max_boxes
+        self._ws = None
+
+    def _workspace(self, B, H, W):
+        need = int(self.lib.surya_det_boxes_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(W), C.c_int(self.max_boxes)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def __call__(self, heat: torch.Tensor, text_threshold: float, low_text: float, page_stride: int = None):
+        """heat: cuda fp32, [B, H, W] contiguous, or a [B, labels, H, W] tensor whose plane 0 is the text map (then the page
+        stride is labels * H * W). Returns a list of (boxes float32 [n, 4, 2], confidences float32 [n]) per page, in the
+        component order cv2.connectedComponentsWithStats would label them."""
+        assert heat.is_cuda and heat.dtype == torch.float32 and heat.is_contiguous()
+        if heat.dim() == 4:
+            B, Lb, H, W = heat.shape
+            stride = Lb * H * W
+        else:
+            B, H, W = heat.shape
+            stride = H * W
+        torch.cuda.set_device(self.device)
+        ws, need = self._workspace(B, H, W)
+        boxes = torch.empty((B, self.max_boxes, 4, 2), dtype=torch.float32, device=self.device)
+        conf = torch.empty((B, self.max_boxes), dtype=torch.float32, device=self.device)
+        count = torch.empty((B,), dtype=torch.int32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.surya_det_boxes(L.ptr(heat), C.c_long(stride), C.c_int(B), C.c_int(H), C.c_int(W), C.c_float(text_threshold),
+                                         C.c_float(low_text), C.c_int(self.max_boxes), L.ptr(boxes), L.ptr(conf), L.ptr(count), L.ptr(ws),
+                                         C.c_size_t(need), stream), "surya_det_boxes")
+        n = count.cpu().numpy()                          # one tiny D2H decides how much of the box arrays to copy
+        if (n < 0).any():
+            raise L.SuryaAmdError(f"surya_det_boxes: a page has more than max_boxes = {self.max_boxes} text components")
+        nmax = int(n.max()) if len(n) else 0
+        bh = boxes[:, :nmax].cpu().numpy() if nmax else np.zeros((B, 0, 4, 2), np.float32)
+        ch = conf[:, :nmax].cpu().numpy() if nmax else np.zeros((B, 0), np.float32)
+        return [(bh[b, : n[b]].copy(), ch[b, : n[b]].copy()) for b in range(B)]

@@ -18,8 +18,8 @@ from PIL import Image, ImageOps
 from ..common.predictor import BasePredictor, ModelLoader
 from ..config import DetConfig, det_config
 from ..settings import settings
-from .heatmap import TextDetectionResult, parallel_get_boxes
-from .model import HipDetModel
+from .heatmap import TextDetectionResult, parallel_get_boxes, result_from_device_boxes
+from .model import HipDetModel, HipDetPost
 
 
 class SegformerImageProcessor:
@@ -113,7 +113,14 @@ class DetectionPredictor(BasePredictor):
                 return sdist.gather_objects(local, mine, len(images), self.process_group)
         return self._detect(images, batch_size, include_maps)
 
+    # Heat map -> boxes runs on the device (surya_det_boxes): what leaves the GPU per page is a few hundred 4-point boxes instead
+    # of two fp32 maps (8 MB at 1024^2). DETECTOR_POSTPROCESS_HOST=1 keeps the host post-processing of the reference layout
+    # (heat maps D2H + surya_amd/detection/heatmap.py on a thread pool): the checker of tests/test_gpu_det.py, not a fallback.
+    device_postprocess: bool = not settings.DETECTOR_POSTPROCESS_HOST
+
     def _detect(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        if self.device_postprocess:
+            return self._detect_device(images, batch_size, include_maps)
         gen = self.batch_detection(images, batch_size=batch_size)
         futures = []
         workers = max(1, min(settings.DETECTOR_POSTPROCESSING_CPU_WORKERS, len(images)))
@@ -127,12 +134,88 @@ class DetectionPredictor(BasePredictor):
             out.extend(parallel_get_boxes(p, s, include_maps) for p, s in zip(preds, sizes))
         return out
 
+    def _detect_device(self, images, batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        if getattr(self, "_post", None) is None:
+            self._post = HipDetPost(self.model.device)
+        tt, lt = settings.DETECTOR_TEXT_THRESHOLD, settings.DETECTOR_BLANK_THRESHOLD
+        out: List[TextDetectionResult] = []
+        for heat, split_index, split_heights, sizes in self.batch_heatmaps(images, batch_size):
+            ph, pw = heat.shape[2], heat.shape[3]
+            n_pages = split_index[-1] + 1
+            tiles_of = [[i for i, k in enumerate(split_index) if k == page] for page in range(n_pages)]
+            whole = [page for page in range(n_pages) if len(tiles_of[page]) == 1]
+            res = {}
+            if whole:
+                sel = heat if len(whole) == heat.shape[0] else heat[[tiles_of[pg][0] for pg in whole]].contiguous()
+                for pg, (bx, cf) in zip(whole, self._post(sel, tt, lt)):
+                    res[pg] = (bx, cf, (pw, ph))
+            for pg in range(n_pages):                    # tall pages: strips re-assembled on the device (:134-151), one call each
+                if pg in res:
+                    continue
+                strips = [heat[t, 0, : split_heights[t]] for t in tiles_of[pg]]
+                full = torch.cat(strips, 0).unsqueeze(0).contiguous()
+                bx, cf = self._post(full, tt, lt)[0]
+                res[pg] = (bx, cf, (pw, full.shape[1]))
+            maps = None
+            if include_maps:                              # callers that want the maps pay for their D2H
+                maps = heat.cpu().numpy()
+            for pg in range(n_pages):
+                bx, cf, psize = res[pg]
+                hi = ai = None
+                if include_maps:
+                    hm = np.vstack([maps[t, 0, : split_heights[t]] for t in tiles_of[pg]])
+                    am = np.vstack([maps[t, 1, : split_heights[t]] for t in tiles_of[pg]])
+                    hi, ai = Image.fromarray((hm * 255).astype(np.uint8)), Image.fromarray((am * 255).astype(np.uint8))
+                out.append(result_from_device_boxes(bx, cf, list(psize), sizes[pg], hi, ai))
+        return out
+
     def prepare_image(self, img: Image.Image) -> torch.Tensor:
         new_size = (self.processor.size["width"], self.processor.size["height"])
         img.thumbnail(new_size, Image.Resampling.LANCZOS)          # the reference's double resize (:50-57)
         img = img.resize(new_size, Image.Resampling.LANCZOS)
         arr = np.asarray(img, dtype=np.uint8)
         return torch.from_numpy(self.processor(arr)["pixel_values"][0])
+
+    def batch_heatmaps(self, images: List, batch_size=None):
+        """Split -> prepare_image -> model, like batch_detection (surya/detection/__init__.py:64-132), but the heat maps stay
+        on the device: yields (heat cuda fp32 [tiles, labels, H, W], page index of each tile, valid rows of each tile, sizes)."""
+        assert all(isinstance(im, Image.Image) for im in images)
+        if batch_size is None:
+            batch_size = self.get_batch_size()
+        batch_size = min(batch_size, self.model.max_batch)
+        ph = self.processor.size["height"]
+        orig_sizes = [im.size for im in images]
+        splits = [get_total_splits(s, ph) for s in orig_sizes]
+        batches, cur, cur_n = [], [], 0
+        for i in range(len(images)):                               # greedy packing by tile count (:77-90)
+            if cur_n + splits[i] > batch_size:
+                if cur:
+                    batches.append(cur)
+                cur, cur_n = [], 0
+            cur.append(i)
+            cur_n += splits[i]
+        if cur:
+            batches.append(cur)
+        for idxs in batches:
+            batch_images = [images[j].convert("RGB") for j in idxs]
+            split_index, split_heights, parts = [], [], []
+            for k, im in enumerate(batch_images):
+                ps, hs = split_image(im, ph)
+                parts.extend(ps)
+                split_index.extend([k] * len(ps))
+                split_heights.extend(hs)
+            if len(parts) > 4:
+                with ThreadPoolExecutor(min(8, len(parts))) as ex:      # PIL resizes release the GIL
+                    prepared = list(ex.map(self.prepare_image, parts))
+            else:
+                prepared = [self.prepare_image(p) for p in parts]
+            tiles = torch.stack(prepared, 0).contiguous()
+            heat_parts = []
+            for s in range(0, tiles.shape[0], self.model.max_batch):        # a single page may exceed max_batch tiles
+                chunk = tiles[s: s + self.model.max_batch].pin_memory().to(self.model.device, non_blocking=True)
+                heat_parts.append(self.model.forward(chunk))
+            heat = heat_parts[0] if len(heat_parts) == 1 else torch.cat(heat_parts, 0)
+            yield heat, split_index, [min(h, ph) for h in split_heights], [orig_sizes[j] for j in idxs]
 
     def batch_detection(self, images: List, batch_size=None) -> Generator[Tuple[List[List[np.ndarray]], List[Tuple[int, int]]], None, None]:
         assert all(isinstance(im, Image.Image) for im in images)

@@ -53,7 +53,9 @@ def main():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
     base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0)
-    if args.configs == "quick":
+    if args.configs == "base":
+        variants = [dict()]
+    elif args.configs == "quick":
         variants = [dict(), dict(dual=1), dict(split_tile=1, gu_tile=1), dict(split_tile=1, gu_tile=1, dual=1)]
     else:
         variants = [dict()]

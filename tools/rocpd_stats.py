@@ -41,7 +41,7 @@ def by_grid(c, name_col, cols):
     device). Separates launches of one template that differ only in shape (qkv / o / down split-K GEMMs)."""
     gcol = next((x for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
     if not gcol:
-        print("\n(no grid-size column in this database)")
+        print("\n(no grid-size column in this database; columns:", cols, ")")
         return
     q = f"""select d.start, d.end, s.{name_col}, d.{gcol} from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s
             on d.kernel_id = s.id order by d.start"""
