@@ -171,6 +171,13 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream);
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream);
+/* The decode regime's small-output projection kernel (32x32 tile per workgroup, K cut over its waves, no split-K slabs):
+ * C = X W^T + bias (+ R, added after rounding the projection to C's type like epilogue 1 of surya_op_gemm). */
+int surya_op_gemm_skinny(int dtype, int out_f32, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, const void* bias,
+                         const void* R, long ldr, int M, int N, int K, void* stream);
+/* SwiGLU GEMM (epilogue 3) on rows that are RMS-normalised inside the kernel: C[M, N/2] = swiglu((x * rsqrt(mean(x^2) + eps)) W^T). */
+int surya_op_gemm_rownorm_swiglu(int dtype, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                                 float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Detection model: EfficientViT-L backbone + SegFormer-style decode head + sigmoid + x4 bilinear upsample.
