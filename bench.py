@@ -7,8 +7,11 @@
 One "step" = one pass of RecognitionPredictor's device loop (prefill + continuous-batching greedy decode until every
 line stopped) over a batch of 256 synthetic ragged line crops per GPU (BASELINE.json configs[1]): REC-FULL synthetic
 weights (no checkpoints offline), bf16, crops 64 x {128..512}, tiles already resident in HBM when the clock starts.
-Weak scaling: every rank processes its own 256 lines; no data-path collective (lines are independent); the token
-all-gather of surya_amd.dist runs once after the timed region to check all ranks finished the same amount of work.
+Weak scaling: every rank processes its own 256 lines; no data-path collective (lines are independent) and none after it --
+the aggregate is the per-rank line count times the world size over the slowest rank's time (all_reduce MAX of the wall time).
+The "e2e" object is BASELINE.json configs[3]: 128 synthetic pages through DetectionPredictor and RecognitionPredictor
+(__call__ to __call__, PIL pages in, OCRResult out), STRONG scaling: with N > 1 every rank passes the same pages, detection
+shards pages and recognition shards lines over the ranks (surya_amd.dist: fingerprint check, one all_gather of the outputs).
 
 Prints ONE JSON line on rank 0 with the metric, plus
   roofline      event-timed GEMM launches of one extra (untimed) pass, dominant tile configuration
@@ -52,6 +55,8 @@ def parse():
     ap.add_argument("--det-size", type=int, default=1024)
     ap.add_argument("--det-steps", type=int, default=5)
     ap.add_argument("--cpu-lines", type=int, default=32, help="lines of the same workload the CPU oracle runs (one batch)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
+    ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--share-device", action="store_true",
@@ -276,6 +281,67 @@ def bench_det_e2e(args, cfg, sd, pages, local_rank):
     return res
 
 
+def bench_e2e(args, pred, local_rank, world, rank, barrier):
+    """BASELINE.json configs[3]: args.e2e_pages synthetic 1024^2 pages, PIL in -> results out, both predictors' __call__:
+    DetectionPredictor (split, LANCZOS resize, H2D, forward, heat map -> boxes on the device, result assembly) then
+    RecognitionPredictor on the pages' text rows (page upload as uint8, crop / resize / normalise / patchify on the device,
+    continuous-batching decode with ~22 lines per page >> slots, detokenise, polygons, OCRResult). The recogniser is fed the rows
+    that were DRAWN (synth.make_pages_with_lines): a randomly initialised detector finds ~1 box per page, which would leave the
+    recognition stage idle; both stages run on the same pages inside the timed region. N > 1: pages / lines sharded over ranks."""
+    from PIL import Image
+    from surya_amd.config import det_config
+    from surya_amd.detection.predictor import DetectionPredictor, DetectionModelLoader
+    from surya_amd.synth import make_det_weights, make_pages_with_lines
+
+    class Loader(DetectionModelLoader):
+        def model(self, device=None, dtype=None, max_batch=None):
+            return super().model(f"cuda:{local_rank}", torch.bfloat16, max_batch=16)
+
+    class Det(DetectionPredictor):
+        model_loader_cls = Loader
+        batch_size = 16
+
+    dcfg = det_config(args.det_config)
+    det = Det(checkpoint={"config": dcfg, "state_dict": make_det_weights(dcfg, 0), "size": args.det_size})
+    pages, rows = make_pages_with_lines(args.e2e_pages, args.det_size, seed=4321)      # same pages on every rank
+    imgs = [Image.fromarray(p) for p in pages]
+    det.shard_pages = pred.shard_lines = world > 1
+    n_lines = sum(len(r) for r in rows)
+
+    def one():
+        t0 = time.perf_counter()
+        d = det(imgs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        o = pred(imgs, bboxes=rows)
+        torch.cuda.synchronize()
+        return d, o, t1 - t0, time.perf_counter() - t1
+
+    one()                                                  # warm-up
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d, o, t_det, t_rec = one()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt, t_det, t_rec], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_det, t_rec = (float(x) for x in t)
+    det.shard_pages = pred.shard_lines = False
+    if rank != 0:
+        return None
+    assert len(o) == len(imgs) and sum(len(r.text_lines) for r in o) == n_lines
+    return {"metric": "end-to-end pages/s and lines/s, detect + recognise (whole node)", "pages": len(imgs), "lines": n_lines,
+            "pages_per_s": round(len(imgs) / dt, 2), "lines_per_s": round(n_lines / dt, 1), "wall_ms": round(dt * 1e3, 1),
+            "detect_ms": round(t_det * 1e3, 1), "recognise_ms": round(t_rec * 1e3, 1), "scaling": "strong",
+            "tokens": int(sum(len(c.chars) for r in o for c in r.text_lines)),
+            "detected_boxes": int(sum(len(r.bboxes) for r in d)),
+            "note": "wall clock of DetectionPredictor.__call__ + RecognitionPredictor.__call__(bboxes = the drawn rows), PIL pages in, "
+                    "OCRResult out; host pre/post-processing, H2D / D2H and continuous-batching refills included; max_tokens="
+                    f"{args.max_tokens}"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -389,9 +455,10 @@ def main():
 
     det = None
     if not args.no_det:
-        del pred
-        torch.cuda.empty_cache()
         det = bench_det(args, local_rank, world, rank, barrier)
+    e2e = None
+    if not args.no_e2e:
+        e2e = bench_e2e(args, pred, local_rank, world, rank, barrier)
 
     if rank == 0:
         lines_total = args.lines * world * args.steps
@@ -403,7 +470,7 @@ def main():
                                    f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
                        "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
                        "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "detection": det,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "detection": det, "e2e": e2e,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

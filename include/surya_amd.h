@@ -149,6 +149,22 @@ int surya_rec_read_outputs(surya_rec* h, int n_steps, int32_t* tokens, float* sc
 int surya_rec_decode_async(surya_rec* h, int n_steps, int ring, void* stream);
 int surya_rec_wait_outputs(surya_rec* h, int n_steps, int ring, int32_t* tokens, float* scores, int32_t* bboxes);
 
+/* Line-crop pre-processing on the device: page pixels -> image_tiles for n_lines lines in one call.
+ * Replaces, per line, slice_bboxes_from_image / slice_and_pad_poly (surya/input/processing.py:35-101), scale_to_fit
+ * (surya/common/surya/processor/__init__.py:141-178, LANCZOS4) and _process_and_tile (:185-230: CUBIC round-up to multiples of
+ * patch * merge, x / 255 in fp64, (x - mean) / std in fp32, merge-block-major patch rows).
+ * pages: device uint8, every page RGB HWC at its descriptor's byte offset. lines: device array of n_lines descriptors
+ *   { int64 page_off; int32 page_w, page_h; int32 x0, y0, cw, ch (crop rectangle, inside the page, >= 1 px);
+ *     int32 has_poly; float poly[8] (4 vertices relative to the crop origin; pixels outside read as pad_value);
+ *     int32 mid_w, mid_h (size after scale_to_fit); int32 out_w, out_h (multiples of patch * merge);
+ *     int64 mask_off (bytes into mask_arena, cw * ch per polygon line); int64 mid_off (floats into mid_arena, 3 mid_w mid_h per
+ *     line whose mid size differs from its crop size); int64 tile_row (first row of the line in tiles) }   -- 112 bytes, C layout.
+ * tiles: device fp32 [sum (out_h / patch) (out_w / patch)][3 patch^2]. The host computes only these integers
+ * (surya_amd/recognition/preprocess_gpu.py). Enqueue only; every buffer is caller-owned. */
+int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
+                         int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
+                         int any_stage1, void* stream);
+
 /* Test hooks (tolerance tests of intermediate tensors):
  *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in
  *                ORIGINAL token order (= get_image_embeddings, common/surya/__init__.py:130-195) to `out`
@@ -171,13 +187,6 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream);
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream);
-/* The decode regime's small-output projection kernel (32x32 tile per workgroup, K cut over its waves, no split-K slabs):
- * C = X W^T + bias (+ R, added after rounding the projection to C's type like epilogue 1 of surya_op_gemm). */
-int surya_op_gemm_skinny(int dtype, int out_f32, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, const void* bias,
-                         const void* R, long ldr, int M, int N, int K, void* stream);
-/* SwiGLU GEMM (epilogue 3) on rows that are RMS-normalised inside the kernel: C[M, N/2] = swiglu((x * rsqrt(mean(x^2) + eps)) W^T). */
-int surya_op_gemm_rownorm_swiglu(int dtype, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
-                                 float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Detection model: EfficientViT-L backbone + SegFormer-style decode head + sigmoid + x4 bilinear upsample.

@@ -128,8 +128,6 @@ struct Tuning {
     int split_min_kt = 4;    // at least this many 128-byte K-tiles per slice
     int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
     int gu_tile = 0;         // decode gate|up (M in (128, 256]): 0 = 64x64, 1 = 128x64, 2 = 128x128
-    int o_skinny = 1;        // decode attention-output projection: skinny GEMM (+ residual) and RMSNorm folded into gate|up (1) or split-K + reduce (0)
-    int qkv_skinny = 0;      // decode qkv projection: skinny GEMM writing one fp32 slab (1) or split-K (0)
     int head_tile = 0;       // lm_head at decode: 0 = 128x128, 1 = 256x128
     int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
     int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)

@@ -55,31 +55,12 @@ struct GemmArgs {
     // four consecutive columns holds two complete rotate_half pairs; rope[m * (D/2) + j] = (cos, sin) of token m, pair j.
     const float2* rope = nullptr;
     int rope_cols = 0, rope_D = 0;
-    float norm_eps = 0.f;        // ROWNORM kernels: eps of the folded RMSNorm (mean over the K real columns)
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
 // was LDS-bound at ~690 TF/s, r01 profile). Fragment of either operand: lane l holds 16 bytes = K-chunk (ks*2 + (l >> 5))
 // of row (l & 31); bf16: one v_mfma_f32_32x32x16_bf16; fp32: four v_mfma_f32_32x32x2_f32 on the chunk's 4 floats
 // (k-permuted identically on both operands, so the sum is unchanged and exact).
-// sum of squares of the 16-byte fragment chunk a lane feeds to the matrix cores (8 bf16 or 4 fp32)
-template <typename TI> __device__ __forceinline__ float sumsq16(const u32x4& c);
-template <> __device__ __forceinline__ float sumsq16<bf16_t>(const u32x4& c) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float lo = __uint_as_float(c[i] << 16), hi = __uint_as_float(c[i] & 0xffff0000u);
-        s += lo * lo; s += hi * hi;
-    }
-    return s;
-}
-template <> __device__ __forceinline__ float sumsq16<float>(const u32x4& c) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const float v = __uint_as_float(c[i]); s += v * v; }
-    return s;
-}
-
 template <typename TI> struct Mfma;
 template <> struct Mfma<bf16_t> {
     __device__ static __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
@@ -96,12 +77,7 @@ template <> struct Mfma<float> {
 };
 
 // BM x BN output tile per workgroup of WM x WN waves.
-// ROWNORM: the A operand is the RAW residual stream and the RMSNorm of its rows is folded into this GEMM: every workgroup reads
-// whole rows of X anyway (full K), so each lane accumulates the squares of the X fragments it feeds to the matrix cores (its
-// fragment row IS the row of its accumulators: D[n][m] layout), and the epilogue scales the accumulators by
-// rsqrt(mean(x^2) + eps). The norm's gain is folded into the weight columns at load time (recognition/weights.py). This removes
-// the standalone norm / split-K-reduce launch in front of the decode gate|up projection.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool ROWNORM = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
@@ -186,13 +162,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             WF[j] = *reinterpret_cast<const u32x4*>(cur_ + XBYTES + row * 128 + ((((KK) * 2 + fch) ^ ((row >> 1) & 7)) << 4)); \
         }                                                                                                      \
     }
-    float ssq[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) ssq[i] = 0.f;
 #define SA_MFMAS(XF, WF)                                   \
     _Pragma("unroll") for (int j = 0; j < FN; ++j)         \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], WF[j], XF[i]); \
-    if constexpr (ROWNORM) { _Pragma("unroll") for (int i = 0; i < FM; ++i) ssq[i] += sumsq16<TI>(XF[i]); }
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) Mfma<TI>::run(acc[j][i], WF[j], XF[i]);
     // Fragments of K-step kk+1 are read from LDS before the MFMAs of step kk are issued, so one wave keeps the matrix
     // pipe busy without relying on a second resident wave to cover its ds_read latency.
 #ifndef SA_INTERLEAVE
@@ -416,12 +388,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
     // N = 1280 residual GEMMs ran at 400 TF/s on it). Instead the tile is staged in the (now idle) staging LDS with bias /
     // activation applied, then stored as whole 16-byte chunks of contiguous rows; the residual is added on the way out.
-    float rstd[FM];
-    if constexpr (ROWNORM) {
-        // lane l summed the K-chunks of parity (l >> 5) of row (l & 31): the partner lane holds the other half
-#pragma unroll
-        for (int i = 0; i < FM; ++i) rstd[i] = rsqrtf((ssq[i] + __shfl_xor(ssq[i], 32, 64)) / (float)p.K + p.norm_eps);
-    }
     __syncthreads();
     constexpr int OW = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;         // output columns of this tile
     using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
@@ -437,10 +403,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             for (int g = 0; g < 4; ++g) {
                 const int ncol = wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;   // tile-local column of v[0]
                 float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                if constexpr (ROWNORM) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= rstd[i];
-                }
                 if constexpr (!SPLIT) {
                     if (p.bias) {
                         const int n = min(n0 + ncol, p.N - 4);
@@ -573,7 +535,7 @@ inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
 inline int gemm_cfg_id(int BM, int BN) { return (BM >= 128 && BN >= 128) ? 0 : (BM == 256 ? 1 : 2); }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool ROWNORM = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = SPLIT ? cdiv(cdiv(a.N, BN) * a.splitk, 8) * 8 * cdiv(a.M, BM) : cdiv(a.M, BM) * cdiv(a.N, BN);
     a.bn_used = BN;
@@ -591,7 +553,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
     constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
-    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS, ROWNORM>;
+    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS>;
     static AttrOnce attr;           // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
@@ -695,116 +657,6 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     }
     a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk);
     return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// "Skinny" GEMM for the decode regime's small-output projections (M <= 256 rows, N ~ 1-2 k columns, e.g. the attention output
-// projection: 327 k outputs from 3.3 MB of weights). These launches are LATENCY-bound, not bandwidth-bound (r02 profile: 7-9.5 us
-// each for ~1 us of data movement; split-K over workgroups added an fp32 partial round trip and a reduce launch). Here a
-// workgroup owns a 32x32 output tile and cuts ITS K range over its 4 waves: every wave streams its own K columns of the 32 X rows
-// and 32 W rows straight from global memory into registers -- no LDS staging, no barrier in the K loop, two K-tiles (2 x 8
-// 16-byte loads) in flight per wave -- and the four partial tiles are summed through 16 KiB of LDS. The result is written once,
-// in its final type, with bias / residual applied: no partial slabs, no reduce kernel, no megabytes of dirty fp32 lines to
-// write back at the kernel boundary.
-// Fragment trick: a lane owns 64 contiguous bytes of its row per 128-byte K-tile (lanes l and l + 32 split the tile), i.e. four
-// 16-byte chunks = the operands of four MFMAs; X and W use the same lane -> k assignment, so the dot products are unchanged.
-// Workgroups that share a W tile (the M / 32 row tiles of one column tile) are queued on one XCD (b % 8), like the split-K GEMM.
-template <typename TI, typename TO>
-struct SkinnyArgs {
-    const TI* X; long ldx;
-    const TI* W; long ldw;
-    TO* C; long ldc;
-    const TI* bias;              // [N] or nullptr
-    const TO* R; long ldr;       // residual (may alias C) or nullptr
-    int M, N, K;
-};
-
-template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs<TI, TO> p) {
-    constexpr int KE = Ty<TI>::KE;
-    __shared__ __attribute__((aligned(16))) float red[4][32][36];            // +4 floats per row: conflict-free 16-byte writes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_m = (p.M + 31) / 32, tiles_n = (p.N + 31) / 32;
-    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-    const int tile_n = (j / tiles_m) * 8 + x, tile_m = j % tiles_m;
-    if (tile_n >= tiles_n) return;
-    const int m0 = tile_m * 32, n0 = tile_n * 32;
-    const int nk = p.K / KE;
-    const int kt0 = (int)((long)wave * nk / 4), kt1 = (int)((long)(wave + 1) * nk / 4), nkw = kt1 - kt0;
-    const int r = lane & 31, h = lane >> 5;
-    const unsigned char* xp = reinterpret_cast<const unsigned char*>(p.X + (long)min(m0 + r, p.M - 1) * p.ldx) + h * 64;
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(p.W + (long)min(n0 + r, p.N - 1) * p.ldw) + h * 64;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    u32x4 xa[4], wa[4], xb[4], wb[4];
-#define SA_SK_LOAD(XR, WR, KT)                                                                       \
-    {                                                                                                \
-        const long o_ = (long)(KT) * 128;                                                            \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) XR[c] = *reinterpret_cast<const u32x4*>(xp + o_ + c * 16); \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) WR[c] = *reinterpret_cast<const u32x4*>(wp + o_ + c * 16); \
-    }
-#define SA_SK_MMA(XR, WR) _Pragma("unroll") for (int c = 0; c < 4; ++c) Mfma<TI>::run(acc, WR[c], XR[c]);
-    if (nkw > 0) {
-        const int last = kt1 - 1;
-        SA_SK_LOAD(xa, wa, kt0);
-        SA_SK_LOAD(xb, wb, min(kt0 + 1, last));
-        for (int t = kt0; t < kt1; t += 2) {             // unconditional clamped prefetch (see gemm_nt_kernel)
-            SA_SK_MMA(xa, wa);
-            SA_SK_LOAD(xa, wa, min(t + 2, last));
-            if (t + 1 < kt1) SA_SK_MMA(xb, wb);
-            SA_SK_LOAD(xb, wb, min(t + 3, last));
-        }
-    }
-#undef SA_SK_LOAD
-#undef SA_SK_MMA
-    // D[n][m]: lane owns row m = lane & 31 and, per register group g, columns n = 8 g + 4 (lane >> 5) + 0..3
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(&red[wave][r][8 * g + 4 * h]) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    __syncthreads();
-    const int m = tid >> 3, c4 = (tid & 7) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][m][c4]);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(&red[w][m][c4]);
-        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-    }
-    const int gm = m0 + m, gn = n0 + c4;
-    if (gm >= p.M || gn >= p.N) return;
-    if (p.bias) {
-        float b[4];
-        load4(p.bias + gn, b);
-        v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-    }
-    if (p.R) {
-        // EPI_RESIDUAL semantics of gemm_nt_kernel: the projection is rounded to the storage type, then the residual is added
-        float rr[4];
-        load4(p.R + (long)gm * p.ldr + gn, rr);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = Ty<TO>::rnd(v[i]) + rr[i];
-    }
-    store4(p.C + (long)gm * p.ldc + gn, v[0], v[1], v[2], v[3]);
-}
-
-template <typename TI, typename TO>
-static inline int launch_gemm_skinny(const SkinnyArgs<TI, TO>& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return SA_OK;
-    if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || a.ldc % 4 != 0 || (a.R && a.ldr % 4 != 0)) return SA_ERR_SHAPE;
-    const int tiles_m = cdiv(a.M, 32), tiles_n = cdiv(a.N, 32);
-    const int grid = cdiv(tiles_n, 8) * 8 * tiles_m;
-    GemmProfiler& pf = gemm_profiler();
-    const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
-    if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
-    hipLaunchKernelGGL((gemm_skinny_kernel<TI, TO>), dim3(grid), dim3(256), 0, s, a);
-    if (prof) {
-        (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
-        pf.cfg_of[pf.n] = 2;
-        pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
-        pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * a.N * sizeof(TO) * (a.R ? 2.0 : 1.0);
-        ++pf.n;
-    }
-    return (int)hipGetLastError();
 }
 
 }  // namespace sa

@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "decode_attn.h"
 #include "attn_mfma.h"
+#include "rec_prep.h"
 
 namespace sa {
 
@@ -563,11 +564,7 @@ struct RecModel : RecBase {
         const int* act = active_dev + h.r0;
         const int* rl = row_len + h.r0;
         int rc, S = 1;
-        if (tuning().qkv_skinny) {
-            SkinnyArgs<T, float> a{hh, Hd, WD(l, SA_RD_QKV_W), Hd, h.part, qkv_d, nullptr, nullptr, 0, M, qkv_d, Hd};
-            if ((rc = launch_gemm_skinny<T, float>(a, s))) return rc;
-            S = 1;                                           // one fp32 slab, combined with the bias by the attention kernel
-        } else if ((rc = splitk_gemm(hh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, h.part, &S, s))) return rc;
+        if ((rc = splitk_gemm(hh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, h.part, &S, s))) return rc;
         dim3 grid(M, nkv), block(256);
         const int G = nq / nkv;
 #define SA_DEC_LAUNCH(KERN, LDS)                                                                                            \
@@ -600,20 +597,9 @@ struct RecModel : RecBase {
 #undef SA_DEC_MFMA
 #undef SA_DEC_LAUNCH
         if ((rc = (int)hipGetLastError())) return rc;
-        if (tuning().o_skinny) {
-            // o-projection written once with the residual added (x <- x + attn . Wo^T), then gate|up reads the RAW x and folds
-            // the post-attention RMSNorm into its own main loop (ROWNORM; the norm's gain lives in the gate|up weight columns)
-            SkinnyArgs<T, T> a{at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, x, Hd, nullptr, x, Hd, M, Hd, nq * d};
-            if ((rc = launch_gemm_skinny<T, T>(a, s))) return rc;
-            GemmArgs<T, T> g{x, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd};
-            g.norm_eps = c.dec_eps;
-            if ((rc = launch_gemm_cfg<T, T, 64, 64, 2, 2, EPI_SWIGLU, false, 2, true>(g, s))) return rc;
-        } else {
-            // (the LN2 gain is folded into the gate|up weights, its slot holds ones: the reduce kernel emits the plain normalised rows)
-            if ((rc = splitk_gemm(at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, h.part, &S, s))) return rc;
-            if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s))) return rc;
-            if ((rc = gemm<EPI_SWIGLU>(hh, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
-        }
+        if ((rc = splitk_gemm(at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, h.part, &S, s))) return rc;
+        if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s))) return rc;
+        if ((rc = gemm<EPI_SWIGLU>(hh, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
         if ((rc = splitk_gemm(ml, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, h.part, &S, s))) return rc;
         const bool last = (l + 1 == c.dec_layers);
         return reduce_residual_norm(S, M, h.part, x, last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1),
@@ -1008,38 +994,15 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
     return SA_ERR_UNSUPPORTED;
 }
 
-int surya_op_gemm_skinny(int dtype, int out_f32, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, const void* bias,
-                         const void* R, long ldr, int M, int N, int K, void* stream) {
-    if (!X || !W || !C) return SA_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == SA_DTYPE_F32) {
-        SkinnyArgs<float, float> a{(const float*)X, ldx, (const float*)W, ldw, (float*)C, ldc, (const float*)bias, (const float*)R, ldr, M, N, K};
-        return launch_gemm_skinny<float, float>(a, s);
-    }
-    if (dtype != SA_DTYPE_BF16) return SA_ERR_UNSUPPORTED;
-    if (out_f32) {
-        SkinnyArgs<bf16_t, float> a{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (float*)C, ldc, (const bf16_t*)bias, (const float*)R, ldr, M, N, K};
-        return launch_gemm_skinny<bf16_t, float>(a, s);
-    }
-    SkinnyArgs<bf16_t, bf16_t> a{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)R, ldr, M, N, K};
-    return launch_gemm_skinny<bf16_t, bf16_t>(a, s);
-}
-
-/* SwiGLU GEMM with the RMSNorm of the X rows folded in (ROWNORM): C[M, N/2] = silu(g) * u of (x * rstd(x)) . W^T, W rows
- * interleaved (gate, up). Test hook for the decode gate|up path. */
-int surya_op_gemm_rownorm_swiglu(int dtype, const void* X, long ldx, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
-                                 float eps, void* stream) {
-    if (!X || !W || !C) return SA_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == SA_DTYPE_F32) {
-        GemmArgs<float, float> g{(const float*)X, ldx, (const float*)W, ldw, (float*)C, ldc, nullptr, nullptr, 0, M, N, K};
-        g.norm_eps = eps;
-        return launch_gemm_cfg<float, float, 64, 64, 2, 2, EPI_SWIGLU, false, 2, true>(g, s);
-    }
-    if (dtype != SA_DTYPE_BF16) return SA_ERR_UNSUPPORTED;
-    GemmArgs<bf16_t, bf16_t> g{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)C, ldc, nullptr, nullptr, 0, M, N, K};
-    g.norm_eps = eps;
-    return launch_gemm_cfg<bf16_t, bf16_t, 64, 64, 2, 2, EPI_SWIGLU, false, 2, true>(g, s);
+int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
+                         int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
+                         int any_stage1, void* stream) {
+    if (!pages || !lines || !tiles || !mean || !std || n_lines < 0 || patch_size <= 0 || merge_size <= 0) return SA_ERR_ARG;
+    sa::prep::PrepArgs p;
+    p.pages = pages; p.lines = reinterpret_cast<const sa::prep::LineDesc*>(lines); p.n_lines = n_lines;
+    p.mask = mask_arena; p.mid = mid_arena; p.tiles = tiles; p.ps = patch_size; p.merge = merge_size; p.pad = pad_value;
+    for (int i = 0; i < 3; ++i) { p.mean[i] = mean[i]; p.std[i] = std[i]; }
+    return sa::prep::prep_run(p, any_poly, any_stage1, (hipStream_t)stream);
 }
 
 int surya_set_tuning(const char* key, int value) {
@@ -1048,7 +1011,7 @@ int surya_set_tuning(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"graph", &t.graph}, {"dual", &t.dual}, {"dual_min", &t.dual_min}, {"split_tile", &t.split_tile},
         {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
-        {"gu_tile", &t.gu_tile}, {"o_skinny", &t.o_skinny}, {"qkv_skinny", &t.qkv_skinny}, {"head_tile", &t.head_tile}, {"bigtile", &t.bigtile}, {"glds", &t.glds}};
+        {"gu_tile", &t.gu_tile}, {"head_tile", &t.head_tile}, {"bigtile", &t.bigtile}, {"glds", &t.glds}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) { *e.v = value; return SA_OK; }
     return SA_ERR_ARG;

@@ -33,6 +33,7 @@ from ..common.predictor import BasePredictor, ModelLoader
 from ..config import RecConfig, rec_config
 from ..settings import settings
 from .model import HipRecModel
+from .preprocess_gpu import DevicePreprocessor, LineRef, bbox_ref, poly_ref
 from .postprocess import (clean_close_polygons, clean_math_tags, detect_repeat_token, fix_unbalanced_tags,
                           prediction_to_polygon_batch, sort_text_lines, unwrap_math, words_from_chars)
 from .processor import NOMATH_TOKEN, SuryaOCRProcessor
@@ -210,6 +211,9 @@ class RecognitionPredictor(BasePredictor):
     # None) and the results all-gathered; every rank must pass the same inputs (checked). Off by default.
     shard_lines: bool = settings.SURYA_AMD_SHARD
     process_group = None
+    # Line crops are cut, padded, resized, normalised and patchified on the device (surya_rec_preprocess): the host keeps page
+    # pixels as uint8 and describes lines by reference. RECOGNITION_PREPROCESS_HOST=1 selects the host (numpy) chain instead.
+    device_preprocess: bool = not settings.RECOGNITION_PREPROCESS_HOST
 
     def __init__(self, checkpoint=None, device=None, dtype=None):
         super().__init__(checkpoint, device, dtype)
@@ -231,6 +235,11 @@ class RecognitionPredictor(BasePredictor):
         return len(self.batch_prompt_mapping) - self.num_empty_slots
 
     # --------------------------------------------------------------------------------------------- slicing
+    def _page(self, flat: dict, image) -> int:
+        """Device path: register a page (uint8 HWC) once, return its index for LineRefs."""
+        flat.setdefault("pages", []).append(np.ascontiguousarray(np.asarray(image, dtype=np.uint8)))
+        return len(flat["pages"]) - 1
+
     def detect_and_slice_bboxes(self, images, task_names, det_predictor, detection_batch_size=None, highres_images=None):
         det_predictions = det_predictor(images, batch_size=detection_batch_size)
         flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
@@ -239,11 +248,16 @@ class RecognitionPredictor(BasePredictor):
             if highres:
                 ws, hs = highres.size[0] / image.size[0], highres.size[1] / image.size[1]
                 scaled = [[[int(p[0] * ws), int(p[1] * hs)] for p in poly] for poly in polygons]
-                slices = slice_polys_from_image(self.processor.image_processor(highres), scaled)
-                scales = [(ws, hs)] * len(slices)
+                src, polys_px = highres, scaled
+                scales = [(ws, hs)] * len(polygons)
             else:
-                slices = slice_polys_from_image(self.processor.image_processor(image), polygons)
-                scales = [(1, 1)] * len(slices)
+                src, polys_px = image, polygons
+                scales = [(1, 1)] * len(polygons)
+            if self.device_preprocess:
+                pg = self._page(flat, src)
+                slices = [poly_ref(pg, src.size[0], src.size[1], poly) for poly in polys_px]
+            else:
+                slices = slice_polys_from_image(self.processor.image_processor(src), polys_px)
             flat["slice_map"].append(len(slices))
             flat["slices"].extend(slices)
             flat["polygons"].extend(polygons)
@@ -256,12 +270,16 @@ class RecognitionPredictor(BasePredictor):
         assert bboxes is not None or polygons is not None
         flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
         for idx, image in enumerate(images):
-            arr = self.processor.image_processor(image)
+            dev = self.device_preprocess and (polygons is None or all(len(pl) == 4 for pl in polygons[idx]))
+            arr = None if dev else self.processor.image_processor(image)
+            pg = self._page(flat, image) if dev else -1
             if polygons is not None:
                 polys = polygons[idx]
-                slices = slice_polys_from_image(arr, polys)
+                slices = ([poly_ref(pg, image.size[0], image.size[1], pl) for pl in polys] if dev
+                          else slice_polys_from_image(arr, polys))
             else:
-                slices = slice_bboxes_from_image(arr, bboxes[idx])
+                slices = ([bbox_ref(pg, image.size[0], image.size[1], b) for b in bboxes[idx]] if dev
+                          else slice_bboxes_from_image(arr, bboxes[idx]))
                 polys = [[[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]] for b in bboxes[idx]]
             flat["slice_map"].append(len(slices))
             flat["slices"].extend(slices)
@@ -288,6 +306,30 @@ class RecognitionPredictor(BasePredictor):
             batch.append({"task": task, "inputs": [{"type": "image", "image": image, "rotated": False},
                                                    {"type": "text", "text": text.strip(), "math": math_mode}]})
         return batch
+
+    def preprocess_prompts_device(self, prompts: List[RecognitionPrompt], pages):
+        """Device path: prompts whose `image` is a LineRef -> one surya_rec_preprocess call; prompt ids on the host."""
+        if getattr(self, "_prep", None) is None:
+            self._prep = DevicePreprocessor(self.model.device, self.processor.patch_size, self.processor.merge_size,
+                                            settings.RECOGNITION_PAD_VALUE, self.processor.image_mean, self.processor.image_std)
+        pages = list(pages)
+        refs = []
+        for p in prompts:
+            ln = p.image
+            if ln.size == 0:          # the reference substitutes a blank crop of the task size (:272-278): a black page of that size
+                size = self.tasks[p.task_name]["img_size"]
+                pages.append(np.zeros((size[1], size[0], 3), np.uint8))
+                ln = LineRef(len(pages) - 1, 0, 0, size[0], size[1])
+            refs.append(ln)
+        tiles, offs, grids = self._prep(pages, refs, [self.tasks[p.task_name]["img_size"] for p in prompts])
+        m2 = self.processor.merge_size ** 2
+        ids = []
+        for p, (gh, gw) in zip(prompts, grids):
+            text = p.text or ""
+            if len(text) > self.tasks[p.task_name]["max_tokens"]:
+                text = ""
+            ids.append(self.processor.prompt_ids(gh * gw // m2, p.task_name, text.strip(), p.math_mode, False))
+        return tiles, offs, grids, ids
 
     def preprocess_prompts(self, prompts: List[RecognitionPrompt]):
         """All prompts -> (device tiles [sum P, 588], per-prompt tile offsets, grids, prompt ids)."""
@@ -316,7 +358,10 @@ class RecognitionPredictor(BasePredictor):
         for idx, (img, txt, task) in enumerate(zip(flat["slices"], flat["input_text"], flat["task_names"])):
             prompts.append(RecognitionPrompt(id=idx, task_name=task, text=txt, image=img, math_mode=math_mode))
             max_tokens[idx] = settings.RECOGNITION_MAX_TOKENS or self.tasks[task]["max_tokens"]
-        tiles, tile_offs, grids, prompt_ids = self.preprocess_prompts(prompts)
+        if prompts and isinstance(prompts[0].image, LineRef):
+            tiles, tile_offs, grids, prompt_ids = self.preprocess_prompts_device(prompts, flat.get("pages", []))
+        else:
+            tiles, tile_offs, grids, prompt_ids = self.preprocess_prompts(prompts)
         return {"prompts": prompts, "max_tokens": max_tokens, "tiles": tiles, "tile_offs": tile_offs, "grids": grids,
                 "prompt_ids": prompt_ids}
 
@@ -453,12 +498,18 @@ class RecognitionPredictor(BasePredictor):
             return self.prediction_loop(flat, recognition_batch_size, math_mode)
         dev = sdist.collective_device(self.model.device, group)
         shapes = np.asarray([s.shape[:2] for s in flat["slices"]], np.int64).reshape(-1, 2)
-        probe = b"".join(np.ascontiguousarray(flat["slices"][i]).tobytes()[:4096] for i in range(0, n, max(1, n // 16)))
+        if n and isinstance(flat["slices"][0], LineRef):      # device path: lines are references into the uploaded pages
+            probe = b"".join(np.asarray([(l.page, l.x0, l.y0, l.x1, l.y1) for l in flat["slices"]], np.int64).tobytes()
+                             for _ in (0,)) + b"".join(pg.reshape(-1)[:4096].tobytes() for pg in flat.get("pages", [])[:16])
+        else:
+            probe = b"".join(np.ascontiguousarray(flat["slices"][i]).tobytes()[:4096] for i in range(0, n, max(1, n // 16)))
         sdist.assert_same_inputs([n, zlib.crc32(shapes.tobytes()), zlib.crc32(probe)], group, dev)
         if n == 0:
             return self.prediction_loop(flat, recognition_batch_size, math_mode)
         mine = sdist.shard_indices(n, world, rank)
         local = {k: [flat[k][i] for i in mine] for k in ("slices", "input_text", "task_names")}
+        if "pages" in flat:
+            local["pages"] = flat["pages"]
         max_tokens = max(settings.RECOGNITION_MAX_TOKENS or self.tasks[t]["max_tokens"] for t in flat["task_names"])
         if mine:
             toks, boxes, scores = self.prediction_loop(local, recognition_batch_size, math_mode)

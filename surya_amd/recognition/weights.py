@@ -107,11 +107,7 @@ def repack_rec_weights(cfg: RecConfig, sd: Dict[str, torch.Tensor], dtype: torch
         put(b + L.RD_QKV_B, torch.cat([f(p + "self_attn.q_proj.bias"), f(p + "self_attn.k_proj.bias"),
                                        f(p + "self_attn.v_proj.bias")], 0))
         put(b + L.RD_O_W, f(p + "self_attn.o_proj.weight"))
-        # The post-attention RMSNorm's gain is folded into the gate / up weight COLUMNS (one rounding of W * g to the compute
-        # dtype): the decode path normalises the rows inside the gate|up GEMM (gemm.h ROWNORM) and never runs a separate norm;
-        # the LN2 slot keeps ones so every stand-alone norm kernel that still sees it (prefill) emits the plain normalised rows.
-        g2 = f(p + "post_attention_layernorm.weight")
-        put(b + L.RD_LN2, torch.ones_like(g2))
-        put(b + L.RD_GU_W, _interleave(f(p + "mlp.gate_proj.weight") * g2[None, :], f(p + "mlp.up_proj.weight") * g2[None, :], Idp))
+        put(b + L.RD_LN2, f(p + "post_attention_layernorm.weight"))
+        put(b + L.RD_GU_W, _interleave(f(p + "mlp.gate_proj.weight"), f(p + "mlp.up_proj.weight"), Idp))
         put(b + L.RD_DOWN_W, _pad_k(f(p + "mlp.down_proj.weight"), Idp))
     return out

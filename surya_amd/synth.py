@@ -197,3 +197,30 @@ def make_pages(n: int, size: int = 1024, seed: int = 1234):
             y += lh + int(rng.integers(12, 36))
         pages.append(img)
     return pages
+
+
+def make_pages_with_lines(n: int, size: int = 1024, seed: int = 1234):
+    """make_pages plus, per page, the bounding boxes [x0, y0, x1, y1] of the text rows that were drawn (4 px margin):
+    the line geometry a trained detector would return for these pages (a randomly initialised one finds ~1 box per page)."""
+    rng = np.random.default_rng(seed)
+    pages, boxes = [], []
+    for _ in range(n):
+        img = np.full((size, size, 3), 255, np.uint8)
+        rows = []
+        y = int(rng.integers(20, 60))
+        while y < size - 40:
+            lh = int(rng.integers(14, 28))
+            x = int(rng.integers(30, 90))
+            xs = x
+            xe = size - int(rng.integers(30, 300))
+            last = x
+            while x < xe:
+                ww = int(rng.integers(10, 70))
+                img[y:y + lh, x:min(xe, x + ww)] = rng.integers(0, 80, size=3, dtype=np.uint8)
+                last = min(xe, x + ww)
+                x += ww + int(rng.integers(6, 16))
+            rows.append([max(xs - 4, 0), max(y - 4, 0), min(last + 4, size), min(y + lh + 4, size)])
+            y += lh + int(rng.integers(12, 36))
+        pages.append(img)
+        boxes.append(rows)
+    return pages, boxes

@@ -140,55 +140,3 @@ def test_rmsnorm(hip_lib, dtype, rows, C_):
     ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype)   # Qwen2RMSNorm semantics
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert (y.float() - ref.float()).abs().max().item() <= tol * max(1.0, ref.float().abs().max().item())
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K,res,out_f32", [(256, 1280, 1280, True, False), (256, 1792, 1280, False, True), (200, 1280, 5120, True, False),
-                                               (37, 96, 192, False, False), (1, 1280, 1280, True, False), (256, 1284, 320, False, False)])
-def test_gemm_skinny(hip_lib, dtype, M, N, K, res, out_f32):
-    """The decode regime's small-output projection kernel (wave-private K slices, no split-K slabs) vs torch fp32: bias,
-    residual-after-rounding, fp32 slab output, ragged M / N edges, K slices of unequal length."""
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
-    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(dtype)
-    b = torch.randn(N, device="cuda", generator=g).to(dtype)
-    odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
-    r = torch.randn(M, N, device="cuda", generator=g).to(odt) if res else None
-    c = torch.full((M, N), float("nan"), dtype=odt, device="cuda")
-    dt = L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16
-    rc = hip_lib.surya_op_gemm_skinny(dt, int(out_f32), L.ptr(x), C.c_long(K), L.ptr(w), C.c_long(K), L.ptr(c), C.c_long(N), L.ptr(b),
-                                      L.ptr(r), C.c_long(N if res else 0), M, N, K, _stream())
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-    ref = x.float() @ w.float().t() + b.float()
-    if res:
-        ref = ref.to(odt).float() + r.float()
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
-    err = (c.float() - ref).abs().max().item()
-    assert torch.isfinite(c.float()).all() and err <= tol * max(1.0, ref.abs().max().item()), err
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(256, 10240, 1280), (130, 512, 256), (64, 1536, 1280)])
-def test_gemm_rownorm_swiglu(hip_lib, dtype, M, N, K):
-    """RMSNorm folded into the SwiGLU GEMM (gain folded into the weight columns by the caller): against torch fp32
-    rms_norm -> linear -> silu(gate) * up with a NON-trivial gain, rows of very different scale."""
-    g = torch.Generator(device="cuda").manual_seed(N + K)
-    x = (torch.randn(M, K, device="cuda", generator=g) * (0.1 + 5 * torch.rand(M, 1, device="cuda", generator=g))).to(dtype)
-    gain = 0.5 + torch.rand(K, device="cuda", generator=g)
-    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5          # rows interleaved (gate_j, up_j)
-    wf = (w * gain[None, :]).to(dtype)                                     # what recognition/weights.py stores
-    eps = 1e-6
-    c = torch.full((M, N // 2), float("nan"), dtype=dtype, device="cuda")
-    dt = L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16
-    rc = hip_lib.surya_op_gemm_rownorm_swiglu(dt, L.ptr(x), C.c_long(K), L.ptr(wf), C.c_long(K), L.ptr(c), C.c_long(N // 2), M, N, K,
-                                              C.c_float(eps), _stream())
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-    xf = x.float()
-    h = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
-    y = h @ wf.float().t()
-    ref = F.silu(y[:, 0::2]) * y[:, 1::2]
-    tol = 3e-5 if dtype == torch.float32 else 3e-2
-    err = (c.float() - ref).abs().max().item()
-    assert torch.isfinite(c.float()).all() and err <= tol * max(1.0, ref.abs().max().item()), err

@@ -1,0 +1,113 @@
+"""GPU: line pre-processing on the device (surya_rec_preprocess, csrc/rec_prep.h) vs the host chain it replaces
+(slice_bboxes_from_image / slice_and_pad_poly -> scale_to_fit -> SuryaOCRProcessor.process_and_tile).
+
+  * sizes that need no resize: tiles BIT-IDENTICAL to the reference processor's own output (tests/golden/processor_tiles.pt)
+    and to the host chain (crop, x / 255 in fp64, normalise, merge-block-major patch order);
+  * Lanczos (area clamp) and / or cubic (x28 round-up) sizes: within 2e-5 of the host chain on the normalised values
+    (same taps, same float64 association; sin() of the Lanczos kernel may differ in the last bit);
+  * polygon crops: the pad mask equals fill_poly_mask, so the tolerance is the same;
+  * grids / tile offsets equal; the predictor's device path yields the same tokens as its host path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from surya_amd.config import rec_config
+from surya_amd.settings import settings
+from surya_amd.synth import make_rec_weights, make_line_crops, make_pages
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _processor():
+    from surya_amd.recognition.predictor import RecognitionModelLoader
+    return RecognitionModelLoader({"config": rec_config("REC-TINY"), "state_dict": {}}).processor()
+
+
+def _host_tiles(proc, crop, max_size=(1024, 256)):
+    img = proc.scale_to_fit(crop.astype(np.float32), max_size)
+    return proc.process_and_tile(img)
+
+
+def test_no_resize_tiles_bit_identical_to_reference(hip_lib):
+    from surya_amd.recognition.preprocess_gpu import DevicePreprocessor, LineRef
+    g = torch.load(os.path.join(GOLD, "processor_tiles.pt"))
+    img = g["image"].numpy().astype(np.uint8)                       # 56 x 84: already a multiple of 28, area < 168^2 though
+    # area 56 * 84 < 168^2 would trigger the Lanczos stage in scale_to_fit; the fixture is _process_and_tile alone, so feed a
+    # max/min-neutral call: use the pre-processor with min_size disabled by passing the exact sizes through a big page
+    pre = DevicePreprocessor("cuda:0")
+    big = np.tile(img, (4, 4, 1))                                    # 224 x 336 page, area > 168^2, multiple of 28
+    tiles, offs, grids = pre([big], [LineRef(0, 0, 0, 336, 224)], [(1024, 256)])
+    proc = _processor()
+    ref, grid = proc.process_and_tile(big.astype(np.float32))
+    assert grids == [grid] and int(offs[-1]) == ref.shape[0]
+    assert np.array_equal(tiles.cpu().numpy(), ref)                  # bit-identical
+    # and the reference's own fixture through the same normalise + patch-order code (host side pinned it; device must agree)
+    t2, _ = proc.process_and_tile(g["image"].numpy())
+    assert np.array_equal(t2, g["tiles"].numpy())
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_bench_crops_match_host_chain(hip_lib, seed):
+    """64 x {128..512} crops (bench.py's workload): Lanczos upscale for the small ones, cubic round-up for all."""
+    from surya_amd.recognition.preprocess_gpu import DevicePreprocessor, LineRef
+    proc = _processor()
+    crops = make_line_crops(24, seed=100 + seed)
+    pre = DevicePreprocessor("cuda:0")
+    refs = [LineRef(i, 0, 0, c.shape[1], c.shape[0]) for i, c in enumerate(crops)]
+    tiles, offs, grids = pre(crops, refs, [(1024, 256)] * len(crops))
+    tiles = tiles.cpu().numpy()
+    worst = 0.0
+    for i, c in enumerate(crops):
+        ref, grid = _host_tiles(proc, c)
+        assert grids[i] == grid
+        got = tiles[int(offs[i]): int(offs[i + 1])]
+        assert got.shape == ref.shape
+        worst = max(worst, float(np.abs(got - ref).max()))
+    assert worst <= 2e-5, worst
+
+
+def test_polygon_crops_and_page_bboxes_match_host_chain(hip_lib):
+    from surya_amd.recognition.predictor import slice_bboxes_from_image, slice_and_pad_poly
+    from surya_amd.recognition.preprocess_gpu import DevicePreprocessor, bbox_ref, poly_ref
+    proc = _processor()
+    page = make_pages(1, 512, seed=5)[0]
+    pagef = page.astype(np.float32)
+    rng = np.random.default_rng(3)
+    bboxes = [[10, 20, 300, 60], [0, 0, 512, 40], [400, 100, 520, 170], [50, 300, 51, 380], [30, 200, 480, 420]]
+    polys = []
+    for _ in range(6):
+        cx, cy, L, T, th = rng.uniform(100, 400), rng.uniform(100, 400), rng.uniform(40, 160), rng.uniform(8, 30), rng.uniform(-0.5, 0.5)
+        u, v = np.array([np.cos(th), np.sin(th)]), np.array([-np.sin(th), np.cos(th)])
+        pts = [np.array([cx, cy]) + a * L * u + b * T * v for a, b in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+        polys.append([[int(np.clip(p[0], 0, 511)), int(np.clip(p[1], 0, 511))] for p in pts])
+    refs = [bbox_ref(0, 512, 512, b) for b in bboxes] + [poly_ref(0, 512, 512, p) for p in polys]
+    host_crops = slice_bboxes_from_image(pagef, bboxes) + [slice_and_pad_poly(pagef, p) for p in polys]
+    pre = DevicePreprocessor("cuda:0")
+    tiles, offs, grids = pre([page], refs, [(1024, 256)] * len(refs))
+    tiles = tiles.cpu().numpy()
+    for i, crop in enumerate(host_crops):
+        assert refs[i].shape == crop.shape, (i, refs[i].shape, crop.shape)
+        ref, grid = _host_tiles(proc, crop)
+        assert grids[i] == grid
+        got = tiles[int(offs[i]): int(offs[i + 1])]
+        assert np.abs(got - ref).max() <= 2e-5, (i, float(np.abs(got - ref).max()))
+
+
+def test_predictor_device_and_host_preprocessing_give_same_tokens(hip_lib):
+    from test_gpu_predictors import make_rec_predictor
+    cfg, sd, pred = make_rec_predictor(max_slots=8, max_tokens=8)
+    pages = [Image.fromarray(p) for p in make_pages(2, 256, seed=8)]
+    bboxes = [[[5, 10, 250, 50], [20, 100, 200, 130], [0, 180, 256, 250]], [[30, 30, 120, 60], [10, 200, 240, 240]]]
+    out = {}
+    for dev in (True, False):
+        pred.device_preprocess = dev
+        out[dev] = pred(pages, bboxes=bboxes)
+    for a, b in zip(out[True], out[False]):
+        assert [l.text for l in a.text_lines] == [l.text for l in b.text_lines]
+        assert [l.polygon for l in a.text_lines] == [l.polygon for l in b.text_lines]
+        for la, lb in zip(a.text_lines, b.text_lines):
+            assert [c.polygon for c in la.chars] == [c.polygon for c in lb.chars]

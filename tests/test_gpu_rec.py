@@ -102,13 +102,9 @@ def test_generate_fp32_bit_exact_tokens(hip_lib, cfg_name):
         assert np.allclose(got_scores[i][:L_], scores_ref[i], rtol=2e-3, atol=1e-6)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32])
-def test_norm_gains_are_folded_correctly(hip_lib, dtype):
-    """Non-trivial RMSNorm gains everywhere (the synthetic init uses ones): the post-attention gain is folded into the gate|up
-    weight columns at load time and the decode path normalises inside the GEMM -- tokens must still equal the oracle's, for the
-    default decode path and for the split-K / stand-alone-norm path."""
-    import ctypes as C
-    from surya_amd import _lib as L
+def test_non_trivial_norm_gains(hip_lib):
+    """RMSNorm gains different from one everywhere (the synthetic init uses ones, which would hide a gain applied twice or not
+    at all): fp32 greedy tokens must still equal the oracle's."""
     from surya_amd.recognition.model import HipRecModel
     cfg = rec_config("REC-SMALL")
     sd = dict(make_rec_weights(cfg, 0))
@@ -120,29 +116,21 @@ def test_norm_gains_are_folded_correctly(hip_lib, dtype):
     tiles, seqs = make_prompts(cfg, GRIDS)
     T = 10
     toks_ref, _, _, _ = _oracle_run(cfg, sd, tiles, seqs, T)
-    lib = L.lib()
-    for o_skinny, qkv_skinny in ((1, 0), (0, 0), (1, 1)):
-        L.check(lib.surya_set_tuning(b"o_skinny", C.c_int(o_skinny)), "tuning")
-        L.check(lib.surya_set_tuning(b"qkv_skinny", C.c_int(qkv_skinny)), "tuning")
-        try:
-            m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
-                            dtype=dtype, max_slots=8, max_kv_len=256, max_patches=4096, max_prefill_tokens=1024)
-            slots = list(range(len(seqs)))
-            m.prefill(tiles.cuda(), GRIDS, seqs, slots)
-            tok, _, _ = m.read_outputs(1)
-            got = [[int(tok[0, s])] for s in slots]
-            m.set_active(slots)
-            m.decode(T - 1)
-            tok, _, _ = m.read_outputs(T - 1)
-            for k in range(T - 1):
-                for i, s in enumerate(slots):
-                    got[i].append(int(tok[k, s]))
-            for i in range(len(seqs)):
-                n = len(toks_ref[i])
-                assert got[i][:n] == toks_ref[i], (o_skinny, qkv_skinny, i, got[i][:n], toks_ref[i])
-        finally:
-            L.check(lib.surya_set_tuning(b"o_skinny", C.c_int(1)), "tuning")
-            L.check(lib.surya_set_tuning(b"qkv_skinny", C.c_int(0)), "tuning")
+    m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    dtype=torch.float32, max_slots=8, max_kv_len=256, max_patches=4096, max_prefill_tokens=1024)
+    slots = list(range(len(seqs)))
+    m.prefill(tiles.cuda(), GRIDS, seqs, slots)
+    tok, _, _ = m.read_outputs(1)
+    got = [[int(tok[0, s])] for s in slots]
+    m.set_active(slots)
+    m.decode(T - 1)
+    tok, _, _ = m.read_outputs(T - 1)
+    for k in range(T - 1):
+        for i, s in enumerate(slots):
+            got[i].append(int(tok[k, s]))
+    for i in range(len(seqs)):
+        n = len(toks_ref[i])
+        assert got[i][:n] == toks_ref[i], (i, got[i][:n], toks_ref[i])
 
 
 def test_multi_step_decode_matches_single_steps(hip_lib):

@@ -52,12 +52,9 @@ def main():
         for k, v in kw.items():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
-    base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0, o_skinny=0, qkv_skinny=0)
+    base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0)
     if args.configs == "base":
         variants = [dict()]
-    elif args.configs == "skinny":
-        variants = [dict(), dict(o_skinny=1), dict(o_skinny=1, qkv_skinny=1), dict(qkv_skinny=1), dict(o_skinny=1, split_target=512),
-                    dict(o_skinny=1, split_target=384)]
     elif args.configs == "quick":
         variants = [dict(), dict(dual=1), dict(split_tile=1, gu_tile=1), dict(split_tile=1, gu_tile=1, dual=1)]
     else:
