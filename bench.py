@@ -318,6 +318,13 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
         return d, o, t1 - t0, time.perf_counter() - t1
 
     one()                                                  # warm-up
+    if args.host_profile and rank == 0:
+        import cProfile, pstats
+        for name, fn in (("detect", lambda: det(imgs)), ("recognise", lambda: pred(imgs, bboxes=rows))):
+            pr = cProfile.Profile()
+            pr.enable(); fn(); torch.cuda.synchronize(); pr.disable()
+            print(f"---- e2e host profile: {name}", file=sys.stderr)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     d, o, t_det, t_rec = one()

@@ -228,6 +228,12 @@ int surya_det_destroy(surya_det* h);
  * heatmaps: device fp32 [batch, labels, H, W] (may be NULL); lowres: device fp32 [batch, labels, H/4, W/4] (may be NULL)
  * = the model's own output before the predictor-side upsample. Enqueue only. */
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream);
+/* Same forward from the resized pages themselves: device uint8 [batch, H, W, 3] (RGB, as PIL delivers them). The rescale
+ * (x * 1/255 in fp32) and normalisation ((x - mean) / std) of SegformerImageProcessor._preprocess
+ * (surya/detection/processor.py:126-146) run inside the first layout kernel: bit-identical pixel_values, a quarter of the
+ * PCIe bytes, no per-pixel host work. */
+int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, const float* mean, const float* std, int batch, float* heatmaps,
+                         float* lowres, void* stream);
 
 /* Heat map -> text boxes on the device. Replaces detect_boxes (surya/detection/heatmap.py:27-107:
  * get_dynamic_thresholds :14-24, cv2.connectedComponentsWithStats, per-component cv2.dilate + cv2.minAreaRect + cv2.boxPoints,

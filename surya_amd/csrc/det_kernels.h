@@ -21,6 +21,24 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
     for (int c = 0; c < CP; ++c) Ty<T>::st(o + c, c < C ? in[(b * C + c) * hw + r] : 0.f);
 }
 
+// uint8 RGB pages (NHWC, as PIL hands them over) -> the first activation buffer: SegformerImageProcessor's rescale and
+// normalise (surya/detection/processor.py:126-146: x * (1/255) in fp32, (x - mean) / std) fused into the layout change, so a
+// page crosses PCIe as 3 bytes per pixel instead of 12 and the host never touches its pixels (det side).
+template <typename T>
+__global__ void u8_to_nhwc_kernel(const unsigned char* __restrict__ in, T* __restrict__ out, long P, int CP, float m0, float m1,
+                                  float m2, float s0, float s1, float s2) {
+#pragma clang fp contract(off)
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;      // pixel index over B*H*W
+    if (p >= P) return;
+    const unsigned char* px = in + p * 3;
+    const float k = 1.0f / 255.0f;                                    // np.float32(1 / 255.0)
+    T* o = out + p * CP;
+    Ty<T>::st(o + 0, ((float)px[0] * k - m0) / s0);
+    Ty<T>::st(o + 1, ((float)px[1] * k - m1) / s1);
+    Ty<T>::st(o + 2, ((float)px[2] * k - m2) / s2);
+    for (int c = 3; c < CP; ++c) Ty<T>::st(o + c, 0.f);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution: out[m, n] = act(sum_{ky,kx,ci} in[b, oy*s+ky-p, ox*s+kx-p, ci] * w[n, (ky,kx,ci)] + bias[n]) (+ res)
 //   m = (b, oy, ox) output pixel, weights [Cout][KH*KW*Cin padded to a multiple of the K-tile] (zero padded).

@@ -15,7 +15,8 @@ namespace sa {
 
 struct DetBase {
     virtual ~DetBase() {}
-    virtual int forward(const float* pixels, int B, float* heat, float* lowres, hipStream_t s) = 0;
+    virtual int forward(const float* pixels, const unsigned char* pixels_u8, const float* mean_std, int B, float* heat, float* lowres,
+                        hipStream_t s) = 0;
 };
 
 template <typename T>
@@ -57,15 +58,22 @@ struct DetModel : DetBase {
 
     const T* WT(int idx) const { return idx < 0 ? nullptr : reinterpret_cast<const T*>(w[idx]); }
 
-    int forward(const float* pixels, int B, float* heat, float* lowres, hipStream_t s) override {
+    int forward(const float* pixels, const unsigned char* pixels_u8, const float* ms, int B, float* heat, float* lowres,
+                hipStream_t s) override {
         if (B <= 0 || B > max_batch) return SA_ERR_ARG;
         int rc;
         for (const surya_det_op& op : ops) {
             switch (op.type) {
                 case SA_DET_INPUT: {
                     const long P = (long)B * op.hin * op.win;
-                    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels, bufs[op.out], B,
-                                       op.cin, op.hin, op.win, op.cout);
+                    if (pixels_u8) {
+                        if (op.cin != 3) return SA_ERR_SHAPE;
+                        hipLaunchKernelGGL(u8_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels_u8, bufs[op.out], P,
+                                           op.cout, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5]);
+                    } else {
+                        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels, bufs[op.out], B,
+                                           op.cin, op.hin, op.win, op.cout);
+                    }
                     break;
                 }
                 case SA_DET_CONV: {
@@ -205,7 +213,14 @@ int surya_det_boxes(const float* heat, long page_stride, int batch, int height, 
 
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream) {
     if (!h || !pixel_values || (!heatmaps && !lowres)) return SA_ERR_ARG;
-    return h->impl->forward(pixel_values, batch, heatmaps, lowres, (hipStream_t)stream);
+    return h->impl->forward(pixel_values, nullptr, nullptr, batch, heatmaps, lowres, (hipStream_t)stream);
+}
+
+int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, const float* mean, const float* std, int batch, float* heatmaps,
+                         float* lowres, void* stream) {
+    if (!h || !pixels_nhwc || !mean || !std || (!heatmaps && !lowres)) return SA_ERR_ARG;
+    const float ms[6] = {mean[0], mean[1], mean[2], std[0], std[1], std[2]};
+    return h->impl->forward(nullptr, pixels_nhwc, ms, batch, heatmaps, lowres, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -229,21 +229,74 @@ __global__ __launch_bounds__(256) void post_merge_kernel(PostArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ 3. flatten + statistics
+// A page's text mask is often a few LARGE components (on noise-like maps one component can hold half the page): per-pixel
+// atomics on one root's six words serialise in L2 (measured 65 ms for a 16-page batch, r02h profile). Pixels are visited in raster
+// order, so a wave usually sees ONE root: it reduces its 64 pixels with cross-lane ops, the workgroup's waves are merged in LDS
+// when they agree, and one lane issues the six atomics -- 256x fewer on the hot addresses. Mixed waves fall back to per-lane.
+struct WaveAgg { int root, cnt, minx, maxx, miny, maxy; unsigned int maxv; };
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void post_stats_kernel(PostArgs p) {
+    __shared__ WaveAgg agg[4];
     const int b = blockIdx.y, N = p.H * p.W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
     const long base = (long)b * N;
     int* lab = p.label + base;
-    if (lab[i] < 0) return;
-    const int r = uf_find(lab, (int)i);
-    lab[i] = r;
-    const int x = (int)(i % p.W), y = (int)(i / p.W);
-    const unsigned int v = __float_as_uint(p.heat[(long)b * p.page_stride + i]);
-    atomicAdd(&p.area[base + r], 1);
-    atomicMin(&p.minx[base + r], x); atomicMax(&p.maxx[base + r], x);
-    atomicMin(&p.miny[base + r], y); atomicMax(&p.maxy[base + r], y);
-    atomicMax(&p.maxv[base + r], v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool fg = i < N && lab[i] >= 0;
+    int r = -1, x = 0, y = 0;
+    unsigned int v = 0;
+    if (fg) {
+        r = uf_find(lab, (int)i);
+        lab[i] = r;
+        x = (int)(i % p.W); y = (int)(i / p.W);
+        v = __float_as_uint(p.heat[(long)b * p.page_stride + i]);
+    }
+    const unsigned long long fgm = __ballot(fg);
+    const int r0 = fgm ? __shfl(r, __builtin_ctzll(fgm), 64) : -1;
+    const bool uniform = fgm && __ballot(fg && r != r0) == 0;
+    if (uniform) {
+        const int cnt = __builtin_popcountll(fgm);
+        const int mnx = wave_min_i(fg ? x : 0x7fffffff), mxx = wave_max_i(fg ? x : -1);
+        const int mny = wave_min_i(fg ? y : 0x7fffffff), mxy = wave_max_i(fg ? y : -1);
+        const unsigned int mv = (unsigned int)wave_max_i((int)(fg ? v : 0u));          // positive floats: bits order like ints
+        if (lane == 0) agg[wave] = WaveAgg{r0, cnt, mnx, mxx, mny, mxy, mv};
+    } else {
+        if (lane == 0) agg[wave].root = -1;
+        if (fg) {
+            atomicAdd(&p.area[base + r], 1);
+            atomicMin(&p.minx[base + r], x); atomicMax(&p.maxx[base + r], x);
+            atomicMin(&p.miny[base + r], y); atomicMax(&p.maxy[base + r], y);
+            atomicMax(&p.maxv[base + r], v);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 4; ++w) {
+            if (agg[w].root < 0) continue;
+            WaveAgg a = agg[w];
+            for (int u = w + 1; u < 4; ++u)
+                if (agg[u].root == a.root) {
+                    a.cnt += agg[u].cnt; a.minx = min(a.minx, agg[u].minx); a.maxx = max(a.maxx, agg[u].maxx);
+                    a.miny = min(a.miny, agg[u].miny); a.maxy = max(a.maxy, agg[u].maxy); a.maxv = max(a.maxv, agg[u].maxv);
+                    agg[u].root = -1;
+                }
+            atomicAdd(&p.area[base + a.root], a.cnt);
+            atomicMin(&p.minx[base + a.root], a.minx); atomicMax(&p.maxx[base + a.root], a.maxx);
+            atomicMin(&p.miny[base + a.root], a.miny); atomicMax(&p.maxy[base + a.root], a.maxy);
+            atomicMax(&p.maxv[base + a.root], a.maxv);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------- 4. select
@@ -351,16 +404,33 @@ __global__ __launch_bounds__(256) void post_scatter_kernel(PostArgs p) {
 __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs p) {
     const int b = blockIdx.y, N = p.H * p.W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N || p.st[b].overflow) return;
+    if (p.st[b].overflow) return;
     const long base = (long)b * N;
-    const int r = p.label[base + i];
-    if (r < 0) return;
-    const int idx = p.area[base + r];
-    if (idx < 0) return;
-    const int x = (int)(i % p.W), y = (int)(i / p.W);
-    const int o = p.comp_rowoff[b * p.max_boxes + idx] + (y - p.comp[b * p.max_boxes + idx].y0);
-    atomicMin(&p.rmin[(long)b * p.row_cap + o], x);
-    atomicMax(&p.rmax[(long)b * p.row_cap + o], x);
+    int idx = -1, x = 0, y = 0;
+    if (i < N) {
+        const int r = p.label[base + i];
+        if (r >= 0) idx = p.area[base + r];
+        x = (int)(i % p.W); y = (int)(i / p.W);
+    }
+    // same aggregation as post_stats_kernel: a wave inside one row of one kept component sends one min and one max
+    const bool on = idx >= 0;
+    const unsigned long long onm = __ballot(on);
+    if (!onm) return;
+    const int first = __builtin_ctzll(onm);
+    const int idx0 = __shfl(idx, first, 64), y0 = __shfl(y, first, 64);
+    const bool uniform = __ballot(on && (idx != idx0 || y != y0)) == 0;
+    if (uniform) {
+        const int mn = wave_min_i(on ? x : 0x7fffffff), mx = wave_max_i(on ? x : -1);
+        if ((threadIdx.x & 63) == first) {
+            const long o = (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + idx0] + (y0 - p.comp[b * p.max_boxes + idx0].y0);
+            atomicMin(&p.rmin[o], mn);
+            atomicMax(&p.rmax[o], mx);
+        }
+    } else if (on) {
+        const long o = (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + idx] + (y - p.comp[b * p.max_boxes + idx].y0);
+        atomicMin(&p.rmin[o], x);
+        atomicMax(&p.rmax[o], x);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------- 6. geometry
@@ -368,8 +438,11 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs p) {
 // chain, the first-strictly-smaller tie rule of the calipers) run on lane 0 out of LDS.
 __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
-    if (p.st[b].overflow || ci >= p.st[b].n_sel) return;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    if (p.st[b].overflow) return;
+    __shared__ int m_sh;
+    for (int ci = blockIdx.x; ci < p.st[b].n_sel; ci += gridDim.x) {       // grid-stride over the page's components
+    __syncthreads();
     const CompStats c = p.comp[b * p.max_boxes + ci];
     const int* rmin = p.rmin + (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + ci];
     const int* rmax = p.rmax + (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + ci];
@@ -389,7 +462,6 @@ __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l = min(l, __shfl_xor(l, o, 64)); r = max(r, __shfl_xor(r, o, 64)); }
     __syncthreads();
-    __shared__ int m_sh;
     if (lane == 0) m_sh = hull_from_rows(pts, n, stack);
     __syncthreads();
     const int m = m_sh;
@@ -424,6 +496,7 @@ __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
     if (lane == 0) {
         const float mc = p.st[b].max_conf;
         p.conf[b * p.max_boxes + ci] = mc > 0.f ? c.maxv / mc : c.maxv;
+    }
     }
 }
 
@@ -502,7 +575,7 @@ static inline int post_run(const float* heat, long page_stride, int B, int H, in
     if (lds > 160 * 1024) return SA_ERR_UNSUPPORTED;
     static AttrOnce attr;
     attr.ensure(post_boxes_kernel, lds);
-    hipLaunchKernelGGL(post_boxes_kernel, dim3(max_boxes, B), dim3(64), lds, s, p);
+    hipLaunchKernelGGL(post_boxes_kernel, dim3(std::min(max_boxes, 256), B), dim3(64), lds, s, p);
     return (int)hipGetLastError();
 }
 

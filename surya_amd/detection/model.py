@@ -83,6 +83,22 @@ class HipDetModel:
                 "surya_det_forward")
         return (heat, low) if want_lowres else heat
 
+    def forward_u8(self, pages_u8: torch.Tensor, mean, std, want_lowres: bool = False):
+        """pages cuda uint8 [B, H, W, 3] (already at the processor size) -> heat maps; rescale + normalise run on the device."""
+        assert pages_u8.is_cuda and pages_u8.dtype == torch.uint8 and pages_u8.is_contiguous()
+        B = pages_u8.shape[0]
+        assert tuple(pages_u8.shape[1:]) == (self.height, self.width, 3) and B <= self.max_batch
+        torch.cuda.set_device(self.device)
+        heat = torch.empty((B, self.cfg.num_labels, self.height, self.width), dtype=torch.float32, device=self.device)
+        low = torch.empty((B, self.cfg.num_labels, self.height // 4, self.width // 4), dtype=torch.float32,
+                          device=self.device) if want_lowres else None
+        m = (C.c_float * 3)(*[float(np.float32(v)) for v in mean])
+        sd = (C.c_float * 3)(*[float(np.float32(v)) for v in std])
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.surya_det_forward_u8(self.handle, L.ptr(pages_u8), m, sd, C.c_int(B), L.ptr(heat), L.ptr(low), stream),
+                "surya_det_forward_u8")
+        return (heat, low) if want_lowres else heat
+
 
 class HipDetPost:
     """Heat map -> boxes on the device (surya_det_boxes, csrc/det_post.h): thresholds, 4-connected labelling, per-component

@@ -169,6 +169,14 @@ class DetectionPredictor(BasePredictor):
                 out.append(result_from_device_boxes(bx, cf, list(psize), sizes[pg], hi, ai))
         return out
 
+    def resize_image(self, img: Image.Image) -> np.ndarray:
+        """The reference's double LANCZOS resize to the processor size (surya/detection/__init__.py:50-57), uint8 HWC."""
+        new_size = (self.processor.size["width"], self.processor.size["height"])
+        if img.size != new_size:
+            img.thumbnail(new_size, Image.Resampling.LANCZOS)
+            img = img.resize(new_size, Image.Resampling.LANCZOS)
+        return np.asarray(img, dtype=np.uint8)
+
     def prepare_image(self, img: Image.Image) -> torch.Tensor:
         new_size = (self.processor.size["width"], self.processor.size["height"])
         img.thumbnail(new_size, Image.Resampling.LANCZOS)          # the reference's double resize (:50-57)
@@ -204,16 +212,23 @@ class DetectionPredictor(BasePredictor):
                 parts.extend(ps)
                 split_index.extend([k] * len(ps))
                 split_heights.extend(hs)
+            # pages go to the device as uint8 at the processor size; rescale + normalise happen in the model's first kernel
+            pw = self.processor.size["width"]
+            host = torch.empty((len(parts), ph, pw, 3), dtype=torch.uint8).pin_memory()
+            hv = host.numpy()
+
+            def put(k):
+                hv[k] = self.resize_image(parts[k])
             if len(parts) > 4:
                 with ThreadPoolExecutor(min(8, len(parts))) as ex:      # PIL resizes release the GIL
-                    prepared = list(ex.map(self.prepare_image, parts))
+                    list(ex.map(put, range(len(parts))))
             else:
-                prepared = [self.prepare_image(p) for p in parts]
-            tiles = torch.stack(prepared, 0).contiguous()
+                for k in range(len(parts)):
+                    put(k)
             heat_parts = []
-            for s in range(0, tiles.shape[0], self.model.max_batch):        # a single page may exceed max_batch tiles
-                chunk = tiles[s: s + self.model.max_batch].pin_memory().to(self.model.device, non_blocking=True)
-                heat_parts.append(self.model.forward(chunk))
+            for s in range(0, len(parts), self.model.max_batch):            # a single page may exceed max_batch tiles
+                chunk = host[s: s + self.model.max_batch].to(self.model.device, non_blocking=True)
+                heat_parts.append(self.model.forward_u8(chunk, self.processor.image_mean, self.processor.image_std))
             heat = heat_parts[0] if len(heat_parts) == 1 else torch.cat(heat_parts, 0)
             yield heat, split_index, [min(h, ph) for h in split_heights], [orig_sizes[j] for j in idxs]
 

@@ -523,53 +523,79 @@ class RecognitionPredictor(BasePredictor):
 
     # ------------------------------------------------------------------------------------- output assembly
     def get_bboxes_text(self, flat, predicted_tokens, scores, predicted_polygons, drop_repeated_text=False) -> list:
-        """Token stream -> TextChar list per line (reference :609-771): the stream is cut into runs of math-BPE ids,
-        single special tags, and UTF-16 ids; only the last kind carries per-character boxes."""
+        """Token stream -> per line (texts, confidences, bbox_valid, polygons [n, 4, 2]) (reference :609-771): the stream is cut
+        into runs of math-BPE ids, single special tags and UTF-16 ids; only the last kind carries per-character boxes.
+        Array form of the reference's per-token loop: run boundaries, close-polygon filtering and the
+        char -> box index map are numpy expressions per line; Python only walks the (few) runs of a line. Lines come back as
+        None (<NOP>), or a tuple that `_chars_of` turns into TextChars after the geometry has been applied in bulk."""
         tk = self.processor.ocr_tokenizer
-        blank = [[0, 0], [0, 1], [1, 1], [1, 0]]
+        eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
+        blank = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float64)
         out = []
         for tokens, polys, sc in zip(predicted_tokens, predicted_polygons, scores):
-            if self.processor.no_output_token in tokens:
+            if nop in tokens:
                 out.append(None)
                 continue
             if drop_repeated_text and detect_repeat_token(tokens):
-                out.append([TextChar(text="", polygon=blank, confidence=0, bbox_valid=False)])
+                out.append(([""], np.zeros(1), np.zeros(1, bool), blank[None].copy()))
                 continue
-            polys = np.asarray(polys[: len(tokens)]).tolist()
-            runs, cur, cur_kind = [], [], None
-            for bbox, tid, s in zip(polys, tokens, sc):
-                if tid in (self.processor.eos_token_id, self.processor.pad_token_id):
-                    break
-                kind = "qwen" if tid < tk.qwen_offset else ("special" if tid < tk.special_token_offset else "ocr")
-                if cur and (kind != cur_kind or kind == "special"):
-                    runs.append((cur_kind, cur))
-                    cur = []
-                cur.append((tid, s, bbox))
-                cur_kind = kind
-            if cur:
-                runs.append((cur_kind, cur))
-            chars = []
-            for kind, items in runs:
-                ids = [i[0] for i in items]
-                confs = [i[1] for i in items]
-                if kind == "ocr":
+            tid = np.asarray(tokens, np.int64)
+            stop = np.nonzero((tid == eos) | (tid == pad))[0]
+            n = int(stop[0]) if len(stop) else len(tid)
+            n = min(n, len(polys), len(sc))              # zip() of the reference stops at the shortest of the three
+            if n == 0:
+                out.append(([], np.zeros(0), np.zeros(0, bool), np.zeros((0, 4, 2))))
+                continue
+            tid = tid[:n]
+            P = np.asarray(polys[:n], np.float64)
+            conf = np.asarray(sc[:n], np.float64)
+            kind = np.where(tid < tk.qwen_offset, 0, np.where(tid < tk.special_token_offset, 1, 2))
+            starts = np.nonzero(np.r_[True, (kind[1:] != kind[:-1]) | (kind[1:] == 1)])[0]
+            ends = np.r_[starts[1:], n]
+            texts, cf, valid, pp = [], [], [], []
+            for a_, b_ in zip(starts.tolist(), ends.tolist()):
+                k = int(kind[a_])
+                ids = tid[a_:b_].tolist()
+                if k == 2:
                     text = tk.decode(ids, task=TaskNames.ocr_with_boxes)
-                    boxes = clean_close_polygons([i[2] for i in items])
-                    bi = 0
-                    for ch in text:
-                        chars.append(TextChar(text=ch, polygon=boxes[bi], confidence=confs[bi], bbox_valid=True))
-                        if bi < len(boxes) - 1:
-                            bi += 1
-                elif kind == "special":
-                    text = tk.decode(ids, task=TaskNames.ocr_without_boxes)
-                    if text == NOMATH_TOKEN or re.match(r"<SCRIPT-\w+>", text):
+                    if not text:
                         continue
-                    chars.append(TextChar(text=text, polygon=blank, confidence=confs[0], bbox_valid=False))
+                    Pr = P[a_:b_]
+                    # clean_close_polygons: drop a box whose 4 corners all sit within 0.1 of the PREVIOUS box (util.py:100-120)
+                    keep = np.r_[True, np.abs(Pr[1:] - Pr[:-1]).max(axis=(1, 2)) > 0.1] if b_ - a_ > 1 else np.ones(1, bool)
+                    boxes = Pr[keep]
+                    bi = np.minimum(np.arange(len(text)), len(boxes) - 1)
+                    texts.extend(text)
+                    cf.append(conf[a_:b_][bi]); valid.append(np.ones(len(text), bool)); pp.append(boxes[bi])
                 else:
-                    text = tk.decode(ids, task=TaskNames.block_without_boxes)
-                    chars.append(TextChar(text=text, polygon=blank, confidence=confs[0], bbox_valid=False))
-            out.append(chars)
+                    text = tk.decode(ids, task=TaskNames.ocr_without_boxes if k == 1 else TaskNames.block_without_boxes)
+                    if k == 1 and (text == NOMATH_TOKEN or re.match(r"<SCRIPT-\w+>", text)):
+                        continue
+                    texts.append(text)
+                    cf.append(conf[a_:a_ + 1]); valid.append(np.zeros(1, bool)); pp.append(blank[None])
+            if not texts:
+                out.append(([], np.zeros(0), np.zeros(0, bool), np.zeros((0, 4, 2))))
+            else:
+                out.append((texts, np.concatenate(cf), np.concatenate(valid), np.concatenate(pp)))
         return out
+
+    @staticmethod
+    def _chars_of(line, res_scale, line_bbox) -> List[TextChar]:
+        """TextChars of one line with the reference's per-char geometry (:905-909: rescale by the high-res factor with int()
+        truncation, shift to the line's corner, clamp into the line's bbox) applied to all of the line's polygons at once;
+        objects are built without re-validating fields that were just computed (pydantic model_construct)."""
+        texts, conf, valid, P = line
+        if not texts:
+            return []
+        P = P.copy()
+        P[..., 0] = np.trunc(P[..., 0] * (1.0 / res_scale[0])) + line_bbox[0]
+        P[..., 1] = np.trunc(P[..., 1] * (1.0 / res_scale[1])) + line_bbox[1]
+        np.clip(P[..., 0], line_bbox[0], line_bbox[2], out=P[..., 0])
+        np.clip(P[..., 1], line_bbox[1], line_bbox[3], out=P[..., 1])
+        polys = P.tolist()
+        conf = [0 if c != c else c for c in conf.tolist()]
+        return [TextChar.model_construct(polygon=pg, confidence=c, text=t, bbox_valid=v)
+                for pg, c, t, v in zip(polys, conf, texts, valid.tolist())]
 
     def __call__(self, images: List[Image.Image], task_names: List[str] | None = None, det_predictor=None,
                  detection_batch_size: int | None = None, recognition_batch_size: int | None = None,
@@ -622,15 +648,12 @@ class RecognitionPredictor(BasePredictor):
             lines = []
             for chars, polygon, res_scale in zip(restored[start:end], flat["polygons"][start:end],
                                                  flat["res_scales"][start:end]):
-                if not chars:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
+                if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
                     lines.append(TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True))
                     continue
-                confidence = float(np.mean([c.confidence for c in chars]))
+                confidence = float(np.mean(chars[1]))
                 box = PolygonBox(polygon=polygon)
-                for c in chars:
-                    c.rescale(res_scale, (1, 1))
-                    c.shift(box.bbox[0], box.bbox[1])
-                    c.clamp(box.bbox)
+                chars = self._chars_of(chars, res_scale, box.bbox)
                 chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
                 text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
                 lines.append(TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,

@@ -68,3 +68,19 @@ def test_det_batch_and_capacity(hip_lib):
     assert torch.equal(full[1:2], one)                  # pages are independent: batch composition changes nothing
     with pytest.raises(AssertionError):
         m.forward(torch.zeros(4, 3, 128, 128, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_det_forward_from_uint8_pages_is_bit_identical(hip_lib, dtype):
+    """surya_det_forward_u8 (rescale + normalise inside the first layout kernel) == surya_det_forward on the host-normalised
+    pixel_values of the same pages (SegformerImageProcessor arithmetic, surya/detection/processor.py:126-146)."""
+    import numpy as np
+    from surya_amd.detection.predictor import SegformerImageProcessor
+    cfg, sd, m = build("DET-TINY", 128, dtype)
+    pages = make_pages(3, 128, seed=11)
+    proc = SegformerImageProcessor({"height": 128, "width": 128})
+    x = torch.from_numpy(np.stack([proc(p)["pixel_values"][0] for p in pages])).cuda().contiguous()
+    ref = m.forward(x)
+    u8 = torch.from_numpy(np.stack(pages)).cuda().contiguous()
+    got = m.forward_u8(u8, proc.image_mean, proc.image_std)
+    assert torch.equal(got, ref)
