@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--det-size", type=int, default=1024)
     ap.add_argument("--det-steps", type=int, default=5)
     ap.add_argument("--cpu-lines", type=int, default=32, help="lines of the same workload the CPU oracle runs (one batch)")
+    ap.add_argument("--no-texify", action="store_true", help="skip the LaTeX-OCR leg (configs[4])")
+    ap.add_argument("--texify-crops", type=int, default=128)
+    ap.add_argument("--texify-tokens", type=int, default=256, help="decode horizon of the texify leg (the task's own default is 768)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
@@ -349,6 +352,54 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
                     f"{args.max_tokens}"}
 
 
+def bench_texify(args, cfg, sd, local_rank):
+    """BASELINE.json configs[4]: LaTeX OCR = RecognitionPredictor with task block_without_boxes on 384 x 384 crops, batch 128
+    (784 patches / 196 image tokens per crop, prompt 202, KV growing to prompt + horizon). bf16 weights. Device loop with tiles
+    resident in HBM, like the main leg; tokens/s is the natural unit (the horizon, not the crop count, sets the work)."""
+    import numpy as np
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    from surya_amd.recognition.schema import TaskNames
+    n, T = args.texify_crops, args.texify_tokens
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype=None, **caps):
+            return super().model(f"cuda:{local_rank}", dtype, max_slots=n, max_kv_len=202 + T + 32, max_patches=n * 784,
+                                 max_prefill_tokens=n * 208)
+
+    class Pred(RecognitionPredictor):
+        model_loader_cls = Loader
+        batch_size = n
+
+    from surya_amd.settings import settings
+    settings.RECOGNITION_MAX_TOKENS = T
+    pred = Pred(checkpoint={"config": cfg, "state_dict": sd})
+    rng = np.random.default_rng(77)
+    crops = []
+    for _ in range(n):
+        img = np.full((384, 384, 3), 255, np.uint8)
+        for _ in range(int(rng.integers(12, 40))):
+            x, y = int(rng.integers(10, 320)), int(rng.integers(10, 350))
+            img[y:y + int(rng.integers(2, 24)), x:x + int(rng.integers(4, 50))] = rng.integers(0, 90, size=3, dtype=np.uint8)
+        crops.append(img.astype(np.float32))
+    flat = {"slices": crops, "input_text": [None] * n, "task_names": [TaskNames.block_without_boxes] * n}
+    pred.device_preprocess = False                        # crops are handed over as arrays here (no page to reference)
+    prep = pred.prepare_lines(flat, math_mode=True)
+    pred.generate(prep, n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks, _, _ = pred.generate(prep, n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ntok = sum(len(t) for t in toks)
+    settings.RECOGNITION_MAX_TOKENS = args.max_tokens
+    del pred
+    torch.cuda.empty_cache()
+    return {"metric": "LaTeX-OCR crops/s and tokens/s (task block_without_boxes)", "crops": n, "crops_per_s": round(n / dt, 2),
+            "tokens_per_s": round(ntok / dt, 1), "tokens": ntok, "ms": round(dt * 1e3, 1), "dtype": "bf16",
+            "config": {"workload": f"{n} synthetic 384x384 crops, batch {n}, max_tokens={T}, prompt 202 tokens (196 image tokens), "
+                                   f"{args.config} synthetic weights; fp8 weight path: not built (DESIGN.md section 7)"}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -467,6 +518,12 @@ def main():
     if not args.no_e2e:
         e2e = bench_e2e(args, pred, local_rank, world, rank, barrier)
 
+    tex = None
+    if rank == 0 and world == 1 and not args.no_texify:
+        del pred
+        torch.cuda.empty_cache()
+        tex = bench_texify(args, cfg, sd, local_rank)
+
     if rank == 0:
         lines_total = args.lines * world * args.steps
         out = {
@@ -477,7 +534,7 @@ def main():
                                    f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
                        "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
                        "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "detection": det, "e2e": e2e,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "detection": det, "e2e": e2e, "texify": tex,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
