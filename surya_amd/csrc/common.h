@@ -128,7 +128,7 @@ struct Tuning {
     int split_min_kt = 4;    // at least this many 128-byte K-tiles per slice
     int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
     int gu_tile = 0;         // decode gate|up (M in (128, 256]): 0 = 64x64, 1 = 128x64, 2 = 128x128
-    int head_tile = 0;       // lm_head at decode: 0 = 128x128, 1 = 256x128
+    int head_tile = 0;       // lm_head at decode: 0 = 128x128 2-stage, 1 = 256x128, 2 / 3 = 128x128 with a 3- / 4-stage LDS ring
     int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
     int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)
 };

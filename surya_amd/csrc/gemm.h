@@ -592,6 +592,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if (a.N >= 64 * 512) {
                 if constexpr (EPI == EPI_ARGMAX) {
                     if (tuning().head_tile == 1) return launch_gemm_cfg<TI, TO, 256, 128, 4, 2, EPI, false, 2>(a, s);
+                    if (tuning().head_tile == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 3>(a, s);   // 3-stage ring, 1 WG / CU
+                    if (tuning().head_tile == 3) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 4>(a, s);   // 4-stage ring
                 }
                 return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
             }

@@ -365,8 +365,9 @@ class RecognitionPredictor(BasePredictor):
         return {"prompts": prompts, "max_tokens": max_tokens, "tiles": tiles, "tile_offs": tile_offs, "grids": grids,
                 "prompt_ids": prompt_ids}
 
-    def generate(self, prep: dict, recognition_batch_size: int | None = None) -> tuple:
-        """Device half: continuous batching over KV slots until every line stopped (reference :501-607)."""
+    def generate(self, prep: dict, recognition_batch_size: int | None = None, on_done=None) -> tuple:
+        """Device half: continuous batching over KV slots until every line stopped (reference :501-607).
+        on_done(line, tokens, scores, bbox_rows[T, 6]) is called once per line, as soon as its stream is final."""
         prompts, batch_max_tokens = prep["prompts"], prep["max_tokens"]
         tiles, tile_offs, grids, prompt_ids = prep["tiles"], prep["tile_offs"], prep["grids"], prep["prompt_ids"]
         n = len(prompts)
@@ -391,6 +392,11 @@ class RecognitionPredictor(BasePredictor):
             batch_pos[p_idx] += 1
             scores[p_idx].append(float(score))
 
+        def finished(p_idx):
+            if on_done is not None:
+                n_ = min(batch_pos[p_idx], overall_max_tokens)
+                on_done(p_idx, predicted_tokens[p_idx], scores[p_idx], batch_bboxes[p_idx, :max(n_, 1)])
+
         def absorb(call):
             """Host half of one decode call: append its tokens, apply the stop rules (reference :583-595)."""
             k, ring = call
@@ -406,6 +412,7 @@ class RecognitionPredictor(BasePredictor):
                     if toks[-1] in (eos, pad) or stop:
                         self.batch_prompt_mapping[s] = None
                         changed = True
+                        finished(p_idx)
             if changed:
                 self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
 
@@ -464,6 +471,8 @@ class RecognitionPredictor(BasePredictor):
                     record(p.id, tok[0, s], sc[0, s], bb[0, s])
                     if predicted_tokens[p.id][-1] not in (eos, nop):       # prefill stop rule (reference :559-563)
                         self.batch_prompt_mapping[s] = p.id
+                    else:
+                        finished(p.id)
                 self.model.set_active([k for k, v in self.batch_prompt_mapping.items() if v is not None])
             else:
                 # steps some active line can still need once the call in flight is done (token budgets are known up front)
@@ -632,32 +641,49 @@ class RecognitionPredictor(BasePredictor):
         for key in ("slices", "input_text", "task_names"):
             flat[key] = [flat[key][i] for i in order]
 
-        loop = self.sharded_prediction_loop if self.shard_lines else self.prediction_loop
-        predicted_tokens, batch_bboxes, scores = loop(flat, recognition_batch_size, math_mode)
+        # original position of every sorted line, so a finished line can be assembled against its own polygon / scale
+        orig_of = order
         bbox_size = self.model.cfg.bbox_size
-        sizes = [img.shape for img in flat["slices"]]
-        polys = prediction_to_polygon_batch(batch_bboxes.numpy(), sizes, bbox_size, bbox_size // 2)
-        char_predictions = self.get_bboxes_text(flat, predicted_tokens, scores, polys, drop_repeated_text)
-        restored = [None] * len(order)
-        for sorted_pos, orig in enumerate(order):
-            restored[orig] = char_predictions[sorted_pos]
+
+        def assemble(sorted_pos, tokens, sc, bbox_rows):
+            """One line's TextLine from its finished token stream (reference :609-771 + :886-925)."""
+            orig = orig_of[sorted_pos]
+            polygon, res_scale = flat["polygons"][orig], flat["res_scales"][orig]
+            polys = prediction_to_polygon_batch(bbox_rows[None], [flat["slices"][sorted_pos].shape], bbox_size, bbox_size // 2)
+            chars = self.get_bboxes_text(flat, [tokens], [sc], polys, drop_repeated_text)[0]
+            if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
+                return TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True)
+            confidence = float(np.mean(chars[1]))
+            box = PolygonBox(polygon=polygon)
+            chars = self._chars_of(chars, res_scale, box.bbox)
+            chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
+            text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
+            return TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
+                            words=words_from_chars(chars, box) if return_words else [])
+
+        text_lines = [None] * len(order)                      # by ORIGINAL position
+        if self.shard_lines:
+            predicted_tokens, batch_bboxes, scores = self.sharded_prediction_loop(flat, recognition_batch_size, math_mode)
+            bb = batch_bboxes.numpy()
+            for k in range(len(order)):
+                text_lines[orig_of[k]] = assemble(k, predicted_tokens[k], scores[k], bb[k])
+        else:
+            # Output assembly is host work of the same order as the device loop itself (~7 us per character object); it runs on
+            # one worker thread WHILE the device decodes the next lines: a line is handed over the moment its stream stops. The
+            # scheduler thread spends most of its time blocked in hipEventSynchronize (GIL released), which is when the worker runs.
+            futures = {}
+            with ThreadPoolExecutor(1) as pool:
+                def on_done(k, tokens, sc, bbox_rows):
+                    futures[k] = pool.submit(assemble, k, list(tokens), list(sc), bbox_rows.copy())
+                self.generate(self.prepare_lines(flat, math_mode), recognition_batch_size, on_done=on_done)
+                for k, f in futures.items():
+                    text_lines[orig_of[k]] = f.result()
+            assert all(t is not None for t in text_lines)
 
         results, start = [], 0
         for idx, image in enumerate(images):
             end = start + flat["slice_map"][idx]
-            lines = []
-            for chars, polygon, res_scale in zip(restored[start:end], flat["polygons"][start:end],
-                                                 flat["res_scales"][start:end]):
-                if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
-                    lines.append(TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True))
-                    continue
-                confidence = float(np.mean(chars[1]))
-                box = PolygonBox(polygon=polygon)
-                chars = self._chars_of(chars, res_scale, box.bbox)
-                chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
-                text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
-                lines.append(TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
-                                      words=words_from_chars(chars, box) if return_words else []))
+            lines = text_lines[start:end]
             start = end
             if sort_lines:
                 lines = sort_text_lines(lines)

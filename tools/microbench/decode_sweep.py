@@ -55,6 +55,8 @@ def main():
     base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0)
     if args.configs == "base":
         variants = [dict()]
+    elif args.configs == "head":
+        variants = [dict(), dict(head_tile=2), dict(head_tile=3), dict(head_tile=1)]
     elif args.configs == "quick":
         variants = [dict(), dict(dual=1), dict(split_tile=1, gu_tile=1), dict(split_tile=1, gu_tile=1, dual=1)]
     else:

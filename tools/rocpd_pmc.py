@@ -54,10 +54,28 @@ def as_json(rows):
     print(json.dumps({b: round(tot[b] / n[b]) for b in tot if n.get(b)}, indent=1))
 
 
+def det_json(rows):
+    """{"detection forward (all kernels)": HBM-side bytes per forward} from PMC passes over `bench.py --det-only`: (2 x FETCH_SIZE
+    + WRITE_SIZE) summed over every model kernel (post-processing and copies excluded) / number of forwards (= dispatches of the
+    final x4 upsample kernel)."""
+    import json
+    tot, fw = 0.0, 0
+    for name, ctr, cnt, mean, total, dur in rows:
+        if "post_" in name or "rocclr" in name or "prof_null" in name:
+            continue
+        tot += total * 1024 * (2 if ctr == "FETCH_SIZE" else 1)
+        if ctr == "FETCH_SIZE" and "upsample_planes_kernel" in name:
+            fw += cnt
+    print(json.dumps({"detection forward (all kernels)": round(tot / max(fw, 1)), "forwards": fw}, indent=1))
+
+
 def main(paths):
     js = "--json" in paths
-    paths = [p for p in paths if p != "--json"]
+    dj = "--det-json" in paths
+    paths = [p for p in paths if p not in ("--json", "--det-json")]
     rows = [r for p in paths for r in load(p)]
+    if dj:
+        return det_json(rows)
     if js:
         return as_json(rows)
     rows.sort(key=lambda r: -r[4])
