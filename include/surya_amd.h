@@ -160,10 +160,11 @@ int surya_rec_wait_outputs(surya_rec* h, int n_steps, int ring, int32_t* tokens,
  *     int64 mask_off (bytes into mask_arena, cw * ch per polygon line); int64 mid_off (floats into mid_arena, 3 mid_w mid_h per
  *     line whose mid size differs from its crop size); int64 tile_row (first row of the line in tiles) }   -- 112 bytes, C layout.
  * tiles: device fp32 [sum (out_h / patch) (out_w / patch)][3 patch^2]. The host computes only these integers
- * (surya_amd/recognition/preprocess_gpu.py). Enqueue only; every buffer is caller-owned. */
+ * (surya_amd/recognition/preprocess_gpu.py). any_poly: some line has a polygon; max_stage1_width: largest mid_w among the lines whose
+ * mid size differs from their crop size (0 = no line needs the Lanczos stage). Enqueue only; every buffer is caller-owned. */
 int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
                          int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
-                         int any_stage1, void* stream);
+                         int max_stage1_width, void* stream);
 
 /* Test hooks (tolerance tests of intermediate tensors):
  *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in

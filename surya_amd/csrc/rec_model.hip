@@ -996,13 +996,14 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
 
 int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
                          int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
-                         int any_stage1, void* stream) {
+                         int max_stage1_width, void* stream) {
     if (!pages || !lines || !tiles || !mean || !std || n_lines < 0 || patch_size <= 0 || merge_size <= 0) return SA_ERR_ARG;
     sa::prep::PrepArgs p;
     p.pages = pages; p.lines = reinterpret_cast<const sa::prep::LineDesc*>(lines); p.n_lines = n_lines;
     p.mask = mask_arena; p.mid = mid_arena; p.tiles = tiles; p.ps = patch_size; p.merge = merge_size; p.pad = pad_value;
     for (int i = 0; i < 3; ++i) { p.mean[i] = mean[i]; p.std[i] = std[i]; }
-    return sa::prep::prep_run(p, any_poly, any_stage1, (hipStream_t)stream);
+    p.max_mid_w = max_stage1_width;
+    return sa::prep::prep_run(p, any_poly, max_stage1_width > 0, (hipStream_t)stream);
 }
 
 int surya_set_tuning(const char* key, int value) {

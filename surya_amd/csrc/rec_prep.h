@@ -40,7 +40,7 @@ struct PrepArgs {
     unsigned char* mask;         // arena: per polygon line [ch][cw] bytes, 1 = inside / on the boundary
     float* mid;                  // arena: per Lanczos line [mid_h][mid_w][3] floats
     float* tiles;                // [sum patches][3 * ps * ps]
-    int ps, merge;
+    int ps, merge, max_mid_w;    // max_mid_w: widest stage-1 output of the call (grid sizing)
     float pad;                   // RECOGNITION_PAD_VALUE
     float mean[3], std[3];
 };
@@ -174,17 +174,45 @@ __device__ __forceinline__ void resample_px(SRC src, int in_h, int in_w, int out
     }
 }
 
-// stage 1 (scale_to_fit): Lanczos-4 of the masked crop into the line's slice of the mid arena
+// stage 1 (scale_to_fit): Lanczos-4 of the masked crop into the line's slice of the mid arena. The 8 taps of an axis cost 16
+// double-precision sin() each, so they are computed ONCE per output column (a thread owns a column and walks down the rows) and
+// once per output row (8 lanes fill an LDS record per row) instead of once per pixel (a first version spent 19.7 ms per call
+// re-deriving them, r02n profile).
 __global__ __launch_bounds__(256) void prep_stage1_kernel(PrepArgs p) {
+#pragma clang fp contract(off)
+    __shared__ double wy_s[8];
+    __shared__ int yi_s[8];
     const LineDesc& L = p.lines[blockIdx.y];
     if (L.mid_w == L.cw && L.mid_h == L.ch) return;
-    const long n = (long)L.mid_w * L.mid_h;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int oy = (int)(i / L.mid_w), ox = (int)(i % L.mid_w);
-        float v[3];
-        resample_px<8>([&](int y, int x, int c) { return crop_px(p, L, y, x, c); }, L.ch, L.cw, L.mid_h, L.mid_w, oy, ox, v);
-        float* dst = p.mid + L.mid_off + i * 3;
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= L.mid_w) return;                          // whole block beyond the line's width
+    const bool rx = L.cw != L.mid_w, ry = L.ch != L.mid_h, live = ox < L.mid_w;
+    int xi[8];
+    double wx[8];
+    if (rx && live) axis_setup<8>(ox, L.cw, L.mid_w, xi, wx);
+    for (int oy = 0; oy < L.mid_h; ++oy) {
+        __syncthreads();
+        if (ry && threadIdx.x == 0) axis_setup<8>(oy, L.ch, L.mid_h, yi_s, wy_s);
+        __syncthreads();
+        if (!live) continue;
+        float* dst = p.mid + L.mid_off + ((long)oy * L.mid_w + ox) * 3;
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;
+            const int ny = ry ? 8 : 1;
+            for (int j = 0; j < ny; ++j) {
+                const int sy = ry ? yi_s[j] : oy;
+                double h;
+                if (rx) {
+                    h = (double)crop_px(p, L, sy, xi[0], c) * wx[0];
+                    for (int k = 1; k < 8; ++k) h = h + (double)crop_px(p, L, sy, xi[k], c) * wx[k];
+                } else {
+                    h = (double)crop_px(p, L, sy, ox, c);
+                }
+                if (ry) acc = j == 0 ? h * wy_s[0] : acc + h * wy_s[j];
+                else acc = h;
+            }
+            dst[c] = (float)acc;
+        }
     }
 }
 
@@ -226,7 +254,7 @@ static inline int prep_run(const PrepArgs& p, int any_poly, int any_stage1, hipS
     }
     if (any_stage1) {
         if (!p.mid) return SA_ERR_ARG;
-        hipLaunchKernelGGL(prep_stage1_kernel, dim3(32, p.n_lines), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(prep_stage1_kernel, dim3(cdiv(p.max_mid_w, 256), p.n_lines), dim3(256), 0, s, p);
     }
     hipLaunchKernelGGL(prep_tiles_kernel, dim3(32, p.n_lines), dim3(256), 0, s, p);
     return (int)hipGetLastError();

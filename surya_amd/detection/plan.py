@@ -92,8 +92,8 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
         return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res)
 
     def mbconv(x, hw, cin, p, stride, res):
-        y, hw1, mid = conv(x, hw, cin, p + ".inverted_conv", 1, 1, ACT_HSWISH)
         wd, bd = _fold(sd, p + ".depth_conv", eps)
+        y, hw1, mid = conv(x, hw, cin, p + ".inverted_conv", 1, 1, ACT_HSWISH)
         y, hw2 = dwconv(y, hw1, mid, wd, bd, 3, stride, ACT_HSWISH)
         return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res)
 

@@ -101,7 +101,7 @@ class DevicePreprocessor:
             total += pg.size
         desc = np.zeros(n, LINE_DESC)
         tile_offs = np.zeros(n + 1, np.int64)
-        grids, mask_bytes, mid_floats = [], 0, 0
+        grids, mask_bytes, mid_floats, max_mid_w = [], 0, 0, 0
         for i, (ln, mx) in enumerate(zip(lines, max_sizes)):
             ph, pw = pages[ln.page].shape[:2]
             h, w = ln.y1 - ln.y0, ln.x1 - ln.x0
@@ -122,6 +122,7 @@ class DevicePreprocessor:
             if (mh, mw) != (h, w):
                 d["mid_off"] = mid_floats
                 mid_floats += mh * mw * 3
+                max_mid_w = max(max_mid_w, mw)
             d["tile_row"] = tile_offs[i]
             gh, gw = oh // self.ps, ow // self.ps
             grids.append((gh, gw))
@@ -139,7 +140,7 @@ class DevicePreprocessor:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib.surya_rec_preprocess(L.ptr(d_pages), L.ptr(d_desc), C.c_int(n), L.ptr(d_mask), L.ptr(d_mid), L.ptr(tiles),
                                               C.c_int(self.ps), C.c_int(self.merge), C.c_float(self.pad), self.mean, self.std,
-                                              C.c_int(int(mask_bytes > 0)), C.c_int(int(mid_floats > 0)), stream),
+                                              C.c_int(int(mask_bytes > 0)), C.c_int(max_mid_w), stream),
                 "surya_rec_preprocess")
         self._keep = (d_pages, d_desc, d_mask, d_mid, host)          # alive until the stream has consumed them
         return tiles, tile_offs, grids
