@@ -118,17 +118,14 @@ __device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x
 
 // Launch-policy knobs, in ONE place. Defaults are the measured best; surya_set_tuning(key, value) changes
 // them at run time for A/B sweeps inside one process (tools/microbench/decode_sweep.py). Nothing in a launch path reads the
-// environment.
+// environment. Round 2 also swept larger decode tiles (128x64 / 128x128 for gate|up and split-K), a 256x128 / deeper-ring
+// lm_head and two-half dual-stream decode through knobs that lived here; all lost (profiles/r02_decode_sweeps.md) and their
+// code paths were removed with them.
 struct Tuning {
-    int graph = 0;           // decode steps as hipGraph replays (1) or plain launches (0)
-    int dual = 0;            // decode the active rows as two half-batches on two streams (rows >= dual_min)
-    int dual_min = 128;
-    int split_tile = 0;      // decode split-K projections: 0 = 64x64 ring-4, 1 = 128x64, 2 = 128x128
-    int split_target = 256;  // aim at this many workgroups
+    int graph = 0;           // decode steps as hipGraph replays (1) or plain launches (0; faster with the pipelined host loop)
+    int split_target = 256;  // decode split-K projections: aim at this many workgroups
     int split_min_kt = 4;    // at least this many 128-byte K-tiles per slice
     int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
-    int gu_tile = 0;         // decode gate|up (M in (128, 256]): 0 = 64x64, 1 = 128x64, 2 = 128x128
-    int head_tile = 0;       // lm_head at decode: 0 = 128x128 2-stage, 1 = 256x128, 2 / 3 = 128x128 with a 3- / 4-stage LDS ring
     int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
     int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)
 };

@@ -586,19 +586,10 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     if (a.M <= 256) {
         if (a.M > 128) {
-            // measured at M = 256 (tools/microbench/gemm_shapes.py, decode_sweep.py): lm_head-sized N -> 128x128 tiles; the rest
-            // 64x64 (r01) or 128x64 / 128x128 (fewer L2->CU requests per MAC: 64x64 asks for 210 MB per gate|up launch, 128x64
-            // for 157 MB, 128x128 for 105 MB, against a ~15 TB/s ceiling), all direct-to-LDS
-            if (a.N >= 64 * 512) {
-                if constexpr (EPI == EPI_ARGMAX) {
-                    if (tuning().head_tile == 1) return launch_gemm_cfg<TI, TO, 256, 128, 4, 2, EPI, false, 2>(a, s);
-                    if (tuning().head_tile == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 3>(a, s);   // 3-stage ring, 1 WG / CU
-                    if (tuning().head_tile == 3) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 4>(a, s);   // 4-stage ring
-                }
-                return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
-            }
-            if (tuning().gu_tile == 2 && a.N >= 128 * 64) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
-            if (tuning().gu_tile == 1 && a.N >= 64 * 64) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI, false, 2>(a, s);
+            // measured at M = 256 (tools/microbench/gemm_shapes.py, decode_sweep.py): lm_head-sized N -> 128x128 tiles, everything
+            // else 64x64, direct-to-LDS. Larger gate|up tiles (128x64: +26 us/step, 128x128: +69), a 256x128 lm_head tile (+30) and
+            // 3- / 4-stage rings for lm_head (+25) all lost in r02 (profiles/r02_decode_sweeps.md).
+            if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
             return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
         }
         if (a.M > 64) {
@@ -645,18 +636,8 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
     if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || !a.part) return SA_ERR_SHAPE;
     const int nk = a.K / Ty<TI>::KE;
-    // r01: 64x64 tiles with a 4-stage direct-to-LDS ring. r02: 128x64 / 128x128 tiles ask L2 for half / a quarter of the bytes
-    // per MAC (the 64x64 launches sat at the ~15 TB/s L2->CU request ceiling); fewer output tiles are made
-    // up for with more K slices. Small M keeps 64-row tiles.
-    const int mode = a.M > 64 ? tuning().split_tile : 0;
-    if (mode == 2) {
-        a.splitk = pick_splitk(cdiv(a.N, 128) * cdiv(a.M, 128), nk);
-        return launch_gemm_cfg<TI, TI, 128, 128, 2, 2, EPI_BIAS, true, 2>(a, s);
-    }
-    if (mode == 1) {
-        a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 128), nk);
-        return launch_gemm_cfg<TI, TI, 128, 64, 4, 1, EPI_BIAS, true, 3>(a, s);
-    }
+    // 64x64 tiles with a 4-stage direct-to-LDS ring and ~256 workgroups. 128x64 / 128x128 split-K tiles (fewer L2->CU requests per
+    // MAC, more slices) were measured in r02 and lose by 70-180 us per decode step (profiles/r02_decode_sweeps.md).
     a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk);
     return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
 }

@@ -178,7 +178,7 @@ struct RecModel : RecBase {
     float2* erope;           // [max_patches][enc head_dim / 2] (cos, sin) of the vision rotary embedding
     float4* amax;            // greedy-head partials of the lm_head GEMM: [slot row][column tile]
     float2* rope_cs;                                     // decoder RoPE table [max_kv_len][head_dim/2] (cos, sin)
-    float* part;                                         // split-K partial sums, per decode half: [2][8][max_slots][max(qkv_dim, hidden)]
+    float* part;                                         // split-K partial sums [8][max_slots][max(qkv_dim, hidden)]
     T *kcache, *vcache;
     int *kv_len, *next_token, *active_dev, *row_len;
     int* out_token; float* out_score; int* out_bbox;     // [SA_MAX_STEPS][max_slots] (bbox x6)
@@ -189,8 +189,6 @@ struct RecModel : RecBase {
     // hipGraph replay of decode steps: a step is ~113 short launches; captured once per (active rows, steps) and replayed
     // from an internal stream (capture is not allowed on the legacy default stream torch hands us).
     hipStream_t gstream = nullptr;
-    hipStream_t hstream = nullptr;                       // second decode half (Tuning::dual)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     hipEvent_t ev_ring[2] = {nullptr, nullptr};          // outputs of ring half r are in the pinned mirror
     std::map<long, hipGraphExec_t> graphs;
@@ -225,7 +223,7 @@ struct RecModel : RecBase {
         size_t o_logits = take(S * (size_t)c.vocab * sizeof(float));
         size_t o_amax = take(S * (size_t)cdiv(c.vocab, 32) * sizeof(float4));
         size_t o_rope = take((size_t)c.max_kv_len * (c.dec_head_dim / 2) * sizeof(float2));
-        size_t o_part = take((size_t)2 * 8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));   // x2: decode halves
+        size_t o_part = take((size_t)8 * S * std::max(qkv_d, (size_t)c.dec_hidden) * sizeof(float));
         const size_t kv_elems = (size_t)c.dec_layers * S * c.dec_kv_heads * c.max_kv_len * c.dec_head_dim;
         size_t o_k = take(kv_elems * sizeof(T));
         size_t o_v = take(kv_elems * sizeof(T));
@@ -285,9 +283,6 @@ struct RecModel : RecBase {
             SA_HIP(hipEventCreateWithFlags(&ev_ahead_free, hipEventDisableTiming));
         }
         SA_HIP(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
-        SA_HIP(hipStreamCreateWithFlags(&hstream, hipStreamNonBlocking));
-        SA_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        SA_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         SA_HIP(hipEventCreateWithFlags(&gev_in, hipEventDisableTiming));
         SA_HIP(hipEventCreateWithFlags(&gev_out, hipEventDisableTiming));
         for (auto& e : ev_ring) SA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -301,9 +296,6 @@ struct RecModel : RecBase {
     ~RecModel() override {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         if (gstream) (void)hipStreamDestroy(gstream);
-        if (hstream) (void)hipStreamDestroy(hstream);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
         if (gev_in) (void)hipEventDestroy(gev_in);
         if (gev_out) (void)hipEventDestroy(gev_out);
         for (auto e : ev_ring) if (e) (void)hipEventDestroy(e);
@@ -530,12 +522,8 @@ struct RecModel : RecBase {
         return (int)hipGetLastError();
     }
 
-    // The rows of one decode step are processed as one or two independent HALVES (contiguous row ranges of the active
-    // list): every per-row buffer is row-major, so a half is a pointer offset plus its own split-K partial workspace and its
-    // own stream. Two halves on two streams interleave on the chip: while one half's kernel drains its tail or waits at a
-    // launch boundary, the other half's kernel has the CUs (the decode chain is ~113 dependent 5-18 us launches per step; two
-    // bench processes sharing one GPU already showed +15 %, r01). Weights are read by both halves within a few tens of
-    // microseconds of each other, i.e. the second read is served by L2 / the 256 MiB Infinity Cache, not HBM.
+    // The rows of a decode step and their workspaces: every per-row buffer is row-major, so a row range is a pointer offset.
+    // (r02 ran two halves of the batch on two streams: no gain -- a 128-row launch takes as long as a 256-row one -- removed.)
     struct Half { int r0, M; float* part; hipStream_t s; };
 
     int decode_embed(const Half& h) {
@@ -606,12 +594,11 @@ struct RecModel : RecBase {
                                     last ? dlast + (size_t)h.r0 * Hd : hh, s);
     }
 
-    // r0 > 0 only for decode halves; prefill passes 0.
-    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s, int r0 = 0) {
+    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s) {
         const int Hd = c.dec_hidden;
         int rc;
-        T* last = dlast + (size_t)r0 * Hd;
-        float4* am = amax + (size_t)r0 * cdiv(c.vocab, 32);
+        T* last = dlast;
+        float4* am = amax;
         if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), last, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
         // lm_head with the greedy reduction in its epilogue: logits stay in LDS, the head combines per-tile partials.
         GemmArgs<T, float> a{last, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
@@ -623,7 +610,7 @@ struct RecModel : RecBase {
                            (long)tiles_n, tiles_n, last, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
                            c.pad_token_id, (float)c.bbox_size, out_token + so, out_score + so, out_bbox + so * 6, next_token,
                            kv_len, len_inc);
-        last_rows = r0 + rows;
+        last_rows = rows;
         return (int)hipGetLastError();
     }
 
@@ -716,34 +703,12 @@ struct RecModel : RecBase {
 
     int decode_eager(int M, int n_steps, int step0, hipStream_t s) {
         int rc;
-        const Tuning& tn = tuning();
-        const size_t part_half = (size_t)8 * c.max_slots * std::max((size_t)(c.dec_heads + 2 * c.dec_kv_heads) * c.dec_head_dim,
-                                                                      (size_t)c.dec_hidden);
-        Half hv[2];
-        int nh = 1;
-        hv[0] = Half{0, M, part, s};
-        if (tn.dual && M >= tn.dual_min && M >= 128) {
-            const int Ma = cdiv(cdiv(M, 2), 64) * 64;            // halves in whole 64-row tiles: 256 -> 128 + 128
-            hv[0].M = Ma;
-            hv[1] = Half{Ma, M - Ma, part + part_half, hstream};
-            nh = 2;
-            SA_HIP(hipEventRecord(ev_fork, s));
-            SA_HIP(hipStreamWaitEvent(hstream, ev_fork, 0));
-        }
-        // launches of the two halves are interleaved layer by layer so neither stream waits for the host to finish with the other
+        const Half h{0, M, part, s};
         for (int step = 0; step < n_steps; ++step) {
-            for (int i = 0; i < nh; ++i)
-                if ((rc = decode_embed(hv[i]))) return rc;
+            if ((rc = decode_embed(h))) return rc;
             for (int l = 0; l < c.dec_layers; ++l)
-                for (int i = 0; i < nh; ++i)
-                    if ((rc = decode_layer(l, hv[i]))) return rc;
-            for (int i = 0; i < nh; ++i)
-                if ((rc = heads(hv[i].M, nullptr, active_dev + hv[i].r0, step0 + step, 1, true, hv[i].s, hv[i].r0))) return rc;
-        }
-        if (nh == 2) {
-            SA_HIP(hipEventRecord(ev_join, hstream));
-            SA_HIP(hipStreamWaitEvent(s, ev_join, 0));
-            last_rows = M;
+                if ((rc = decode_layer(l, h))) return rc;
+            if ((rc = heads(M, nullptr, active_dev, step0 + step, 1, true, s))) return rc;
         }
         return SA_OK;
     }
@@ -785,7 +750,7 @@ struct RecModel : RecBase {
         const int M = n_active;
         if (M == 0 || n_steps == 0) return SA_OK;
         if (!use_graph || !tuning().graph || gemm_profiler().enabled) return decode_eager(M, n_steps, step0, s);
-        const long key = (((long)M * 64 + n_steps) * 64 + step0) * 2 + (tuning().dual ? 1 : 0);
+        const long key = ((long)M * 64 + n_steps) * 64 + step0;
         auto it = graphs.find(key);
         if (it == graphs.end()) {
             // first sight of this shape runs eagerly (one-time hipFuncSetAttribute calls must not happen inside a capture)
@@ -1010,9 +975,8 @@ int surya_set_tuning(const char* key, int value) {
     if (!key) return SA_ERR_ARG;
     Tuning& t = tuning();
     struct { const char* k; int* v; } tab[] = {
-        {"graph", &t.graph}, {"dual", &t.dual}, {"dual_min", &t.dual_min}, {"split_tile", &t.split_tile},
-        {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
-        {"gu_tile", &t.gu_tile}, {"head_tile", &t.head_tile}, {"bigtile", &t.bigtile}, {"glds", &t.glds}};
+        {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
+        {"bigtile", &t.bigtile}, {"glds", &t.glds}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) { *e.v = value; return SA_OK; }
     return SA_ERR_ARG;

@@ -159,7 +159,9 @@ def test_multi_step_decode_matches_single_steps(hip_lib):
 def test_pipelined_decode_ring_matches_single_steps(hip_lib, monkeypatch, graph):
     """decode_async / wait_outputs (two calls in flight, alternating ring halves; plain launches and hipGraph replay)
     produce the same tokens, scores and boxes as synchronous single steps."""
-    monkeypatch.setenv("SURYA_AMD_GRAPH", graph)
+    import ctypes as C
+    from surya_amd import _lib as L
+    L.check(L.lib().surya_set_tuning(b"graph", C.c_int(int(graph))), "surya_set_tuning")      # launch policy, not an env knob
     cfg, sd, m = build("REC-TINY", torch.float32)
     tiles, seqs = make_prompts(cfg, GRIDS)
     slots = list(range(len(seqs)))
@@ -185,6 +187,7 @@ def test_pipelined_decode_ring_matches_single_steps(hip_lib, monkeypatch, graph)
             assert np.array_equal(got[k][0][slots], single[k][0][slots]), (rep, k)
             assert np.array_equal(got[k][2][slots], single[k][2][slots]), (rep, k)
             assert np.allclose(got[k][1][slots], single[k][1][slots])
+    L.check(L.lib().surya_set_tuning(b"graph", C.c_int(0)), "surya_set_tuning")
 
 
 def test_encode_ahead_equals_inline_encode(hip_lib):

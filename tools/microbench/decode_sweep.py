@@ -5,7 +5,10 @@ For every tuning configuration (surya_set_tuning, csrc/common.h sa::Tuning) this
 read, and reports wall us/step (HIP events around the whole run) plus whether the greedy tokens equal the first
 configuration's (tile / split-K changes re-order fp32 sums, so bf16 argmax near-ties may flip; reported, not asserted).
 
-    python tools/microbench/decode_sweep.py [--steps 32] [--configs all|quick]
+    python tools/microbench/decode_sweep.py [--steps 32] [--configs all|base]
+
+The tile-shape / dual-stream / lm_head-ring / skinny-GEMM variants swept in round 2 lost and were removed from the library; their
+results are in profiles/r02_decode_sweeps.md.
 """
 from __future__ import annotations
 
@@ -52,24 +55,12 @@ def main():
         for k, v in kw.items():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
-    base = dict(graph=0, dual=0, split_tile=0, split_target=256, split_min_kt=4, split_max=8, gu_tile=0, head_tile=0)
+    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8)
     if args.configs == "base":
         variants = [dict()]
-    elif args.configs == "head":
-        variants = [dict(), dict(head_tile=2), dict(head_tile=3), dict(head_tile=1)]
-    elif args.configs == "quick":
-        variants = [dict(), dict(dual=1), dict(split_tile=1, gu_tile=1), dict(split_tile=1, gu_tile=1, dual=1)]
     else:
-        variants = [dict()]
-        variants += [dict(gu_tile=g) for g in (1, 2)]
-        variants += [dict(split_tile=1, split_min_kt=k) for k in (4, 2)]
-        variants += [dict(split_tile=2, split_min_kt=k, split_target=t) for k, t in ((4, 256), (2, 256), (2, 512))]
-        variants += [dict(split_tile=0, split_target=512)]
-        variants += [dict(head_tile=1)]
-        variants += [dict(dual=1), dict(dual=1, graph=1), dict(graph=1)]
-        variants += [dict(dual=1, gu_tile=1, split_tile=1), dict(dual=1, gu_tile=2, split_tile=2, split_min_kt=2),
-                     dict(dual=1, gu_tile=1, split_tile=1, graph=1), dict(gu_tile=1, split_tile=1), dict(gu_tile=2, split_tile=2, split_min_kt=2),
-                     dict(dual=1, gu_tile=1, split_tile=2, split_min_kt=2), dict(dual=1, gu_tile=1, split_tile=2, split_min_kt=2, head_tile=1)]
+        variants = [dict(), dict(graph=1), dict(split_target=512), dict(split_target=384), dict(split_target=192), dict(split_min_kt=2),
+                    dict(split_max=4)]
 
     def run(n_steps):
         m.prefill(tiles, grids, seqs, slots)
