@@ -430,8 +430,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                         const int m = min(m0 + row, p.M - 1), j = (n % p.rope_D) >> 1, half = p.rope_D >> 1;
                         const float4 cs = *reinterpret_cast<const float4*>(p.rope + (long)m * half + j);   // (cos j, sin j, cos j+1, sin j+1)
                         const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
-                        v[0] = x0 * cs.x - x1 * cs.y; v[1] = x1 * cs.x + x0 * cs.y;
-                        v[2] = x2 * cs.z - x3 * cs.w; v[3] = x3 * cs.z + x2 * cs.w;
+                        // products and sums pinned (one rounded product, one fused multiply-add): left to the compiler, the
+                        // 128x128 and 256x256 instantiations contracted these differently and the SAME patch got encoder features
+                        // one bf16 ulp apart depending on how many other lines were in the batch (r02 batch-invariance test)
+                        v[0] = __fmaf_rn(x0, cs.x, -__fmul_rn(x1, cs.y)); v[1] = __fmaf_rn(x1, cs.x, __fmul_rn(x0, cs.y));
+                        v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
                     }
                 }
                 if constexpr (EPI == EPI_SWIGLU && !SPLIT) {
@@ -624,9 +627,14 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
 // Split-K launch for the decode regime (M <= 256, small N): tiles x splitk workgroups so a skinny GEMM still covers the
 // chip; raw fp32 partial sums go to a.part[splitk][M][N] and the NEXT kernel combines them (launch-boundary reduce).
 // Returns the slice count actually used through a.splitk (caller passes the same struct to the consumer).
-static inline int pick_splitk(int tiles, int nk) {
+// The slice count is a function of (N, K) ONLY -- it is sized for a full 256-row batch (4 M-tiles) whatever the number of active
+// rows: the fp32 partial sums of an output element are then grouped the same way at every batch size, and since every GEMM tile
+// shape walks K in the same order with the same MFMA, a line's bf16 results no longer depend on how many other lines are active
+// (round 1 picked the count from the actual M: near-tie argmaxes could flip between slot counts).
+static inline int pick_splitk(int tiles_n, int nk) {
     const Tuning& t = tuning();
-    int s = (t.split_target + tiles / 2) / tiles;          // aim at ~target workgroups
+    const int tiles = tiles_n * 4;
+    int s = (t.split_target + tiles / 2) / tiles;          // aim at ~target workgroups at M = 256
     s = std::min(s, nk / std::max(1, t.split_min_kt));    // keep enough K-tiles per slice to fill the pipeline
     return std::max(1, std::min(s, std::min(t.split_max, 8)));      // consumers hold <= 8 slabs in flight
 }
@@ -638,7 +646,7 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     const int nk = a.K / Ty<TI>::KE;
     // 64x64 tiles with a 4-stage direct-to-LDS ring and ~256 workgroups. 128x64 / 128x128 split-K tiles (fewer L2->CU requests per
     // MAC, more slices) were measured in r02 and lose by 70-180 us per decode step (profiles/r02_decode_sweeps.md).
-    a.splitk = pick_splitk(cdiv(a.N, 64) * cdiv(a.M, 64), nk);
+    a.splitk = pick_splitk(cdiv(a.N, 64), nk);
     return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
 }
 

@@ -140,3 +140,21 @@ def test_rmsnorm(hip_lib, dtype, rows, C_):
     ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype)   # Qwen2RMSNorm semantics
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert (y.float() - ref.float()).abs().max().item() <= tol * max(1.0, ref.float().abs().max().item())
+
+
+@pytest.mark.parametrize("N,K,epi", [(1280, 1280, L.EPI_BIAS), (3840, 1280, L.EPI_BIAS), (6912, 1280, L.EPI_SWIGLU), (1280, 3456, L.EPI_RESIDUAL),
+                                     (81920, 1280, L.EPI_BIAS)])
+def test_gemm_rows_do_not_depend_on_batch_rows(hip_lib, N, K, epi):
+    """Row r of X . W^T must be bit-identical whatever M is: the launcher picks other tile shapes / staging generations for other
+    row counts (64x64 register-staged, 128x128 and 256x256 direct-to-LDS, decode-regime tiles), but all of them walk K in the same
+    order with the same MFMA. This is what makes a line's bf16 results independent of batch composition."""
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    Ms = (40, 200, 700, 2200, 8200, 33000) if N < 50000 else (40, 200, 256)
+    x = torch.randn(max(Ms), K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    No = N // 2 if epi == L.EPI_SWIGLU else N
+    res = torch.randn(max(Ms), No, device="cuda", generator=g).to(torch.bfloat16) if epi == L.EPI_RESIDUAL else None
+    outs = [run_gemm(hip_lib, x[:M].contiguous(), w, b, epi, res[:M].contiguous() if res is not None else None) for M in Ms]
+    for M, o in zip(Ms, outs):
+        assert torch.equal(o[:40], outs[0][:40]), f"rows differ between M = {Ms[0]} and M = {M}"
