@@ -588,6 +588,12 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             return SA_ERR_SHAPE;
     }
     if (a.M <= 256) {
+        if constexpr (EPI == EPI_ARGMAX) {
+            // the fused lm_head hands per-column-block (max, sum-exp) partials to greedy_head: keep the block width a function
+            // of N alone so a line's score is summed in the same groups whatever the number of active rows
+            if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
+            return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
+        }
         if (a.M > 128) {
             // measured at M = 256 (tools/microbench/gemm_shapes.py, decode_sweep.py): lm_head-sized N -> 128x128 tiles, everything
             // else 64x64, direct-to-LDS. Larger gate|up tiles (128x64: +26 us/step, 128x128: +69), a 256x128 lm_head tile (+30) and
