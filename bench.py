@@ -390,20 +390,36 @@ def bench_texify(args, cfg, sd, local_rank):
     flat = {"slices": crops, "input_text": [None] * n, "task_names": [TaskNames.block_without_boxes] * n}
     pred.device_preprocess = False                        # crops are handed over as arrays here (no page to reference)
     prep = pred.prepare_lines(flat, math_mode=True)
-    pred.generate(prep, n)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks, _, _ = pred.generate(prep, n)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ntok = sum(len(t) for t in toks)
+
+    def timed():
+        pred.generate(prep, n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks, _, _ = pred.generate(prep, n)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ntok = sum(len(t) for t in toks)
+        return {"crops_per_s": round(n / dt, 2), "tokens_per_s": round(ntok / dt, 1), "tokens": ntok, "ms": round(dt * 1e3, 1)}, toks
+
+    bf16, toks_b = timed()
+    # the fp8 weight path configs[4] names: decode steps on MXFP8 weights + activations (csrc/gemm_mx.h), prefill in bf16
+    pred.model.set_decode_fp8(True)
+    fp8, toks_f = timed()
+    pred.model.set_decode_fp8(False)
+    same = sum(int(a == b) for x, y in zip(toks_b, toks_f) for a, b in zip(x, y))
+    fp8["tokens_equal_to_bf16_run"] = round(same / max(1, min(bf16["tokens"], fp8["tokens"])), 4)
+    fp8["speedup_vs_bf16"] = round(bf16["ms"] / fp8["ms"], 3)
     settings.RECOGNITION_MAX_TOKENS = args.max_tokens
     del pred
     torch.cuda.empty_cache()
-    return {"metric": "LaTeX-OCR crops/s and tokens/s (task block_without_boxes)", "crops": n, "crops_per_s": round(n / dt, 2),
-            "tokens_per_s": round(ntok / dt, 1), "tokens": ntok, "ms": round(dt * 1e3, 1), "dtype": "bf16",
-            "config": {"workload": f"{n} synthetic 384x384 crops, batch {n}, max_tokens={T}, prompt 202 tokens (196 image tokens), "
-                                   f"{args.config} synthetic weights; fp8 weight path: not built (DESIGN.md section 7)"}}
+    out = {"metric": "LaTeX-OCR crops/s and tokens/s (task block_without_boxes)", "crops": n}
+    out.update(bf16)
+    out.update({"dtype": "bf16", "fp8_decode": fp8,
+                "config": {"workload": f"{n} synthetic 384x384 crops, batch {n}, max_tokens={T}, prompt 202 tokens (196 image tokens), "
+                                       f"{args.config} synthetic weights; fp8_decode = the same run with the decode steps on MXFP8 "
+                                       "weights and activations (v_mfma_scale_f32_32x32x64_f8f6f4), prefill bf16; on random weights "
+                                       "the two token streams part at the first near-tie (tokens_equal_to_bf16_run)"}})
+    return out
 
 
 def main():

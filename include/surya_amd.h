@@ -179,6 +179,20 @@ int surya_rec_copy_last_logits(surya_rec* h, float* dst, int max_rows, int* rows
 /* Force the token fed to the next decode step (teacher forcing in parity tests). */
 int surya_rec_set_next_tokens(surya_rec* h, const int32_t* slots, const int32_t* tokens, int n, void* stream);
 
+/* MXFP8 weights for the decode steps (BASELINE.json configs[4]: the fp8 MFMA weight path of the texify configuration; the
+ * reference has no fp8 mode -- its decode loop, surya/recognition/__init__.py:473-607, runs the checkpoint dtype). bf16
+ * models only. Each projection is given as OCP e4m3 bytes in the SAME kernel layout as its bf16 weight (qkv fused, gate|up
+ * row-interleaved, [out][in]) plus one E8M0 scale byte per 32 consecutive input features, stored K-TILE-MAJOR:
+ * [in / 128][out][4] bytes (the 4 block scales of a row inside one 128-wide K-tile are one dword, and the dwords of
+ * consecutive rows are contiguous -- what the GEMM's scale fetch reads in one piece). After this call
+ * surya_rec_decode / _decode_async multiply MXFP8 activations (quantised inside the producing kernels) by these weights with
+ * v_mfma_scale_f32_32x32x64_f8f6f4; prefill keeps the bf16 weights. table == NULL returns to the bf16 decode path.
+ * The caller keeps the tensors alive. Needs dec_hidden, heads * head_dim and intermediate sizes that are multiples of 128. */
+enum { SA_MX_QKV_W = 0, SA_MX_QKV_S, SA_MX_O_W, SA_MX_O_S, SA_MX_GU_W, SA_MX_GU_S, SA_MX_DOWN_W, SA_MX_DOWN_S, SA_MX_COUNT };
+enum { SA_MX_LM_W = 0, SA_MX_LM_S, SA_MX_GLOBALS };      /* after the per-layer entries */
+#define SA_MX_TOTAL(dec_layers) ((dec_layers) * SA_MX_COUNT + SA_MX_GLOBALS)
+int surya_rec_set_mx_weights(surya_rec* h, const void* const* table, int n);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Op-level entry points (unit tests of the kernels through the same library; row-major, compute dtype).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -188,6 +202,14 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream);
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream);
+/* MXFP8 ops (csrc/gemm_mx.h). quantize: fp32 rows [rows][K], K % 128 == 0 -> e4m3 [rows][K] + e8m0 scales K-tile-major
+ * [K / 128][rows][4], with the rule every producer kernel uses (block scale = smallest power of two that keeps absmax <=
+ * 448, round to nearest even). gemm_mx: C[M,N] fp32 = X W^T from MXFP8 operands (scales K-tile-major with M resp. N rows),
+ * M <= 256. mode 0: one pass; mode 1: split-K, `C` receives the slabs [*splitk][M][N] (capacity 8 slabs) and the caller sums
+ * them; mode 2: SwiGLU epilogue -> MXFP8 [M][N/2] in q_out, scales [N / 256][M][4] in sq_out (N % 256 == 0). */
+int surya_op_mx_quantize(const float* x, int rows, int K, uint8_t* q, uint8_t* scales, void* stream);
+int surya_op_gemm_mx(int mode, const uint8_t* X, const uint8_t* SX, const uint8_t* W, const uint8_t* SW, int M, int N, int K,
+                     float* C, int* splitk, uint8_t* q_out, uint8_t* sq_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Detection model: EfficientViT-L backbone + SegFormer-style decode head + sigmoid + x4 bilinear upsample.

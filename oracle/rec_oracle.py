@@ -26,6 +26,23 @@ SD = Dict[str, torch.Tensor]
 # ALL_ATTENTION_FUNCTIONS["sdpa"], decoder/__init__.py:220-222), <= 5e-7 apart in fp32 and what a user of the
 # reference actually runs: bench.py's cpu_baseline times this one.
 ATTN_IMPL = "eager"
+# Emulation of the MXFP8 decode path (csrc/gemm_mx.h): when True, OracleRecModel.decode() quantise-dequantises both operands
+# of the decoder projections and lm_head (oracle/mx_oracle.py; weights from their bf16 rounding, as the product does). There is
+# no reference counterpart -- this pins the product's fp8 arithmetic to the published MX format, not to surya.
+MX_DECODE = False
+_MX_W = {}
+
+
+def _lin(x, sd, key, bias_key=None, mx=False):
+    w = sd[key]
+    b = sd[bias_key] if bias_key else None
+    if mx:
+        from . import mx_oracle
+        ck = (id(sd), key)
+        if ck not in _MX_W:
+            _MX_W[ck] = mx_oracle.fake_quant(w.bfloat16().float())
+        return F.linear(mx_oracle.fake_quant(x), _MX_W[ck].to(x.dtype), b)
+    return F.linear(x, w, b)
 
 
 # ------------------------------------------------------------------------------------------ shared pieces
@@ -219,7 +236,7 @@ class OracleKV:
 
 
 def decoder_forward(sd: SD, d: DecoderConfig, x: torch.Tensor, attention_mask, position_ids, cache: OracleKV,
-                    taps: Optional[dict] = None) -> torch.Tensor:
+                    taps: Optional[dict] = None, mx: bool = False) -> torch.Tensor:
     """SuryaDecoderModel.forward (decoder/__init__.py:417-490) with the eager attention of :101-128."""
     B, S, H = x.shape
     nq, nkv, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
@@ -231,9 +248,9 @@ def decoder_forward(sd: SD, d: DecoderConfig, x: torch.Tensor, attention_mask, p
     for li in range(d.num_hidden_layers):
         p = f"decoder.layers.{li}."
         h = rms_norm(x, sd[p + "input_layernorm.weight"], d.rms_norm_eps)
-        q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]).view(B, S, nq, hd).transpose(1, 2)
-        k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
-        v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
+        q = _lin(h, sd, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias", mx).view(B, S, nq, hd).transpose(1, 2)
+        k = _lin(h, sd, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias", mx).view(B, S, nkv, hd).transpose(1, 2)
+        v = _lin(h, sd, p + "self_attn.v_proj.weight", p + "self_attn.v_proj.bias", mx).view(B, S, nkv, hd).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin                                # apply_rotary_pos_emb :60-84
         k = k * cos + rotate_half(k) * sin
         k, v = cache.update(li, k, v)
@@ -247,10 +264,10 @@ def decoder_forward(sd: SD, d: DecoderConfig, x: torch.Tensor, attention_mask, p
             w = torch.matmul(q, kk.transpose(2, 3)) * scaling + mask[:, :, :, : kk.shape[-2]]
             w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
             a = torch.matmul(w, vv).transpose(1, 2).reshape(B, S, -1)
-        x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"])
+        x = x + _lin(a, sd, p + "self_attn.o_proj.weight", None, mx)
         h = rms_norm(x, sd[p + "post_attention_layernorm.weight"], d.rms_norm_eps)
-        h = F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"])
-        x = x + F.linear(h, sd[p + "mlp.down_proj.weight"])
+        h = F.silu(_lin(h, sd, p + "mlp.gate_proj.weight", None, mx)) * _lin(h, sd, p + "mlp.up_proj.weight", None, mx)
+        x = x + _lin(h, sd, p + "mlp.down_proj.weight", None, mx)
         if taps is not None:
             taps[f"dec_layer{li}"] = x.clone()
     return rms_norm(x, sd["decoder.norm.weight"], d.rms_norm_eps)
@@ -278,10 +295,10 @@ class OracleRecModel:
             x = x.masked_scatter(m, feats.to(x.dtype))
         return x
 
-    def heads(self, hidden_last: torch.Tensor):
+    def heads(self, hidden_last: torch.Tensor, mx: bool = False):
         """:323-330 with logits_to_keep=1."""
         bbox = torch.sigmoid(F.linear(hidden_last, self.sd["bbox_head.weight"], self.sd["bbox_head.bias"]))
-        lm = F.linear(hidden_last, self.sd["lm_head.weight"], self.sd["lm_head.bias"])
+        lm = _lin(hidden_last, self.sd, "lm_head.weight", "lm_head.bias", mx)
         return lm, bbox
 
     @torch.inference_mode()
@@ -294,8 +311,8 @@ class OracleRecModel:
     @torch.inference_mode()
     def decode(self, input_ids, attention_mask, position_ids):
         x = self.sd["embedder.token_embed.weight"][input_ids]
-        h = decoder_forward(self.sd, self.cfg.decoder, x, attention_mask, position_ids, self.cache)
-        return self.heads(h[:, -1:, :])
+        h = decoder_forward(self.sd, self.cfg.decoder, x, attention_mask, position_ids, self.cache, mx=MX_DECODE)
+        return self.heads(h[:, -1:, :], mx=MX_DECODE)
 
 
 def process_outputs(lm_logits, bbox_logits, eos_id: int, pad_id: int, bbox_size: int):

@@ -100,6 +100,35 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ---- MX quantisation helpers (producers of an MXFP8 GEMM operand: gemm_mx.h's SwiGLU epilogue, kernels.h, decode_attn.h) -----------
+// Scale of a block = the smallest power of two s with absmax / s <= 448 (the e4m3 maximum): nothing saturates. (The OCP
+// recipe floor(log2 absmax) - 8 can leave values in (448, 512) s that clip.) E8M0 byte = exponent + 127; an all-zero block
+// gets byte 0.
+__device__ __forceinline__ int mx_block_exp(float absmax) {
+    if (!(absmax > 0.f)) return -127;
+    int ex;
+    const float f = frexpf(absmax, &ex);             // absmax = f * 2^ex, f in [0.5, 1); 448 = 0.875 * 2^9
+    const int e = (f <= 0.875f) ? ex - 9 : ex - 8;
+    return max(-127, min(127, e));
+}
+// 4 floats (already divided by the block scale) -> 4 e4m3 bytes, round to nearest even (v_cvt_pk_fp8_f32, OCP on gfx950)
+__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) { return fmaxf(v, dpp_mov<CTRL>(v)); }
+__device__ __forceinline__ float quad_max(float v) { return dpp_max<0x4E>(dpp_max<0xB1>(v)); }
+__device__ __forceinline__ float oct_max(float v) { return dpp_max<0x141>(quad_max(v)); }      // aligned groups of 8 lanes
+// This lane owns 4 consecutive elements; the aligned group of 8 lanes owns one 32-element MX block (all 8 lanes active).
+__device__ __forceinline__ uint32_t mx_quant4_oct(const float (&v)[4], int& e8) {
+    const float m = oct_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    const int e = mx_block_exp(m);
+    e8 = e + 127;
+    return mx_pack4(ldexpf(v[0], -e), ldexpf(v[1], -e), ldexpf(v[2], -e), ldexpf(v[3], -e));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
                                                                 bf16_t* __restrict__ out, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                                 const int* __restrict__ active_slots, const int* __restrict__ row_len,
                                                                 const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
-                                                                float scale) {
+                                                                float scale, uint8_t* __restrict__ out8 = nullptr,
+                                                                uint8_t* __restrict__ sout = nullptr, int srows = 0) {
     typedef bf16_t T;
     constexpr int CPR = D / 8;                               // 16-byte chunks per K/V row
     constexpr int ROWB = D * 2;                              // bytes per K/V row
@@ -481,7 +482,16 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
             den += e * rec[D + 1];
         }
         const float inv = 1.0f / den;
-        store4(out + (long)a * nq * D + (long)(kvh * G + oh) * D + od, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+        const long o_off = (long)a * nq * D + (long)(kvh * G + oh) * D + od;
+        store4(out + o_off, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+        if (out8) {   // MXFP8 copy for the fp8 o-projection (gemm_mx.h): 8 adjacent threads own one 32-wide block of a head
+            const float q[4] = {Ty<T>::rnd(num[0] * inv), Ty<T>::rnd(num[1] * inv), Ty<T>::rnd(num[2] * inv), Ty<T>::rnd(num[3] * inv)};
+            int e8;
+            const uint32_t pk = mx_quant4_oct(q, e8);
+            *reinterpret_cast<uint32_t*>(out8 + o_off) = pk;
+            const int col = (kvh * G + oh) * D + od;             // K-tile-major scales (gemm_mx.h): [col / 128][srows][4]
+            if ((tid & 7) == 0) sout[((long)(col >> 7) * srows + a) * 4 + ((col >> 5) & 3)] = (uint8_t)e8;
+        }
     }
     SA_DA_STAMP(7)
     SA_DA_STAMP(8)

@@ -290,7 +290,9 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 template <typename T>
 __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float* __restrict__ part, int S, int M, T* __restrict__ x,
                                                                     const T* __restrict__ bias, const T* __restrict__ w,
-                                                                    T* __restrict__ y, int H, float eps) {
+                                                                    T* __restrict__ y, int H, float eps,
+                                                                    uint8_t* __restrict__ y8 = nullptr, uint8_t* __restrict__ sy = nullptr,
+                                                                    int srows = 0) {
     const int row = blockIdx.x, tid = threadIdx.x;       // one workgroup per row: M workgroups keep the chip busy at M = 256
     __shared__ float red[16];
     T* xr = x + (long)row * H;
@@ -325,9 +327,18 @@ __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float*
     float tot = 0.f;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
     const float rstd = rsqrtf(tot / (float)H + eps);
-    if (on_row)
-        store4(y + (long)row * H + c, g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
-               g[3] * Ty<T>::rnd(v[3] * rstd));
+    const float o[4] = {g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
+                        g[3] * Ty<T>::rnd(v[3] * rstd)};
+    if (on_row) store4(y + (long)row * H + c, o[0], o[1], o[2], o[3]);
+    if (y8) {   // MXFP8 copy of the normalised row for the fp8 decode GEMMs (gemm_mx.h): 8 lanes = one 32-element block (H % 32 == 0)
+        const float q[4] = {Ty<T>::rnd(o[0]), Ty<T>::rnd(o[1]), Ty<T>::rnd(o[2]), Ty<T>::rnd(o[3])};
+        int e8;
+        const uint32_t pk = mx_quant4_oct(q, e8);
+        if (on_row) {
+            *reinterpret_cast<uint32_t*>(y8 + (long)row * H + c) = pk;
+            if ((tid & 7) == 0) sy[((long)(c >> 7) * srows + row) * 4 + ((c >> 5) & 3)] = (uint8_t)e8;   // K-tile-major scales (gemm_mx.h)
+        }
+    }
 }
 
 // Decode-step embedding fused with the first layer's input RMSNorm: x[a] = table[next_token[slot]], y[a] = norm(x[a]).
@@ -335,7 +346,9 @@ template <typename T>
 __global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
                                                               const int* __restrict__ active_slots, const int* __restrict__ kv_len,
                                                               int Tmax, int* __restrict__ row_len, T* __restrict__ x,
-                                                              const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
+                                                              const T* __restrict__ w, T* __restrict__ y, int H, float eps,
+                                                              uint8_t* __restrict__ y8 = nullptr, uint8_t* __restrict__ sy = nullptr,
+                                                              int srows = 0) {
     const int a = blockIdx.x, lane = threadIdx.x;
     const int slot = active_slots[a];
     // compact per-row context length for this step's attention kernels; clamped so a slot that keeps stepping after its
@@ -357,8 +370,16 @@ __global__ __launch_bounds__(64) void embed_slots_norm_kernel(const T* __restric
         float v[4], g[4];
         load4(src + c, v);
         load4(w + c, g);
-        store4(yr + c, g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
-               g[3] * Ty<T>::rnd(v[3] * rstd));
+        const float o[4] = {g[0] * Ty<T>::rnd(v[0] * rstd), g[1] * Ty<T>::rnd(v[1] * rstd), g[2] * Ty<T>::rnd(v[2] * rstd),
+                            g[3] * Ty<T>::rnd(v[3] * rstd)};
+        store4(yr + c, o[0], o[1], o[2], o[3]);
+        if (y8) {   // MXFP8 copy (H % 256 == 0 on this path: whole 8-lane groups stay inside the row)
+            const float q[4] = {Ty<T>::rnd(o[0]), Ty<T>::rnd(o[1]), Ty<T>::rnd(o[2]), Ty<T>::rnd(o[3])};
+            int e8;
+            const uint32_t pk = mx_quant4_oct(q, e8);
+            *reinterpret_cast<uint32_t*>(y8 + (long)a * H + c) = pk;
+            if ((lane & 7) == 0) sy[((long)(c >> 7) * srows + a) * 4 + ((c >> 5) & 3)] = (uint8_t)e8;
+        }
     }
 }
 

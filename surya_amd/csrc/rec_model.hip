@@ -19,6 +19,7 @@
 
 #include "../../include/surya_amd.h"
 #include "gemm.h"
+#include "gemm_mx.h"
 #include "kernels.h"
 #include "decode_attn.h"
 #include "attn_mfma.h"
@@ -154,6 +155,7 @@ struct RecBase {
     virtual int encode_only(const float*, const int32_t*, int, void*, hipStream_t) = 0;
     virtual int copy_last_logits(float*, int, int*, hipStream_t) = 0;
     virtual int set_next_tokens(const int32_t*, const int32_t*, int, hipStream_t) = 0;
+    virtual int set_mx_weights(const void* const*, int) = 0;
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -186,6 +188,7 @@ struct RecModel : RecBase {
     size_t out_bytes = 0;
     int n_active = 0;
     int last_rows = 0;
+    bool last_heads_mx = false;                          // the last heads() call ran the MXFP8 lm_head (test hook below)
     // hipGraph replay of decode steps: a step is ~113 short launches; captured once per (active rows, steps) and replayed
     // from an internal stream (capture is not allowed on the legacy default stream torch hands us).
     hipStream_t gstream = nullptr;
@@ -194,6 +197,16 @@ struct RecModel : RecBase {
     std::map<long, hipGraphExec_t> graphs;
     std::set<long> seen_keys;
     bool use_graph = true;
+    // MXFP8 decode weights (surya_rec_set_mx_weights; gemm_mx.h): e4m3 copies + e8m0 block scales of the decoder projections
+    // and lm_head, used by the decode steps only (prefill keeps the bf16 weights), and MXFP8 twins of the four decode-step
+    // activation buffers, written by the kernels that produce the bf16 ones.
+    std::vector<const uint8_t*> mxw;
+    char* mx_arena = nullptr;
+    uint8_t *dh8 = nullptr, *sdh = nullptr, *dattn8 = nullptr, *sattn = nullptr, *dmlp8 = nullptr, *smlp = nullptr, *dlast8 = nullptr,
+            *slast = nullptr;
+    bool mx() const { return !mxw.empty(); }
+    const uint8_t* MXW(int l, int k) const { return mxw[(size_t)l * SA_MX_COUNT + k]; }
+    const uint8_t* MXG(int k) const { return mxw[(size_t)c.dec_layers * SA_MX_COUNT + k]; }
 
     const T* W(int idx) const { return reinterpret_cast<const T*>(w[idx]); }
     const T* WE(int l, int k) const { return W(SA_RW_ENC(l, k)); }
@@ -294,6 +307,7 @@ struct RecModel : RecBase {
         return SA_OK;
     }
     ~RecModel() override {
+        if (mx_arena) (void)hipFree(mx_arena);
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         if (gstream) (void)hipStreamDestroy(gstream);
         if (gev_in) (void)hipEventDestroy(gev_in);
@@ -514,12 +528,50 @@ struct RecModel : RecBase {
         *S = a.splitk;
         return rc;
     }
-    int reduce_residual_norm(int S, int M, const float* part_, T* x, const T* wnorm, T* y, hipStream_t s) {
+    int reduce_residual_norm(int S, int M, const float* part_, T* x, const T* wnorm, T* y, hipStream_t s, uint8_t* y8 = nullptr,
+                             uint8_t* sy = nullptr) {
         const int threads = cdiv(c.dec_hidden / 4, 64) * 64;         // one 4-element chunk per thread
         if (threads > 1024 || c.dec_hidden % 4) return SA_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr,
-                           wnorm, y, c.dec_hidden, c.dec_eps);
+                           wnorm, y, c.dec_hidden, c.dec_eps, y8, sy, c.max_slots);
         return (int)hipGetLastError();
+    }
+    // Activation scale tensors are K-tile-major with max_slots rows per K-tile ([K / 128][max_slots][4]); a row range of the
+    // batch is a pointer offset of 4 bytes per row.
+    int splitk_gemm_mx(const uint8_t* X, const uint8_t* SX, long ldx, const uint8_t* Wq, const uint8_t* SW, int M, int N, int K,
+                       float* part_, int* S, hipStream_t s) {
+        MxArgs a{X, ldx, SX, Wq, (long)K, SW, M, N, K, (long)c.max_slots, (long)N};
+        a.part = part_;
+        int rc = launch_gemm_mx_splitk(a, s);
+        *S = a.splitk;
+        return rc;
+    }
+
+    // MXFP8 weight table of the decode steps: per layer SA_MX_COUNT pointers, then SA_MX_LM_W, SA_MX_LM_S. bf16 model only.
+    int set_mx_weights(const void* const* tbl, int n) override {
+        if constexpr (!std::is_same<T, bf16_t>::value) return SA_ERR_UNSUPPORTED;
+        if (!tbl) { mxw.clear(); return SA_OK; }                     // back to the bf16 decode weights
+        if (n != SA_MX_TOTAL(c.dec_layers)) return SA_ERR_ARG;
+        for (int i = 0; i < n; ++i)
+            if (!tbl[i]) return SA_ERR_ARG;
+        const int Hd = c.dec_hidden, A = c.dec_heads * c.dec_head_dim, I = c.dec_inter;
+        if (Hd % 128 || A % 128 || I % 128 || c.dec_head_dim % 32) return SA_ERR_SHAPE;     // whole 128-element K-tiles, 32-wide blocks
+        if (!mx_arena) {
+            const size_t S = c.max_slots;
+            size_t off = 0;
+            auto take = [&](size_t b) { size_t o = off; off = align_up(off + b); return o; };
+            const size_t o1 = take(S * Hd), o2 = take(S * Hd / 32), o3 = take(S * A), o4 = take(S * A / 32), o5 = take(S * I),
+                         o6 = take(S * I / 32), o7 = take(S * Hd), o8 = take(S * Hd / 32);
+            SA_HIP(hipMalloc((void**)&mx_arena, off));
+            SA_HIP(hipMemset(mx_arena, 0, off));
+            uint8_t* b = reinterpret_cast<uint8_t*>(mx_arena);
+            dh8 = b + o1; sdh = b + o2; dattn8 = b + o3; sattn = b + o4; dmlp8 = b + o5; smlp = b + o6; dlast8 = b + o7; slast = b + o8;
+        }
+        mxw.resize(n);
+        for (int i = 0; i < n; ++i) mxw[i] = reinterpret_cast<const uint8_t*>(tbl[i]);
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the old launch arguments
+        graphs.clear(); seen_keys.clear();
+        return SA_OK;
     }
 
     // The rows of a decode step and their workspaces: every per-row buffer is row-major, so a row range is a pointer offset.
@@ -530,7 +582,7 @@ struct RecModel : RecBase {
         const int Hd = c.dec_hidden;
         hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(h.M), dim3(64), 0, h.s, W(SA_RW_TOK_EMBED), next_token, active_dev + h.r0,
                            kv_len, c.max_kv_len, row_len + h.r0, dx + (size_t)h.r0 * Hd, WD(0, SA_RD_LN1), dh + (size_t)h.r0 * Hd, Hd,
-                           c.dec_eps);
+                           c.dec_eps, mx() ? dh8 + (size_t)h.r0 * Hd : nullptr, mx() ? sdh + (size_t)h.r0 * 4 : nullptr, c.max_slots);
         return (int)hipGetLastError();
     }
 
@@ -552,19 +604,29 @@ struct RecModel : RecBase {
         const int* act = active_dev + h.r0;
         const int* rl = row_len + h.r0;
         int rc, S = 1;
-        if ((rc = splitk_gemm(hh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, h.part, &S, s))) return rc;
+        const bool q8 = mx();
+        const int A = nq * d;
+        uint8_t *hh8 = nullptr, *shh = nullptr, *at8 = nullptr, *sat = nullptr, *ml8 = nullptr, *sml = nullptr;
+        if (q8) {
+            hh8 = dh8 + (size_t)h.r0 * Hd; shh = sdh + (size_t)h.r0 * 4;
+            at8 = dattn8 + (size_t)h.r0 * A; sat = sattn + (size_t)h.r0 * 4;
+            ml8 = dmlp8 + (size_t)h.r0 * I; sml = smlp + (size_t)h.r0 * 4;
+        }
+        if (q8) rc = splitk_gemm_mx(hh8, shh, Hd, MXW(l, SA_MX_QKV_W), MXW(l, SA_MX_QKV_S), M, qkv_d, Hd, h.part, &S, s);
+        else rc = splitk_gemm(hh, Hd, WD(l, SA_RD_QKV_W), Hd, M, qkv_d, Hd, h.part, &S, s);
+        if (rc) return rc;
         dim3 grid(M, nkv), block(256);
         const int G = nq / nkv;
-#define SA_DEC_LAUNCH(KERN, LDS)                                                                                            \
+#define SA_DEC_LAUNCH(KERN, LDS, ...)                                                                                       \
     {                                                                                                                       \
         auto kern = KERN;                                                                                                   \
         static AttrOnce attr;                                                                                               \
         attr.ensure(kern, LDS);                                                                                             \
         hipLaunchKernelGGL(kern, grid, block, LDS, s, h.part, S, WD(l, SA_RD_QKV_B), at, kc, vc, act, rl, rope_cs, nq, nkv,  \
-                           c.max_kv_len, scale);                                                                            \
+                           c.max_kv_len, scale, ##__VA_ARGS__);                                                             \
     }
 #define SA_DEC_MFMA(DD, GG) SA_DEC_LAUNCH((decode_attn_mfma_kernel<T, DD, GG>), (decode_attn_mfma_lds<T, DD, GG>()))
-#define SA_DEC_FLASH(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()))
+#define SA_DEC_FLASH(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), at8, sat, c.max_slots)
         bool launched = false;
         if constexpr (std::is_same<T, bf16_t>::value) {      // bf16: per-wave flash kernel (decode_attn.h, third version)
             launched = true;
@@ -585,13 +647,25 @@ struct RecModel : RecBase {
 #undef SA_DEC_MFMA
 #undef SA_DEC_LAUNCH
         if ((rc = (int)hipGetLastError())) return rc;
+        if (q8 && !launched) return SA_ERR_UNSUPPORTED;      // only the flash kernel writes the MXFP8 copy of its output
+        const bool last = (l + 1 == c.dec_layers);
+        const T* wnext = last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1);
+        T* ynext = last ? dlast + (size_t)h.r0 * Hd : hh;
+        if (q8) {
+            if ((rc = splitk_gemm_mx(at8, sat, A, MXW(l, SA_MX_O_W), MXW(l, SA_MX_O_S), M, Hd, A, h.part, &S, s))) return rc;
+            if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s, hh8, shh))) return rc;
+            MxArgs g{hh8, Hd, shh, MXW(l, SA_MX_GU_W), Hd, MXW(l, SA_MX_GU_S), M, 2 * I, Hd, (long)c.max_slots, (long)2 * I};
+            g.Q = ml8; g.ldq = I; g.SQ = sml; g.sq_rows = c.max_slots;
+            if ((rc = launch_gemm_mx<MX_EPI_SWIGLU>(g, s))) return rc;
+            if ((rc = splitk_gemm_mx(ml8, sml, I, MXW(l, SA_MX_DOWN_W), MXW(l, SA_MX_DOWN_S), M, Hd, I, h.part, &S, s))) return rc;
+            return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s, last ? dlast8 + (size_t)h.r0 * Hd : hh8,
+                                        last ? slast + (size_t)h.r0 * 4 : shh);
+        }
         if ((rc = splitk_gemm(at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, h.part, &S, s))) return rc;
         if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s))) return rc;
         if ((rc = gemm<EPI_SWIGLU>(hh, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
         if ((rc = splitk_gemm(ml, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, h.part, &S, s))) return rc;
-        const bool last = (l + 1 == c.dec_layers);
-        return reduce_residual_norm(S, M, h.part, x, last ? W(SA_RW_DEC_NORM) : WD(l + 1, SA_RD_LN1),
-                                    last ? dlast + (size_t)h.r0 * Hd : hh, s);
+        return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s);
     }
 
     int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s) {
@@ -601,16 +675,29 @@ struct RecModel : RecBase {
         float4* am = amax;
         if (!normed && (rc = rmsnorm(dx, Hd, W(SA_RW_DEC_NORM), last, Hd, d_last_row, rows, Hd, c.dec_eps, s))) return rc;
         // lm_head with the greedy reduction in its epilogue: logits stay in LDS, the head combines per-tile partials.
-        GemmArgs<T, float> a{last, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
-        a.amax = am;
-        if ((rc = launch_gemm<T, float, EPI_ARGMAX>(a, s))) return rc;
-        const int tiles_n = cdiv(c.vocab, a.bn_used);
+        int bn_used = 0;
+        if (mx() && normed) {       // decode steps: MXFP8 lm_head on the MXFP8 copy of the final-norm rows
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                MxArgs a{dlast8, Hd, slast, MXG(SA_MX_LM_W), Hd, MXG(SA_MX_LM_S), rows, c.vocab, Hd, (long)c.max_slots, (long)c.vocab};
+                a.amax = am;
+                a.bias = W(SA_RW_LM_B);
+                if ((rc = launch_gemm_mx<MX_EPI_ARGMAX>(a, s))) return rc;
+                bn_used = a.bn_used;
+            }
+        } else {
+            GemmArgs<T, float> a{last, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, rows, c.vocab, Hd};
+            a.amax = am;
+            if ((rc = launch_gemm<T, float, EPI_ARGMAX>(a, s))) return rc;
+            bn_used = a.bn_used;
+        }
+        const int tiles_n = cdiv(c.vocab, bn_used);
         const size_t so = (size_t)step * c.max_slots;
         hipLaunchKernelGGL((greedy_head_kernel<T, true>), dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(am),
                            (long)tiles_n, tiles_n, last, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
                            c.pad_token_id, (float)c.bbox_size, out_token + so, out_score + so, out_bbox + so * 6, next_token,
                            kv_len, len_inc);
         last_rows = rows;
+        last_heads_mx = mx() && normed;
         return (int)hipGetLastError();
     }
 
@@ -800,9 +887,17 @@ struct RecModel : RecBase {
         *rows = r;
         if (r <= 0) return SA_OK;
         const int Hd = c.dec_hidden;
-        GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, last_rows, c.vocab, Hd};
         int rc;
-        if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
+        if (last_heads_mx) {
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                MxArgs a{dlast8, Hd, slast, MXG(SA_MX_LM_W), Hd, MXG(SA_MX_LM_S), last_rows, c.vocab, Hd, (long)c.max_slots, (long)c.vocab};
+                a.C = logits; a.ldc = c.vocab; a.bias = W(SA_RW_LM_B);
+                if ((rc = launch_gemm_mx<MX_EPI_F32>(a, s))) return rc;
+            }
+        } else {
+            GemmArgs<T, float> a{dlast, Hd, W(SA_RW_LM_W), Hd, logits, c.vocab, W(SA_RW_LM_B), nullptr, 0, last_rows, c.vocab, Hd};
+            if ((rc = launch_gemm<T, float, EPI_BIAS>(a, s))) return rc;
+        }
         SA_HIP(hipMemcpyAsync(dst, logits, (size_t)r * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
         return SA_OK;
     }
@@ -948,6 +1043,11 @@ int surya_rec_set_next_tokens(surya_rec* h, const int32_t* slots, const int32_t*
     return h->impl->set_next_tokens(slots, tokens, n, (hipStream_t)stream);
 }
 
+int surya_rec_set_mx_weights(surya_rec* h, const void* const* table, int n) {
+    if (!h) return SA_ERR_ARG;
+    return h->impl->set_mx_weights(table, n);
+}
+
 int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, const void* W, long ldw, void* C, long ldc,
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream) {
     if (!X || !W || !C) return SA_ERR_ARG;
@@ -957,6 +1057,50 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
         return out_f32 ? op_gemm_t<bf16_t, float>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s)
                        : op_gemm_t<bf16_t, bf16_t>(epi, X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, s);
     return SA_ERR_UNSUPPORTED;
+}
+
+__global__ __launch_bounds__(256) void mx_quantize_rows_kernel(const float* __restrict__ x, int K, uint8_t* __restrict__ q,
+                                                               uint8_t* __restrict__ sc) {
+    const long row = blockIdx.x, rows = gridDim.x;
+    for (int c = threadIdx.x * 4; c < K; c += 1024) {            // K % 32 == 0: an 8-lane group is inside the row or outside it
+        float v[4];
+        load4(x + row * K + c, v);
+        int e8;
+        const uint32_t pk = mx_quant4_oct(v, e8);
+        *reinterpret_cast<uint32_t*>(q + row * K + c) = pk;
+        if ((threadIdx.x & 7) == 0) sc[((long)(c >> 7) * rows + row) * 4 + ((c >> 5) & 3)] = (uint8_t)e8;
+    }
+}
+
+int surya_op_mx_quantize(const float* x, int rows, int K, uint8_t* q, uint8_t* scales, void* stream) {
+    if (!x || !q || !scales || rows <= 0 || K <= 0 || K % 128) return SA_ERR_ARG;
+    hipLaunchKernelGGL(mx_quantize_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, K, q, scales);
+    return (int)hipGetLastError();
+}
+
+int surya_op_gemm_mx(int mode, const uint8_t* X, const uint8_t* SX, const uint8_t* W, const uint8_t* SW, int M, int N, int K,
+                     float* C, int* splitk, uint8_t* q_out, uint8_t* sq_out, void* stream) {
+    if (!X || !SX || !W || !SW) return SA_ERR_ARG;
+    MxArgs a{X, (long)K, SX, W, (long)K, SW, M, N, K, (long)M, (long)N};
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        if (!C) return SA_ERR_ARG;
+        a.C = C; a.ldc = N;
+        return launch_gemm_mx<MX_EPI_F32>(a, s);
+    }
+    if (mode == 1) {
+        if (!C || !splitk) return SA_ERR_ARG;
+        a.part = C;
+        int rc = launch_gemm_mx_splitk(a, s);
+        *splitk = a.splitk;
+        return rc;
+    }
+    if (mode == 2) {
+        if (!q_out || !sq_out) return SA_ERR_ARG;
+        a.Q = q_out; a.ldq = N / 2; a.SQ = sq_out; a.sq_rows = M;
+        return launch_gemm_mx<MX_EPI_SWIGLU>(a, s);
+    }
+    return SA_ERR_ARG;
 }
 
 int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,

@@ -20,7 +20,7 @@ class HipRecModel:
     def __init__(self, cfg: RecConfig, state_dict, *, image_token_id: int, pad_token_id: int, eos_token_id: int,
                  dtype: torch.dtype = torch.bfloat16, device="cuda:0", max_slots: int = 256, max_kv_len: int = 512,
                  max_patches: int = 65536, max_prefill_tokens: Optional[int] = None, broadcast_weights: bool = False,
-                 process_group=None):
+                 process_group=None, decode_fp8: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise L.SuryaAmdError("HipRecModel needs a GPU (MI355X); there is no CPU fallback")
         self.lib = L.lib()
@@ -65,6 +65,30 @@ class HipRecModel:
         self._tok = np.zeros((L.SA_MAX_STEPS, max_slots), np.int32)
         self._score = np.zeros((L.SA_MAX_STEPS, max_slots), np.float32)
         self._bbox = np.zeros((L.SA_MAX_STEPS, max_slots, 6), np.int32)
+        self.mx_weights = None
+        self.decode_fp8 = False
+        if decode_fp8 is None:
+            from ..settings import settings
+            decode_fp8 = settings.RECOGNITION_DECODE_FP8
+        if decode_fp8:
+            self.set_decode_fp8(True)
+
+    def set_decode_fp8(self, on: bool):
+        """Decode steps on MXFP8 weights and activations (surya_rec_set_mx_weights; bf16 models only). The e4m3 / e8m0 twins
+        of the decoder projections and lm_head are quantised once from the kernel-layout bf16 table and stay resident next to
+        it (prefill keeps using the bf16 weights)."""
+        if on and self.dtype != torch.bfloat16:
+            raise ValueError("the fp8 decode path exists for bfloat16 models only")
+        if on:
+            if self.mx_weights is None:
+                from ..mx import repack_rec_mx_weights
+                self.mx_weights = repack_rec_mx_weights(self.cfg, self.weights, self.device)
+            table = (C.c_void_p * len(self.mx_weights))(*[t.data_ptr() for t in self.mx_weights])
+            L.check(self.lib.surya_rec_set_mx_weights(self.handle, table, C.c_int(len(self.mx_weights))), "surya_rec_set_mx_weights")
+        else:
+            L.check(self.lib.surya_rec_set_mx_weights(self.handle, None, C.c_int(0)), "surya_rec_set_mx_weights")
+        torch.cuda.synchronize(self.device)
+        self.decode_fp8 = bool(on)
 
     def __del__(self):
         h = getattr(self, "handle", None)

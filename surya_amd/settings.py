@@ -46,6 +46,9 @@ class Settings:
         # crop / pad / resize / normalise / patchify of the line crops on the GPU (surya_rec_preprocess); 1 keeps the host
         # (numpy, thread pool) pre-processing of round 1 -- the checker of tests/test_gpu_prep.py, not a fallback
         self.RECOGNITION_PREPROCESS_HOST: bool = _env("RECOGNITION_PREPROCESS_HOST", bool, False)
+        # decode steps on MXFP8 weights + activations (csrc/gemm_mx.h; BASELINE.json configs[4]). Off by default: the
+        # reference computes in the checkpoint dtype, and fp8 changes which token wins a near-tie
+        self.RECOGNITION_DECODE_FP8: bool = _env("RECOGNITION_DECODE_FP8", bool, False)
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
         # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the

@@ -5,7 +5,9 @@ For every tuning configuration (surya_set_tuning, csrc/common.h sa::Tuning) this
 read, and reports wall us/step (HIP events around the whole run) plus whether the greedy tokens equal the first
 configuration's (tile / split-K changes re-order fp32 sums, so bf16 argmax near-ties may flip; reported, not asserted).
 
-    python tools/microbench/decode_sweep.py [--steps 32] [--configs all|base]
+    python tools/microbench/decode_sweep.py [--steps 32] [--configs all|base|fp8]
+
+`fp8`: bf16 decode vs the MXFP8 decode path (HipRecModel.set_decode_fp8, csrc/gemm_mx.h) on the same lines.
 
 The tile-shape / dual-stream / lm_head-ring / skinny-GEMM variants swept in round 2 lost and were removed from the library; their
 results are in profiles/r02_decode_sweeps.md.
@@ -58,6 +60,10 @@ def main():
     base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8)
     if args.configs == "base":
         variants = [dict()]
+    elif args.configs == "fp8only":
+        variants = [dict(fp8=1)]
+    elif args.configs == "fp8":
+        variants = [dict(), dict(fp8=1), dict(fp8=1, split_min_kt=2), dict(fp8=1, split_min_kt=3), dict(fp8=1, split_target=320)]
     else:
         variants = [dict(), dict(graph=1), dict(split_target=512), dict(split_target=384), dict(split_target=192), dict(split_min_kt=2),
                     dict(split_max=4)]
@@ -85,7 +91,10 @@ def main():
     ref = None
     print(f"# REC-FULL bf16, {n} active slots, {args.steps} decode steps per run, us/step (event) | us/step (host wall) | tokens == config 0")
     for v in variants:
+        v = dict(v)
+        m.set_decode_fp8(bool(v.pop("fp8", 0)))
         setk(**{**base, **v})
+        v = {**v, "fp8": int(m.decode_fp8)}
         run(8)                                   # warm-up (attribute set, graph capture on 2nd sight)
         run(8)
         best = min((run(args.steps) for _ in range(3)), key=lambda r: r[0])
@@ -94,6 +103,7 @@ def main():
         same = float((best[2] == ref).all(axis=0).mean())
         print(f"{str(v):90s} {best[0]:8.1f} {best[1]:8.1f}   lines identical {same:.3f}", flush=True)
     setk(**base)
+    m.set_decode_fp8(False)
 
 
 if __name__ == "__main__":
