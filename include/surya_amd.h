@@ -153,7 +153,8 @@ int surya_rec_wait_outputs(surya_rec* h, int n_steps, int ring, int32_t* tokens,
  * Replaces, per line, slice_bboxes_from_image / slice_and_pad_poly (surya/input/processing.py:35-101), scale_to_fit
  * (surya/common/surya/processor/__init__.py:141-178, LANCZOS4) and _process_and_tile (:185-230: CUBIC round-up to multiples of
  * patch * merge, x / 255 in fp64, (x - mean) / std in fp32, merge-block-major patch rows).
- * pages: device uint8, every page RGB HWC at its descriptor's byte offset. lines: device array of n_lines descriptors
+ * pages: device uint8, every page HWC at its descriptor's byte offset, `pixel_stride` bytes per pixel: 3 (RGB) or 4 (RGBX, the
+ * layout PIL keeps in memory -- the host then uploads page memory as is instead of repacking it, ~2 ms per 1024^2 page). lines: device array of n_lines descriptors
  *   { int64 page_off; int32 page_w, page_h; int32 x0, y0, cw, ch (crop rectangle, inside the page, >= 1 px);
  *     int32 has_poly; float poly[8] (4 vertices relative to the crop origin; pixels outside read as pad_value);
  *     int32 mid_w, mid_h (size after scale_to_fit); int32 out_w, out_h (multiples of patch * merge);
@@ -164,7 +165,7 @@ int surya_rec_wait_outputs(surya_rec* h, int n_steps, int ring, int32_t* tokens,
  * mid size differs from their crop size (0 = no line needs the Lanczos stage). Enqueue only; every buffer is caller-owned. */
 int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
                          int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
-                         int max_stage1_width, void* stream);
+                         int max_stage1_width, int pixel_stride, void* stream);
 
 /* Test hooks (tolerance tests of intermediate tensors):
  *   encode_only: run the vision encoder + 2-D position embedding, write [P/merge^2, dec_hidden] features in
@@ -251,12 +252,13 @@ int surya_det_destroy(surya_det* h);
  * heatmaps: device fp32 [batch, labels, H, W] (may be NULL); lowres: device fp32 [batch, labels, H/4, W/4] (may be NULL)
  * = the model's own output before the predictor-side upsample. Enqueue only. */
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream);
-/* Same forward from the resized pages themselves: device uint8 [batch, H, W, 3] (RGB, as PIL delivers them). The rescale
+/* Same forward from the resized pages themselves: device uint8 [batch, H, W, pixel_stride], pixel_stride 3 (RGB) or 4 (RGBX =
+ * PIL's in-memory layout, uploaded without repacking; the fourth byte is ignored). The rescale
  * (x * 1/255 in fp32) and normalisation ((x - mean) / std) of SegformerImageProcessor._preprocess
  * (surya/detection/processor.py:126-146) run inside the first layout kernel: bit-identical pixel_values, a quarter of the
  * PCIe bytes, no per-pixel host work. */
-int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, const float* mean, const float* std, int batch, float* heatmaps,
-                         float* lowres, void* stream);
+int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, int pixel_stride, const float* mean, const float* std, int batch,
+                         float* heatmaps, float* lowres, void* stream);
 
 /* Heat map -> text boxes on the device. Replaces detect_boxes (surya/detection/heatmap.py:27-107:
  * get_dynamic_thresholds :14-24, cv2.connectedComponentsWithStats, per-component cv2.dilate + cv2.minAreaRect + cv2.boxPoints,

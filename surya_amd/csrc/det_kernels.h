@@ -26,11 +26,11 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 // page crosses PCIe as 3 bytes per pixel instead of 12 and the host never touches its pixels (det side).
 template <typename T>
 __global__ void u8_to_nhwc_kernel(const unsigned char* __restrict__ in, T* __restrict__ out, long P, int CP, float m0, float m1,
-                                  float m2, float s0, float s1, float s2) {
+                                  float m2, float s0, float s1, float s2, int pix) {
 #pragma clang fp contract(off)
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;      // pixel index over B*H*W
     if (p >= P) return;
-    const unsigned char* px = in + p * 3;
+    const unsigned char* px = in + p * pix;                           // 3 = RGB, 4 = RGBX (PIL's in-memory layout)
     const float k = 1.0f / 255.0f;                                    // np.float32(1 / 255.0)
     T* o = out + p * CP;
     Ty<T>::st(o + 0, ((float)px[0] * k - m0) / s0);

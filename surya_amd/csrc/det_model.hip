@@ -16,7 +16,7 @@ namespace sa {
 struct DetBase {
     virtual ~DetBase() {}
     virtual int forward(const float* pixels, const unsigned char* pixels_u8, const float* mean_std, int B, float* heat, float* lowres,
-                        hipStream_t s) = 0;
+                        hipStream_t s, int pix = 3) = 0;
 };
 
 template <typename T>
@@ -59,7 +59,7 @@ struct DetModel : DetBase {
     const T* WT(int idx) const { return idx < 0 ? nullptr : reinterpret_cast<const T*>(w[idx]); }
 
     int forward(const float* pixels, const unsigned char* pixels_u8, const float* ms, int B, float* heat, float* lowres,
-                hipStream_t s) override {
+                hipStream_t s, int pix = 3) override {
         if (B <= 0 || B > max_batch) return SA_ERR_ARG;
         int rc;
         for (const surya_det_op& op : ops) {
@@ -69,7 +69,7 @@ struct DetModel : DetBase {
                     if (pixels_u8) {
                         if (op.cin != 3) return SA_ERR_SHAPE;
                         hipLaunchKernelGGL(u8_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels_u8, bufs[op.out], P,
-                                           op.cout, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5]);
+                                           op.cout, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], pix);
                     } else {
                         hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3((unsigned)cdivl(P, 256)), dim3(256), 0, s, pixels, bufs[op.out], B,
                                            op.cin, op.hin, op.win, op.cout);
@@ -216,11 +216,11 @@ int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float*
     return h->impl->forward(pixel_values, nullptr, nullptr, batch, heatmaps, lowres, (hipStream_t)stream);
 }
 
-int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, const float* mean, const float* std, int batch, float* heatmaps,
-                         float* lowres, void* stream) {
-    if (!h || !pixels_nhwc || !mean || !std || (!heatmaps && !lowres)) return SA_ERR_ARG;
+int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, int pixel_stride, const float* mean, const float* std, int batch,
+                         float* heatmaps, float* lowres, void* stream) {
+    if (!h || !pixels_nhwc || !mean || !std || (!heatmaps && !lowres) || (pixel_stride != 3 && pixel_stride != 4)) return SA_ERR_ARG;
     const float ms[6] = {mean[0], mean[1], mean[2], std[0], std[1], std[2]};
-    return h->impl->forward(nullptr, pixels_nhwc, ms, batch, heatmaps, lowres, (hipStream_t)stream);
+    return h->impl->forward(nullptr, pixels_nhwc, ms, batch, heatmaps, lowres, (hipStream_t)stream, pixel_stride);
 }
 
 }  // extern "C"

@@ -1105,13 +1105,15 @@ int surya_op_gemm_mx(int mode, const uint8_t* X, const uint8_t* SX, const uint8_
 
 int surya_rec_preprocess(const uint8_t* pages, const void* lines, int n_lines, uint8_t* mask_arena, float* mid_arena, float* tiles,
                          int patch_size, int merge_size, float pad_value, const float* mean, const float* std, int any_poly,
-                         int max_stage1_width, void* stream) {
+                         int max_stage1_width, int pixel_stride, void* stream) {
     if (!pages || !lines || !tiles || !mean || !std || n_lines < 0 || patch_size <= 0 || merge_size <= 0) return SA_ERR_ARG;
+    if (pixel_stride != 3 && pixel_stride != 4) return SA_ERR_ARG;
     sa::prep::PrepArgs p;
     p.pages = pages; p.lines = reinterpret_cast<const sa::prep::LineDesc*>(lines); p.n_lines = n_lines;
     p.mask = mask_arena; p.mid = mid_arena; p.tiles = tiles; p.ps = patch_size; p.merge = merge_size; p.pad = pad_value;
     for (int i = 0; i < 3; ++i) { p.mean[i] = mean[i]; p.std[i] = std[i]; }
     p.max_mid_w = max_stage1_width;
+    p.pix = pixel_stride;
     return sa::prep::prep_run(p, any_poly, max_stage1_width > 0, (hipStream_t)stream);
 }
 

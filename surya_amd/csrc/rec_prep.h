@@ -41,6 +41,7 @@ struct PrepArgs {
     float* mid;                  // arena: per Lanczos line [mid_h][mid_w][3] floats
     float* tiles;                // [sum patches][3 * ps * ps]
     int ps, merge, max_mid_w;    // max_mid_w: widest stage-1 output of the call (grid sizing)
+    int pix = 3;                 // bytes per page pixel: 3 (RGB) or 4 (RGBX, the layout PIL keeps in memory: pages then need no repacking on the host)
     float pad;                   // RECOGNITION_PAD_VALUE
     float mean[3], std[3];
 };
@@ -141,7 +142,7 @@ __device__ __forceinline__ void axis_setup(int out_i, int in_len, int out_len, i
 // source pixel of a line's (masked) crop, channel c
 __device__ __forceinline__ float crop_px(const PrepArgs& p, const LineDesc& L, int y, int x, int c) {
     if (L.has_poly && !p.mask[L.mask_off + (long)y * L.cw + x]) return p.pad;
-    return (float)p.pages[L.page_off + ((long)(L.y0 + y) * L.page_w + (L.x0 + x)) * 3 + c];
+    return (float)p.pages[L.page_off + ((long)(L.y0 + y) * L.page_w + (L.x0 + x)) * p.pix + c];
 }
 
 // out(y, x, :) of resampling a [in_h][in_w][3] source to [out_h][out_w]: horizontal pass first (per tap row), then vertical,

@@ -84,10 +84,11 @@ class HipDetModel:
         return (heat, low) if want_lowres else heat
 
     def forward_u8(self, pages_u8: torch.Tensor, mean, std, want_lowres: bool = False):
-        """pages cuda uint8 [B, H, W, 3] (already at the processor size) -> heat maps; rescale + normalise run on the device."""
+        """pages cuda uint8 [B, H, W, 3 | 4] (RGB or RGBX, already at the processor size) -> heat maps; rescale + normalise run
+        on the device."""
         assert pages_u8.is_cuda and pages_u8.dtype == torch.uint8 and pages_u8.is_contiguous()
-        B = pages_u8.shape[0]
-        assert tuple(pages_u8.shape[1:]) == (self.height, self.width, 3) and B <= self.max_batch
+        B, pix = pages_u8.shape[0], pages_u8.shape[3]
+        assert tuple(pages_u8.shape[1:3]) == (self.height, self.width) and pix in (3, 4) and B <= self.max_batch
         torch.cuda.set_device(self.device)
         heat = torch.empty((B, self.cfg.num_labels, self.height, self.width), dtype=torch.float32, device=self.device)
         low = torch.empty((B, self.cfg.num_labels, self.height // 4, self.width // 4), dtype=torch.float32,
@@ -95,7 +96,7 @@ class HipDetModel:
         m = (C.c_float * 3)(*[float(np.float32(v)) for v in mean])
         sd = (C.c_float * 3)(*[float(np.float32(v)) for v in std])
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        L.check(self.lib.surya_det_forward_u8(self.handle, L.ptr(pages_u8), m, sd, C.c_int(B), L.ptr(heat), L.ptr(low), stream),
+        L.check(self.lib.surya_det_forward_u8(self.handle, L.ptr(pages_u8), C.c_int(pix), m, sd, C.c_int(B), L.ptr(heat), L.ptr(low), stream),
                 "surya_det_forward_u8")
         return (heat, low) if want_lowres else heat
 
@@ -119,10 +120,10 @@ class HipDetPost:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws, need
 
-    def __call__(self, heat: torch.Tensor, text_threshold: float, low_text: float, page_stride: int = None):
-        """heat: cuda fp32, [B, H, W] contiguous, or a [B, labels, H, W] tensor whose plane 0 is the text map (then the page
-        stride is labels * H * W). Returns a list of (boxes float32 [n, 4, 2], confidences float32 [n]) per page, in the
-        component order cv2.connectedComponentsWithStats would label them."""
+    def launch(self, heat: torch.Tensor, text_threshold: float, low_text: float):
+        """Enqueue the post-processing of a batch of maps and the D2H of its (small, fixed-size) outputs into pinned memory;
+        returns a handle for `collect`. Nothing here waits for the GPU, so a caller can prepare and launch the NEXT batch before
+        it looks at this one (DetectionPredictor._detect_device does)."""
         assert heat.is_cuda and heat.dtype == torch.float32 and heat.is_contiguous()
         if heat.dim() == 4:
             B, Lb, H, W = heat.shape
@@ -139,10 +140,25 @@ class HipDetPost:
         L.check(self.lib.surya_det_boxes(L.ptr(heat), C.c_long(stride), C.c_int(B), C.c_int(H), C.c_int(W), C.c_float(text_threshold),
                                          C.c_float(low_text), C.c_int(self.max_boxes), L.ptr(boxes), L.ptr(conf), L.ptr(count), L.ptr(ws),
                                          C.c_size_t(need), stream), "surya_det_boxes")
-        n = count.cpu().numpy()                          # one tiny D2H decides how much of the box arrays to copy
+        # 148 KB per page: cheaper to copy whole than to wait for the counts first
+        hb = torch.empty(boxes.shape, dtype=torch.float32, pin_memory=True).copy_(boxes, non_blocking=True)
+        hc = torch.empty(conf.shape, dtype=torch.float32, pin_memory=True).copy_(conf, non_blocking=True)
+        hn = torch.empty(count.shape, dtype=torch.int32, pin_memory=True).copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return (ev, hb, hc, hn, heat)                    # `heat` rides along so its memory is not reused before the kernels ran
+
+    def collect(self, pending):
+        ev, hb, hc, hn, _ = pending
+        ev.synchronize()
+        n = hn.numpy()
         if (n < 0).any():
             raise L.SuryaAmdError(f"surya_det_boxes: a page has more than max_boxes = {self.max_boxes} text components")
-        nmax = int(n.max()) if len(n) else 0
-        bh = boxes[:, :nmax].cpu().numpy() if nmax else np.zeros((B, 0, 4, 2), np.float32)
-        ch = conf[:, :nmax].cpu().numpy() if nmax else np.zeros((B, 0), np.float32)
-        return [(bh[b, : n[b]].copy(), ch[b, : n[b]].copy()) for b in range(B)]
+        bh, ch = hb.numpy(), hc.numpy()
+        return [(bh[b, : n[b]].copy(), ch[b, : n[b]].copy()) for b in range(len(n))]
+
+    def __call__(self, heat: torch.Tensor, text_threshold: float, low_text: float):
+        """heat: cuda fp32, [B, H, W] contiguous, or a [B, labels, H, W] tensor whose plane 0 is the text map (then the page
+        stride is labels * H * W). Returns a list of (boxes float32 [n, 4, 2], confidences float32 [n]) per page, in the
+        component order cv2.connectedComponentsWithStats would label them."""
+        return self.collect(self.launch(heat, text_threshold, low_text))

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 from PIL import Image, ImageOps
 
-from ..common.predictor import BasePredictor, ModelLoader
+from ..common.imageops import page_pixels
+from ..common.predictor import BasePredictor, ModelLoader, gc_paused
 from ..config import DetConfig, det_config
 from ..settings import settings
 from .heatmap import TextDetectionResult, parallel_get_boxes, result_from_device_boxes
@@ -99,6 +100,10 @@ class DetectionPredictor(BasePredictor):
     process_group = None
 
     def __call__(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        with gc_paused():                                  # result objects are acyclic; see common/predictor.py
+            return self._call(images, batch_size, include_maps)
+
+    def _call(self, images, batch_size=None, include_maps=False) -> List[TextDetectionResult]:
         if self.shard_pages:
             from .. import dist as sdist
             rank, world = sdist.world_info(self.process_group)
@@ -139,26 +144,15 @@ class DetectionPredictor(BasePredictor):
             self._post = HipDetPost(self.model.device)
         tt, lt = settings.DETECTOR_TEXT_THRESHOLD, settings.DETECTOR_BLANK_THRESHOLD
         out: List[TextDetectionResult] = []
-        for heat, split_index, split_heights, sizes in self.batch_heatmaps(images, batch_size):
-            ph, pw = heat.shape[2], heat.shape[3]
-            n_pages = split_index[-1] + 1
-            tiles_of = [[i for i, k in enumerate(split_index) if k == page] for page in range(n_pages)]
-            whole = [page for page in range(n_pages) if len(tiles_of[page]) == 1]
+
+        def finish(job):
+            """Results of one launched batch (waits for ITS event only)."""
+            jobs, n_pages, tiles_of, split_heights, sizes, heat, pw = job
             res = {}
-            if whole:
-                sel = heat if len(whole) == heat.shape[0] else heat[[tiles_of[pg][0] for pg in whole]].contiguous()
-                for pg, (bx, cf) in zip(whole, self._post(sel, tt, lt)):
-                    res[pg] = (bx, cf, (pw, ph))
-            for pg in range(n_pages):                    # tall pages: strips re-assembled on the device (:134-151), one call each
-                if pg in res:
-                    continue
-                strips = [heat[t, 0, : split_heights[t]] for t in tiles_of[pg]]
-                full = torch.cat(strips, 0).unsqueeze(0).contiguous()
-                bx, cf = self._post(full, tt, lt)[0]
-                res[pg] = (bx, cf, (pw, full.shape[1]))
-            maps = None
-            if include_maps:                              # callers that want the maps pay for their D2H
-                maps = heat.cpu().numpy()
+            for pages_, pending, psizes in jobs:
+                for pg, (bx, cf), psize in zip(pages_, self._post.collect(pending), psizes):
+                    res[pg] = (bx, cf, psize)
+            maps = heat.cpu().numpy() if include_maps else None      # callers that want the maps pay for their D2H
             for pg in range(n_pages):
                 bx, cf, psize = res[pg]
                 hi = ai = None
@@ -167,6 +161,31 @@ class DetectionPredictor(BasePredictor):
                     am = np.vstack([maps[t, 1, : split_heights[t]] for t in tiles_of[pg]])
                     hi, ai = Image.fromarray((hm * 255).astype(np.uint8)), Image.fromarray((am * 255).astype(np.uint8))
                 out.append(result_from_device_boxes(bx, cf, list(psize), sizes[pg], hi, ai))
+
+        # One batch in flight ahead of the one being read: the generator prepares (PIL convert / resize, pinned staging) and
+        # launches batch i + 1 while the GPU still works on batch i, whose boxes are only then waited for.
+        prev = None
+        for heat, split_index, split_heights, sizes in self.batch_heatmaps(images, batch_size):
+            ph, pw = heat.shape[2], heat.shape[3]
+            n_pages = split_index[-1] + 1
+            tiles_of = [[i for i, k in enumerate(split_index) if k == page] for page in range(n_pages)]
+            whole = [page for page in range(n_pages) if len(tiles_of[page]) == 1]
+            jobs = []
+            if whole:
+                sel = heat if len(whole) == heat.shape[0] else heat[[tiles_of[pg][0] for pg in whole]].contiguous()
+                jobs.append((whole, self._post.launch(sel, tt, lt), [(pw, ph)] * len(whole)))
+            for pg in range(n_pages):                    # tall pages: strips re-assembled on the device (:134-151), one call each
+                if len(tiles_of[pg]) == 1:
+                    continue
+                strips = [heat[t, 0, : split_heights[t]] for t in tiles_of[pg]]
+                full = torch.cat(strips, 0).unsqueeze(0).contiguous()
+                jobs.append(([pg], self._post.launch(full, tt, lt), [(pw, full.shape[1])]))
+            job = (jobs, n_pages, tiles_of, split_heights, sizes, heat, pw)
+            if prev is not None:
+                finish(prev)
+            prev = job
+        if prev is not None:
+            finish(prev)
         return out
 
     def resize_image(self, img: Image.Image) -> np.ndarray:
@@ -175,7 +194,7 @@ class DetectionPredictor(BasePredictor):
         if img.size != new_size:
             img.thumbnail(new_size, Image.Resampling.LANCZOS)
             img = img.resize(new_size, Image.Resampling.LANCZOS)
-        return np.asarray(img, dtype=np.uint8)
+        return page_pixels(img)
 
     def prepare_image(self, img: Image.Image) -> torch.Tensor:
         new_size = (self.processor.size["width"], self.processor.size["height"])
@@ -214,17 +233,18 @@ class DetectionPredictor(BasePredictor):
                 split_heights.extend(hs)
             # pages go to the device as uint8 at the processor size; rescale + normalise happen in the model's first kernel
             pw = self.processor.size["width"]
-            host = torch.empty((len(parts), ph, pw, 3), dtype=torch.uint8).pin_memory()
-            hv = host.numpy()
-
-            def put(k):
-                hv[k] = self.resize_image(parts[k])
             if len(parts) > 4:
-                with ThreadPoolExecutor(min(8, len(parts))) as ex:      # PIL resizes release the GIL
-                    list(ex.map(put, range(len(parts))))
+                if getattr(self, "_prep_pool", None) is None:               # one pool per predictor: thread start-up cost ~0.7 ms each
+                    self._prep_pool = ThreadPoolExecutor(8)
+                px = list(self._prep_pool.map(self.resize_image, parts))    # PIL resizes release the GIL
             else:
-                for k in range(len(parts)):
-                    put(k)
+                px = [self.resize_image(p_) for p_ in parts]
+            # RGBX views of PIL's own memory where it can export them (page_pixels), else repacked RGB; one stride per batch
+            pix = 4 if all(a.shape[2] == 4 for a in px) else 3
+            host = torch.empty((len(parts), ph, pw, pix), dtype=torch.uint8, pin_memory=True)   # caching host allocator
+            hv = host.numpy()
+            for k, a in enumerate(px):
+                hv[k] = a if a.shape[2] == pix else a[..., :3]
             heat_parts = []
             for s in range(0, len(parts), self.model.max_batch):            # a single page may exceed max_batch tiles
                 chunk = host[s: s + self.model.max_batch].to(self.model.device, non_blocking=True)

@@ -18,6 +18,8 @@ from __future__ import annotations
 import json
 import os
 import re
+import time
+from array import array
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
@@ -29,16 +31,33 @@ from PIL import Image
 
 from ..common.geometry import PolygonBox
 from ..common.imageops import fill_poly_mask
-from ..common.predictor import BasePredictor, ModelLoader
+from ..common.predictor import BasePredictor, ModelLoader, gc_paused
 from ..config import RecConfig, rec_config
 from ..settings import settings
 from .model import HipRecModel
-from .preprocess_gpu import DevicePreprocessor, LineRef, bbox_ref, poly_ref
+from .preprocess_gpu import DevicePreprocessor, LineRef, bbox_ref, page_pixels, poly_ref
 from .postprocess import (clean_close_polygons, clean_math_tags, detect_repeat_token, fix_unbalanced_tags,
                           prediction_to_polygon_batch, sort_text_lines, unwrap_math, words_from_chars)
 from .processor import NOMATH_TOKEN, SuryaOCRProcessor
 from .schema import OCRResult, TaskNames, TextChar, TextLine
 from .tokenizer import ByteMathTokenizer, OCRTokenizer
+
+
+_SCRIPT_TAG = re.compile(r"<SCRIPT-\w+>")
+_CHAR_FIELDS = frozenset(("polygon", "confidence", "text", "bbox_valid"))
+assert _CHAR_FIELDS == frozenset(TextChar.model_fields), "TextChar fields changed: update _text_char"
+_new_char, _set = TextChar.__new__, object.__setattr__
+
+
+def _text_char(polygon, confidence, text, bbox_valid) -> TextChar:
+    """TextChar.model_construct(...) with all four fields given, without its per-call field loop (1.9 -> 0.55 us; a page of
+    text is ~10^4 of these). Same object state: __dict__, fields_set, no extras, no private attributes."""
+    m = _new_char(TextChar)
+    _set(m, "__dict__", {"polygon": polygon, "confidence": confidence, "text": text, "bbox_valid": bbox_valid})
+    _set(m, "__pydantic_fields_set__", set(_CHAR_FIELDS))
+    _set(m, "__pydantic_extra__", None)
+    _set(m, "__pydantic_private__", None)
+    return m
 
 
 # ------------------------------------------------------------------------------------------------ input slicing
@@ -237,7 +256,7 @@ class RecognitionPredictor(BasePredictor):
     # --------------------------------------------------------------------------------------------- slicing
     def _page(self, flat: dict, image) -> int:
         """Device path: register a page (uint8 HWC) once, return its index for LineRefs."""
-        flat.setdefault("pages", []).append(np.ascontiguousarray(np.asarray(image, dtype=np.uint8)))
+        flat.setdefault("pages", []).append(page_pixels(image))
         return len(flat["pages"]) - 1
 
     def detect_and_slice_bboxes(self, images, task_names, det_predictor, detection_batch_size=None, highres_images=None):
@@ -539,6 +558,7 @@ class RecognitionPredictor(BasePredictor):
         None (<NOP>), or a tuple that `_chars_of` turns into TextChars after the geometry has been applied in bulk."""
         tk = self.processor.ocr_tokenizer
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
+        q_off, s_off = tk.qwen_offset, tk.special_token_offset
         blank = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float64)
         out = []
         for tokens, polys, sc in zip(predicted_tokens, predicted_polygons, scores):
@@ -558,34 +578,42 @@ class RecognitionPredictor(BasePredictor):
             tid = tid[:n]
             P = np.asarray(polys[:n], np.float64)
             conf = np.asarray(sc[:n], np.float64)
-            kind = np.where(tid < tk.qwen_offset, 0, np.where(tid < tk.special_token_offset, 1, 2))
-            starts = np.nonzero(np.r_[True, (kind[1:] != kind[:-1]) | (kind[1:] == 1)])[0]
-            ends = np.r_[starts[1:], n]
-            texts, cf, valid, pp = [], [], [], []
-            for a_, b_ in zip(starts.tolist(), ends.tolist()):
-                k = int(kind[a_])
-                ids = tid[a_:b_].tolist()
+            ids = tid.tolist()
+            kind = [0 if t < q_off else (1 if t < s_off else 2) for t in ids]
+            # clean_close_polygons: a box is dropped when all 4 corners sit within 0.1 of the PREVIOUS box of its run (util.py:100-120)
+            far = (np.abs(P[1:] - P[:-1]).reshape(n - 1, 8).max(axis=1) > 0.1).tolist() if n > 1 else []
+            # per output char: its text, the token whose BOX it takes, the token whose CONFIDENCE it takes, bbox_valid. The
+            # reference indexes the run's unfiltered confidences with the index into its FILTERED boxes (:700-712): kept as is.
+            texts, src, csrc, valid = [], [], [], []
+            a_ = 0
+            while a_ < n:
+                k = kind[a_]
+                b_ = a_ + 1
+                if k != 1:
+                    while b_ < n and kind[b_] == k:
+                        b_ += 1
                 if k == 2:
-                    text = tk.decode(ids, task=TaskNames.ocr_with_boxes)
-                    if not text:
-                        continue
-                    Pr = P[a_:b_]
-                    # clean_close_polygons: drop a box whose 4 corners all sit within 0.1 of the PREVIOUS box (util.py:100-120)
-                    keep = np.r_[True, np.abs(Pr[1:] - Pr[:-1]).max(axis=(1, 2)) > 0.1] if b_ - a_ > 1 else np.ones(1, bool)
-                    boxes = Pr[keep]
-                    bi = np.minimum(np.arange(len(text)), len(boxes) - 1)
-                    texts.extend(text)
-                    cf.append(conf[a_:b_][bi]); valid.append(np.ones(len(text), bool)); pp.append(boxes[bi])
+                    # a run of UTF-16 code units decodes in one piece (tokenizer._decode_ocr's flush of a non-math buffer)
+                    text = array("H", [t - s_off for t in ids[a_:b_]]).tobytes().decode("utf-16le", errors="ignore")
+                    if text:
+                        boxes = [a_] + [j for j in range(a_ + 1, b_) if far[j - 1]]
+                        L, nb = len(text), len(boxes)
+                        texts.extend(text)
+                        src.extend(boxes[:L] if L <= nb else boxes + [boxes[-1]] * (L - nb))      # char i -> box min(i, nb - 1)
+                        csrc.extend(range(a_, a_ + L) if L <= nb else list(range(a_, a_ + nb)) + [a_ + nb - 1] * (L - nb))
+                        valid.extend([True] * L)
                 else:
-                    text = tk.decode(ids, task=TaskNames.ocr_without_boxes if k == 1 else TaskNames.block_without_boxes)
-                    if k == 1 and (text == NOMATH_TOKEN or re.match(r"<SCRIPT-\w+>", text)):
-                        continue
-                    texts.append(text)
-                    cf.append(conf[a_:a_ + 1]); valid.append(np.zeros(1, bool)); pp.append(blank[None])
+                    text = tk.decode(ids[a_:b_], task=TaskNames.ocr_without_boxes if k == 1 else TaskNames.block_without_boxes)
+                    if not (k == 1 and (text == NOMATH_TOKEN or _SCRIPT_TAG.match(text))):
+                        texts.append(text); src.append(a_); csrc.append(a_); valid.append(False)
+                a_ = b_
             if not texts:
                 out.append(([], np.zeros(0), np.zeros(0, bool), np.zeros((0, 4, 2))))
             else:
-                out.append((texts, np.concatenate(cf), np.concatenate(valid), np.concatenate(pp)))
+                v = np.asarray(valid, bool)
+                pp = P[src]
+                pp[~v] = blank
+                out.append((texts, conf[csrc], v, pp))
         return out
 
     @staticmethod
@@ -603,8 +631,22 @@ class RecognitionPredictor(BasePredictor):
         np.clip(P[..., 1], line_bbox[1], line_bbox[3], out=P[..., 1])
         polys = P.tolist()
         conf = [0 if c != c else c for c in conf.tolist()]
-        return [TextChar.model_construct(polygon=pg, confidence=c, text=t, bbox_valid=v)
-                for pg, c, t, v in zip(polys, conf, texts, valid.tolist())]
+        return [_text_char(pg, c, t, v) for pg, c, t, v in zip(polys, conf, texts, valid.tolist())]
+
+    def _assemble_line(self, flat, sorted_pos, orig, tokens, sc, bbox_rows, drop_repeated_text, return_words, bbox_size) -> TextLine:
+        """One line's TextLine from its finished token stream (reference :609-771 + :886-925)."""
+        polygon, res_scale = flat["polygons"][orig], flat["res_scales"][orig]
+        polys = prediction_to_polygon_batch(bbox_rows[None], [flat["slices"][sorted_pos].shape], bbox_size, bbox_size // 2)
+        chars = self.get_bboxes_text(flat, [tokens], [sc], polys, drop_repeated_text)[0]
+        if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
+            return TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True)
+        confidence = float(np.mean(chars[1]))
+        box = PolygonBox(polygon=polygon)
+        chars = self._chars_of(chars, res_scale, box.bbox)
+        chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
+        text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
+        return TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
+                        words=words_from_chars(chars, box) if return_words else [])
 
     def __call__(self, images: List[Image.Image], task_names: List[str] | None = None, det_predictor=None,
                  detection_batch_size: int | None = None, recognition_batch_size: int | None = None,
@@ -612,7 +654,16 @@ class RecognitionPredictor(BasePredictor):
                  polygons: List[List[List[List[int]]]] | None = None, input_text: List[List[str | None]] | None = None,
                  sort_lines: bool = False, math_mode: bool = True, return_words: bool = False,
                  drop_repeated_text: bool = False) -> List[OCRResult]:
+        # the whole call runs with the cyclic GC paused (gc_paused): slicing, scheduling and assembly allocate ~10^6 acyclic objects
+        with gc_paused():
+            return self._call(images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images,
+                              bboxes, polygons, input_text, sort_lines, math_mode, return_words, drop_repeated_text)
+
+    def _call(self, images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images, bboxes,
+              polygons, input_text, sort_lines, math_mode, return_words, drop_repeated_text) -> List[OCRResult]:
         allowed = self.tasks.keys()
+        t_call = time.perf_counter()
+        stamps = self.last_timing = {}                    # wall-clock phases of this call in ms (bench.py's e2e leg reports them)
         if task_names is None:
             task_names = [TaskNames.ocr_with_boxes] * len(images)
         assert all(t in allowed for t in task_names), (
@@ -635,6 +686,7 @@ class RecognitionPredictor(BasePredictor):
             flat = self.slice_bboxes(images, bboxes=bboxes, polygons=polygons, input_text=input_text, task_names=task_names)
         if len(flat["slices"]) == 0:
             return []
+        stamps["slice_ms"] = (time.perf_counter() - t_call) * 1e3
 
         # widest first: the length bucketing that keeps prefill batches homogeneous (reference :847-854)
         order = sorted(range(len(flat["slices"])), key=lambda i: -flat["slices"][i].shape[1])
@@ -646,20 +698,8 @@ class RecognitionPredictor(BasePredictor):
         bbox_size = self.model.cfg.bbox_size
 
         def assemble(sorted_pos, tokens, sc, bbox_rows):
-            """One line's TextLine from its finished token stream (reference :609-771 + :886-925)."""
-            orig = orig_of[sorted_pos]
-            polygon, res_scale = flat["polygons"][orig], flat["res_scales"][orig]
-            polys = prediction_to_polygon_batch(bbox_rows[None], [flat["slices"][sorted_pos].shape], bbox_size, bbox_size // 2)
-            chars = self.get_bboxes_text(flat, [tokens], [sc], polys, drop_repeated_text)[0]
-            if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
-                return TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True)
-            confidence = float(np.mean(chars[1]))
-            box = PolygonBox(polygon=polygon)
-            chars = self._chars_of(chars, res_scale, box.bbox)
-            chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
-            text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
-            return TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
-                            words=words_from_chars(chars, box) if return_words else [])
+            return self._assemble_line(flat, sorted_pos, orig_of[sorted_pos], tokens, sc, bbox_rows, drop_repeated_text,
+                                       return_words, bbox_size)
 
         text_lines = [None] * len(order)                      # by ORIGINAL position
         if self.shard_lines:
@@ -675,9 +715,15 @@ class RecognitionPredictor(BasePredictor):
             with ThreadPoolExecutor(1) as pool:
                 def on_done(k, tokens, sc, bbox_rows):
                     futures[k] = pool.submit(assemble, k, list(tokens), list(sc), bbox_rows.copy())
-                self.generate(self.prepare_lines(flat, math_mode), recognition_batch_size, on_done=on_done)
+                t0 = time.perf_counter()
+                prep = self.prepare_lines(flat, math_mode)
+                t1 = time.perf_counter()
+                self.generate(prep, recognition_batch_size, on_done=on_done)
+                t2 = time.perf_counter()
                 for k, f in futures.items():
                     text_lines[orig_of[k]] = f.result()
+                stamps.update(prepare_ms=(t1 - t0) * 1e3, device_loop_ms=(t2 - t1) * 1e3,
+                              assemble_tail_ms=(time.perf_counter() - t2) * 1e3)
             assert all(t is not None for t in text_lines)
 
         results, start = [], 0
@@ -688,4 +734,5 @@ class RecognitionPredictor(BasePredictor):
             if sort_lines:
                 lines = sort_text_lines(lines)
             results.append(OCRResult(text_lines=lines, image_bbox=[0, 0, image.size[0], image.size[1]]))
+        stamps["total_ms"] = (time.perf_counter() - t_call) * 1e3
         return results

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..common.imageops import page_pixels  # noqa: F401  (re-exported: the predictor and tests import it from here)
 
 # must match sa::prep::LineDesc (csrc/rec_prep.h); align=True reproduces the C layout (8-byte longs after the int block)
 LINE_DESC = np.dtype([("page_off", np.int64), ("page_w", np.int32), ("page_h", np.int32), ("x0", np.int32), ("y0", np.int32),
@@ -90,13 +91,16 @@ class DevicePreprocessor:
         self.std = (C.c_float * 3)(*[float(np.float32(s)) for s in std])
 
     def __call__(self, pages: Sequence[np.ndarray], lines: Sequence[LineRef], max_sizes: Sequence[Tuple[int, int]]):
-        """pages: uint8 [H, W, 3] arrays; lines: LineRefs into them; max_sizes: the task's img_size per line.
+        """pages: uint8 [H, W, 3] (RGB) or [H, W, 4] (RGBX) arrays; lines: LineRefs into them; max_sizes: the task's img_size per line.
         Returns (tiles cuda fp32 [sum P, 3 ps^2], tile_offs int64 [n + 1], grids [(gh, gw)])."""
         n = len(lines)
         f = self.ps * self.merge
         offs, total = [], 0
+        pix = 4 if pages and all(pg.shape[2] == 4 for pg in pages) else 3
+        if pix == 3:                                   # mixed strides: repack the RGBX views
+            pages = [pg if pg.shape[2] == 3 else np.ascontiguousarray(pg[..., :3]) for pg in pages]
         for pg in pages:
-            assert pg.dtype == np.uint8 and pg.ndim == 3 and pg.shape[2] == 3
+            assert pg.dtype == np.uint8 and pg.ndim == 3 and pg.shape[2] == pix
             offs.append(total)
             total += pg.size
         desc = np.zeros(n, LINE_DESC)
@@ -128,7 +132,9 @@ class DevicePreprocessor:
             grids.append((gh, gw))
             tile_offs[i + 1] = tile_offs[i] + gh * gw
         torch.cuda.set_device(self.device)
-        host = torch.empty(max(total, 1), dtype=torch.uint8).pin_memory()
+        # pinned staging straight from torch's caching host allocator (a pageable buffer + .pin_memory() would allocate, fault in and
+        # copy the pages' ~3 MB each a second time)
+        host = torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=True)
         hv = host.numpy()
         for pg, o in zip(pages, offs):
             hv[o: o + pg.size] = pg.reshape(-1)
@@ -140,7 +146,7 @@ class DevicePreprocessor:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(self.lib.surya_rec_preprocess(L.ptr(d_pages), L.ptr(d_desc), C.c_int(n), L.ptr(d_mask), L.ptr(d_mid), L.ptr(tiles),
                                               C.c_int(self.ps), C.c_int(self.merge), C.c_float(self.pad), self.mean, self.std,
-                                              C.c_int(int(mask_bytes > 0)), C.c_int(max_mid_w), stream),
+                                              C.c_int(int(mask_bytes > 0)), C.c_int(max_mid_w), C.c_int(pix), stream),
                 "surya_rec_preprocess")
         self._keep = (d_pages, d_desc, d_mask, d_mid, host)          # alive until the stream has consumed them
         return tiles, tile_offs, grids

@@ -46,6 +46,8 @@ class Settings:
         # crop / pad / resize / normalise / patchify of the line crops on the GPU (surya_rec_preprocess); 1 keeps the host
         # (numpy, thread pool) pre-processing of round 1 -- the checker of tests/test_gpu_prep.py, not a fallback
         self.RECOGNITION_PREPROCESS_HOST: bool = _env("RECOGNITION_PREPROCESS_HOST", bool, False)
+        # pause Python's cyclic GC while a predictor call assembles its result objects (recognition/predictor.py gc_paused)
+        self.SURYA_AMD_PAUSE_GC: bool = _env("SURYA_AMD_PAUSE_GC", bool, True)
         # decode steps on MXFP8 weights + activations (csrc/gemm_mx.h; BASELINE.json configs[4]). Off by default: the
         # reference computes in the checkpoint dtype, and fp8 changes which token wins a near-tie
         self.RECOGNITION_DECODE_FP8: bool = _env("RECOGNITION_DECODE_FP8", bool, False)

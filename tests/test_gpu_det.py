@@ -84,3 +84,7 @@ def test_det_forward_from_uint8_pages_is_bit_identical(hip_lib, dtype):
     u8 = torch.from_numpy(np.stack(pages)).cuda().contiguous()
     got = m.forward_u8(u8, proc.image_mean, proc.image_std)
     assert torch.equal(got, ref)
+    # the same pages in PIL's RGBX memory layout (pixel stride 4, junk in the fourth byte)
+    x4 = np.concatenate([np.stack(pages), np.random.default_rng(0).integers(0, 256, size=(3, 128, 128, 1), dtype=np.uint8)], 3)
+    got4 = m.forward_u8(torch.from_numpy(x4).cuda().contiguous(), proc.image_mean, proc.image_std)
+    assert torch.equal(got4, ref)

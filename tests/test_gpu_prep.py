@@ -111,3 +111,26 @@ def test_predictor_device_and_host_preprocessing_give_same_tokens(hip_lib):
         assert [l.polygon for l in a.text_lines] == [l.polygon for l in b.text_lines]
         for la, lb in zip(a.text_lines, b.text_lines):
             assert [c.polygon for c in la.chars] == [c.polygon for c in lb.chars]
+
+
+def test_rgbx_pages_give_the_same_tiles_as_rgb(hip_lib):
+    """Pages handed over in PIL's own RGBX memory layout (pixel stride 4, preprocess_gpu.page_pixels) == the repacked RGB pages,
+    bit for bit, incl. polygon lines; and page_pixels returns the PIL image's pixels whichever path it takes."""
+    from PIL import Image
+    from surya_amd.recognition.preprocess_gpu import DevicePreprocessor, bbox_ref, page_pixels, poly_ref
+    rng = np.random.default_rng(3)
+    pages = [rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8), rng.integers(0, 256, size=(260, 500, 3), dtype=np.uint8)]
+    imgs = [Image.fromarray(p) for p in pages]
+    views = [page_pixels(im) for im in imgs]
+    for v, p in zip(views, pages):
+        assert v.shape[2] in (3, 4) and np.array_equal(v[..., :3], p)
+    rgbx = [np.concatenate([p, rng.integers(0, 256, size=p.shape[:2] + (1,), dtype=np.uint8)], 2) for p in pages]   # junk in X
+    lines = [bbox_ref(0, 400, 300, [10, 20, 390, 84]), bbox_ref(1, 500, 260, [5, 100, 480, 150]),
+             poly_ref(0, 400, 300, [[20, 120], [380, 128], [378, 190], [18, 180]]), bbox_ref(1, 500, 260, [100, 10, 300, 40])]
+    pre = DevicePreprocessor("cuda:0")
+    sizes = [(1024, 256)] * len(lines)
+    t3, o3, g3 = pre(pages, lines, sizes)
+    t4, o4, g4 = pre(rgbx, lines, sizes)
+    assert g3 == g4 and np.array_equal(o3, o4) and torch.equal(t3, t4)
+    tm, om, gm = pre([pages[0], rgbx[1]], lines, sizes)              # mixed strides: repacked to RGB on the host
+    assert torch.equal(tm, t3)
