@@ -528,6 +528,8 @@ def main():
         L.check(lib.surya_prof_event_overhead(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(null_ms)), "surya_prof_event_overhead")
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
                 "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic_for(dom["kernel"]),
+                "traffic_source": "profiles/hbm_traffic.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  "(profiles/r02_n_rec_hbm_traffic_pmc.md), bytes per launch of this bucket; not re-measured in this run",
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 # an event pair around an EMPTY kernel costs this much: rocprofv3's begin->end duration of the same launches
                 # lies between avg_launch_ms - event_pair_null_ms and avg_launch_ms

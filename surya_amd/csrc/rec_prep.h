@@ -175,44 +175,93 @@ __device__ __forceinline__ void resample_px(SRC src, int in_h, int in_w, int out
     }
 }
 
-// stage 1 (scale_to_fit): Lanczos-4 of the masked crop into the line's slice of the mid arena. The 8 taps of an axis cost 16
-// double-precision sin() each, so they are computed ONCE per output column (a thread owns a column and walks down the rows) and
-// once per output row (8 lanes fill an LDS record per row) instead of once per pixel (a first version spent 19.7 ms per call
-// re-deriving them, r02n profile).
+// the three channels of a source pixel of a line's (masked) crop: one 32-bit load for RGBX pages
+__device__ __forceinline__ void crop_px3(const PrepArgs& p, const LineDesc& L, int y, int x, double (&v)[3]) {
+    if (L.has_poly && !p.mask[L.mask_off + (long)y * L.cw + x]) { v[0] = v[1] = v[2] = (double)p.pad; return; }
+    const unsigned char* px = p.pages + L.page_off + ((long)(L.y0 + y) * L.page_w + (L.x0 + x)) * p.pix;
+    if (p.pix == 4) {                                       // page_off and the pixel offset are multiples of 4
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(px);
+        v[0] = (double)(w & 0xff); v[1] = (double)((w >> 8) & 0xff); v[2] = (double)((w >> 16) & 0xff);
+    } else {
+        v[0] = (double)px[0]; v[1] = (double)px[1]; v[2] = (double)px[2];
+    }
+}
+
+// stage 1 (scale_to_fit): Lanczos-4 of the masked crop into the line's slice of the mid arena. A thread owns an output column
+// and walks down the rows. Values are those of resample_px (horizontal pass per source row, then the vertical taps, float64
+// products summed in tap order), computed without its redundancy:
+//   * the 8 horizontal taps (16 double-precision sin() per axis position) once per column, the vertical ones once per output
+//     row by the first lanes of the block, all rows up front (the first version re-derived them per pixel: 19.7 ms per call);
+//   * the horizontal pass h(sy, ox, c) of a SOURCE row once, kept in an 8-slot LDS ring indexed by sy & 7: consecutive output
+//     rows share 7 of their 8 source rows when a line is scaled up, and every thread of the block needs the same rows (the second
+//     version recomputed it for each of the 8 vertical taps: 192 byte loads per output pixel, 25 ms per 2842-line call).
+constexpr int S1_ROWS = 128;      // output rows whose vertical taps are resident at a time (61 KB of LDS per block with the ring)
 __global__ __launch_bounds__(256) void prep_stage1_kernel(PrepArgs p) {
 #pragma clang fp contract(off)
-    __shared__ double wy_s[8];
-    __shared__ int yi_s[8];
+    __shared__ double wy_s[S1_ROWS][8];
+    __shared__ int yi_s[S1_ROWS][8];
+    __shared__ double ring[8][3][256];
+    __shared__ int tag[8];
     const LineDesc& L = p.lines[blockIdx.y];
     if (L.mid_w == L.cw && L.mid_h == L.ch) return;
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x, ox = blockIdx.x * blockDim.x + tid;
     if (blockIdx.x * blockDim.x >= L.mid_w) return;                          // whole block beyond the line's width
     const bool rx = L.cw != L.mid_w, ry = L.ch != L.mid_h, live = ox < L.mid_w;
     int xi[8];
     double wx[8];
     if (rx && live) axis_setup<8>(ox, L.cw, L.mid_w, xi, wx);
-    for (int oy = 0; oy < L.mid_h; ++oy) {
-        __syncthreads();
-        if (ry && threadIdx.x == 0) axis_setup<8>(oy, L.ch, L.mid_h, yi_s, wy_s);
-        __syncthreads();
-        if (!live) continue;
-        float* dst = p.mid + L.mid_off + ((long)oy * L.mid_w + ox) * 3;
-        for (int c = 0; c < 3; ++c) {
-            double acc = 0.0;
-            const int ny = ry ? 8 : 1;
-            for (int j = 0; j < ny; ++j) {
-                const int sy = ry ? yi_s[j] : oy;
-                double h;
-                if (rx) {
-                    h = (double)crop_px(p, L, sy, xi[0], c) * wx[0];
-                    for (int k = 1; k < 8; ++k) h = h + (double)crop_px(p, L, sy, xi[k], c) * wx[k];
-                } else {
-                    h = (double)crop_px(p, L, sy, ox, c);
-                }
-                if (ry) acc = j == 0 ? h * wy_s[0] : acc + h * wy_s[j];
-                else acc = h;
+    if (tid < 8) tag[tid] = -1;
+    // horizontal pass of source row sy for this thread's column
+    auto hrow = [&](int sy, double (&h)[3]) {
+        if (rx) {
+            double v[3];
+            crop_px3(p, L, sy, xi[0], v);
+            h[0] = v[0] * wx[0]; h[1] = v[1] * wx[0]; h[2] = v[2] * wx[0];
+            for (int k = 1; k < 8; ++k) {
+                crop_px3(p, L, sy, xi[k], v);
+                h[0] = h[0] + v[0] * wx[k]; h[1] = h[1] + v[1] * wx[k]; h[2] = h[2] + v[2] * wx[k];
             }
-            dst[c] = (float)acc;
+        } else {
+            crop_px3(p, L, sy, ox, h);
+        }
+    };
+    for (int r0 = 0; r0 < L.mid_h; r0 += S1_ROWS) {
+        const int nr = min(S1_ROWS, L.mid_h - r0);
+        __syncthreads();
+        if (ry && tid < nr) axis_setup<8>(r0 + tid, L.ch, L.mid_h, yi_s[tid], wy_s[tid]);
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const int oy = r0 + r;
+            float* dst = p.mid + L.mid_off + ((long)oy * L.mid_w + ox) * 3;
+            if (!ry) {                                       // height unchanged: the horizontal pass is the result
+                if (live) {
+                    double h[3];
+                    hrow(oy, h);
+                    dst[0] = (float)h[0]; dst[1] = (float)h[1]; dst[2] = (float)h[2];
+                }
+                continue;
+            }
+            // make the 8 source rows resident (block-uniform decisions: every thread sees the same tags)
+            for (int j = 0; j < 8; ++j) {
+                const int sy = yi_s[r][j], slot = sy & 7;
+                if (tag[slot] != sy) {
+                    __syncthreads();                         // everyone has finished reading the row this slot held
+                    if (live) {
+                        double h[3];
+                        hrow(sy, h);
+                        ring[slot][0][tid] = h[0]; ring[slot][1][tid] = h[1]; ring[slot][2][tid] = h[2];
+                    }
+                    if (tid == 0) tag[slot] = sy;
+                    __syncthreads();
+                }
+            }
+            if (live) {
+                for (int c = 0; c < 3; ++c) {
+                    double acc = ring[yi_s[r][0] & 7][c][tid] * wy_s[r][0];
+                    for (int j = 1; j < 8; ++j) acc = acc + ring[yi_s[r][j] & 7][c][tid] * wy_s[r][j];
+                    dst[c] = (float)acc;
+                }
+            }
         }
     }
 }

@@ -56,8 +56,13 @@ def test_encoder_bf16(hip_lib, cfg_name):
     tiles, _ = make_prompts(cfg, GRIDS)
     ref = ro.image_embeddings(sd, cfg, tiles, [(1, h, w) for h, w in GRIDS])
     out = m.encode_only(tiles.cuda(), GRIDS).float().cpu()
-    rel = (out - ref).abs().max().item() / ref.abs().max().item()
-    assert rel <= 6e-2, rel
+    # bound by the reference's own rounding model (same oracle in bf16), not by a free constant (r01 used 6e-2 of max|ref|)
+    grids = [(1, h, w) for h, w in GRIDS]
+    ref_b16 = ro.image_embeddings({k: v.bfloat16() for k, v in sd.items()}, cfg, tiles.bfloat16(), grids).float()
+    scale = ref.abs().max().item()
+    err, ref_dev = (out - ref).abs().max().item(), (ref_b16 - ref).abs().max().item()
+    print(f"encoder bf16 {cfg_name}: max err {err / scale:.4f} of max|ref|, torch bf16 path {ref_dev / scale:.4f}")
+    assert err <= 2 * ref_dev + 5e-3 * scale, (err, ref_dev, scale)
 
 
 def _oracle_run(cfg, sd, tiles, seqs, max_tokens):

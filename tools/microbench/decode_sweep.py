@@ -60,6 +60,9 @@ def main():
     base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8)
     if args.configs == "base":
         variants = [dict()]
+    elif args.configs == "fewer":        # fewer, longer split-K slices for the bf16 path
+        variants = [dict(), dict(split_min_kt=6), dict(split_min_kt=8), dict(split_min_kt=10), dict(split_max=2), dict(split_target=192),
+                    dict(split_target=128), dict(split_max=1)]
     elif args.configs == "fp8only":
         variants = [dict(fp8=1)]
     elif args.configs == "fp8":
