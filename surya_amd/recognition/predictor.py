@@ -7,10 +7,10 @@ Same call signature, class attributes and output schema as the reference
   * prompts are pre-processed once up front (thread pool) and their tiles stay resident in HBM;
   * the continuous-batching policy is the reference's (:539-599: prefill when more than `min_prefill_ratio` of the
     slots are empty, same stop rules), but decode runs `RECOGNITION_STEPS_PER_SYNC` device-resident steps per host
-    round trip. Per-line outputs do not depend on batch composition MATHEMATICALLY (attention and positions are
-    per-sequence); in fp32 mode the emitted tokens are bit-identical to the oracle's. In bf16 the GEMM tile / split-K
-    choice depends on the number of active rows, so a near-tie argmax can flip between batch sizes (bounded in
-    tests/test_gpu_fullsize.py); for a fixed slot count results are bit-reproducible whatever the host pacing.
+    round trip. Per-line outputs do not depend on batch composition: attention and positions are per-sequence, every GEMM
+    tile shape walks K in the same order, and the split-K slice count / lm_head partial width depend on the weight shape only
+    (tests/test_gpu_fullsize.py demands identical tokens, boxes and scores across slot counts); in fp32 mode the emitted
+    tokens are bit-identical to the oracle's.
 There is no CPU fallback: without the HIP library and a GPU, construction raises.
 """
 from __future__ import annotations
