@@ -283,8 +283,25 @@ def bench_det_e2e(args, cfg, sd, pages, local_rank):
         dt = (time.perf_counter() - t0) / reps
         res[name] = {"pages_per_s": round(len(imgs) / dt, 1), "ms_per_batch": round(dt * 1e3, 1),
                      "boxes": sum(len(r.bboxes) for r in out)}
+    # pages that are NOT at the processor size (every real page): US-letter at 150 dpi, 1275 x 1650 -> thumbnail 791 x 1024 ->
+    # 1024 x 1024, the reference's double LANCZOS resize (detection/__init__.py:50-57) on the device vs Pillow on 8 host threads
+    pred.device_postprocess = True
+    letter = [Image.fromarray(p).resize((1275, 1650), Image.Resampling.BILINEAR) for p in pages]
+    for name, dev in (("letter_pages_device_resize", True), ("letter_pages_host_resize", False)):
+        pred.device_resize = dev
+        out = pred(letter)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = pred(letter)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        res[name] = {"pages_per_s": round(len(letter) / dt, 1), "ms_per_batch": round(dt * 1e3, 1),
+                     "boxes": sum(len(r.bboxes) for r in out)}
+    pred.device_resize = True
     res["note"] = (f"{len(imgs)} PIL pages per call, wall clock of DetectionPredictor.__call__ incl. host pre-processing, H2D, forward, "
-                   "heat map -> boxes, result assembly; one process, host threads as configured")
+                   "heat map -> boxes, result assembly; one process, host threads as configured; letter_pages_* = 1275 x 1650 pages "
+                   "that need the double LANCZOS resize to the 1024^2 processor size")
     del pred
     torch.cuda.empty_cache()
     return res

@@ -260,6 +260,19 @@ int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float*
 int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, int pixel_stride, const float* mean, const float* std, int batch,
                          float* heatmaps, float* lowres, void* stream);
 
+/* One Pillow `Image.resize(size, LANCZOS)` of an 8-bit RGB page on the device (detection side). Replaces the
+ * two host resizes of DetectionPredictor.prepare_image (surya/detection/__init__.py:50-57: img.thumbnail(size, LANCZOS) then
+ * img.resize(size, LANCZOS) = two calls here; the sizes and the 22-bit fixed-point coefficient tables of Pillow's resampler come
+ * from surya_amd/common/pil_resample.py, which restates Pillow's precompute_coeffs / normalize_coeffs_8bpc). Bit-identical to
+ * Pillow: int32 accumulation from 2^21, arithmetic shift by 22, clip to 0..255, horizontal pass first into `tmp`.
+ *   src / dst   device uint8 [h][w][pix], pix = 3 (RGB) or 4 (RGBX, fourth byte ignored / written 0)
+ *   bounds_*    device int32 [out][2] = (first source index, tap count); taps_* device int32 [out][ksize_*]
+ *               (x tables may be NULL when the width does not change, y tables when the height does not)
+ *   tmp         device scratch of src_h * dst_w * 4 bytes, needed when both axes change. Enqueue only. */
+int surya_resample_lanczos_u8(const uint8_t* src, int src_w, int src_h, int src_pix, uint8_t* dst, int dst_w, int dst_h, int dst_pix,
+                              const int32_t* bounds_x, const int32_t* taps_x, int ksize_x, const int32_t* bounds_y,
+                              const int32_t* taps_y, int ksize_y, uint8_t* tmp, void* stream);
+
 /* Heat map -> text boxes on the device. Replaces detect_boxes (surya/detection/heatmap.py:27-107:
  * get_dynamic_thresholds :14-24, cv2.connectedComponentsWithStats, per-component cv2.dilate + cv2.minAreaRect + cv2.boxPoints,
  * corner order, confidence = component max / page max) for `batch` pages at once; what is left for the host is

@@ -10,6 +10,7 @@
 #include "../../include/surya_amd.h"
 #include "det_kernels.h"
 #include "det_post.h"
+#include "resample.h"
 
 namespace sa {
 
@@ -221,6 +222,15 @@ int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, int pixel_str
     if (!h || !pixels_nhwc || !mean || !std || (!heatmaps && !lowres) || (pixel_stride != 3 && pixel_stride != 4)) return SA_ERR_ARG;
     const float ms[6] = {mean[0], mean[1], mean[2], std[0], std[1], std[2]};
     return h->impl->forward(nullptr, pixels_nhwc, ms, batch, heatmaps, lowres, (hipStream_t)stream, pixel_stride);
+}
+
+int surya_resample_lanczos_u8(const uint8_t* src, int src_w, int src_h, int src_pix, uint8_t* dst, int dst_w, int dst_h, int dst_pix,
+                              const int32_t* bounds_x, const int32_t* taps_x, int ksize_x, const int32_t* bounds_y,
+                              const int32_t* taps_y, int ksize_y, uint8_t* tmp, void* stream) {
+    if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_h > 65535 || dst_h > 65535) return SA_ERR_ARG;
+    if ((src_pix != 3 && src_pix != 4) || (dst_pix != 3 && dst_pix != 4)) return SA_ERR_ARG;
+    return sa::rs::resample_run(src, src_w, src_h, src_pix, dst, dst_w, dst_h, dst_pix, bounds_x, taps_x, ksize_x, bounds_y, taps_y,
+                                ksize_y, tmp, (hipStream_t)stream);
 }
 
 }  // extern "C"

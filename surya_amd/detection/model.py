@@ -162,3 +162,45 @@ class HipDetPost:
         stride is labels * H * W). Returns a list of (boxes float32 [n, 4, 2], confidences float32 [n]) per page, in the
         component order cv2.connectedComponentsWithStats would label them."""
         return self.collect(self.launch(heat, text_threshold, low_text))
+
+
+class DeviceResampler:
+    """Pillow LANCZOS resizes of uint8 pages on the device (surya_resample_lanczos_u8, csrc/resample.h). Coefficient tables are
+    built once per (source length, target length) pair by common/pil_resample.py and cached on the device."""
+
+    def __init__(self, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise L.SuryaAmdError("DeviceResampler needs a GPU (MI355X)")
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self._tables = {}
+
+    def _axis(self, n_in: int, n_out: int):
+        key = (n_in, n_out)
+        t = self._tables.get(key)
+        if t is None:
+            from ..common.pil_resample import lanczos_coeffs
+            b, kk, ks = lanczos_coeffs(n_in, n_out)
+            t = self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(kk).to(self.device), ks)
+        return t
+
+    def resize(self, src: torch.Tensor, size, out: torch.Tensor = None) -> torch.Tensor:
+        """src cuda uint8 [h, w, 3|4] -> Image.resize((W, H), LANCZOS) of it as uint8 [H, W, out.shape[2] or 4]."""
+        assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 3
+        h, w, sp = src.shape
+        W, H = int(size[0]), int(size[1])
+        if out is None:
+            out = torch.empty((H, W, 4), dtype=torch.uint8, device=self.device)
+        assert out.is_cuda and out.is_contiguous() and tuple(out.shape[:2]) == (H, W) and out.shape[2] in (3, 4)
+        bx = kx = by = ky = None
+        ksx = ksy = 0
+        if W != w:
+            bx, kx, ksx = self._axis(w, W)
+        if H != h:
+            by, ky, ksy = self._axis(h, H)
+        tmp = torch.empty((h, W, 4), dtype=torch.uint8, device=self.device) if (W != w and H != h) else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.surya_resample_lanczos_u8(L.ptr(src), C.c_int(w), C.c_int(h), C.c_int(sp), L.ptr(out), C.c_int(W), C.c_int(H),
+                                                   C.c_int(out.shape[2]), L.ptr(bx), L.ptr(kx), C.c_int(ksx), L.ptr(by), L.ptr(ky),
+                                                   C.c_int(ksy), L.ptr(tmp), stream), "surya_resample_lanczos_u8")
+        return out

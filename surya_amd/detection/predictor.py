@@ -20,7 +20,8 @@ from ..common.predictor import BasePredictor, ModelLoader, gc_paused
 from ..config import DetConfig, det_config
 from ..settings import settings
 from .heatmap import TextDetectionResult, parallel_get_boxes, result_from_device_boxes
-from .model import HipDetModel, HipDetPost
+from ..common.pil_resample import plan as plan_resize
+from .model import DeviceResampler, HipDetModel, HipDetPost
 
 
 class SegformerImageProcessor:
@@ -122,6 +123,9 @@ class DetectionPredictor(BasePredictor):
     # of two fp32 maps (8 MB at 1024^2). DETECTOR_POSTPROCESS_HOST=1 keeps the host post-processing of the reference layout
     # (heat maps D2H + surya_amd/detection/heatmap.py on a thread pool): the checker of tests/test_gpu_det.py, not a fallback.
     device_postprocess: bool = not settings.DETECTOR_POSTPROCESS_HOST
+    # the double LANCZOS resize of every page on the device; DETECTOR_RESIZE_HOST=1 keeps Pillow on a thread pool (the checker of
+    # tests/test_gpu_resample.py; also what pages take whose resize needs Pillow's reduce() pre-pass)
+    device_resize: bool = not settings.DETECTOR_RESIZE_HOST
 
     def _detect(self, images: List[Image.Image], batch_size=None, include_maps=False) -> List[TextDetectionResult]:
         if self.device_postprocess:
@@ -231,24 +235,48 @@ class DetectionPredictor(BasePredictor):
                 parts.extend(ps)
                 split_index.extend([k] * len(ps))
                 split_heights.extend(hs)
-            # pages go to the device as uint8 at the processor size; rescale + normalise happen in the model's first kernel
+            # pages go to the device as uint8; the reference's double LANCZOS resize to the processor size runs there too
+            # (surya_resample_lanczos_u8, bit-identical to Pillow) unless Pillow would take a path the kernels do not restate
+            # (a reduce() pre-pass for >= 4x shrinks: common/pil_resample.plan) or DETECTOR_RESIZE_HOST=1 asks for the host path;
+            # rescale + normalise happen in the model's first kernel
             pw = self.processor.size["width"]
-            if len(parts) > 4:
+            plans = [None if not self.device_resize else plan_resize(p_.size[0], p_.size[1], (pw, ph)) for p_ in parts]
+            on_host = [k for k, pl in enumerate(plans) if pl is None]
+            px = [None] * len(parts)
+            if len(on_host) > 4:
                 if getattr(self, "_prep_pool", None) is None:               # one pool per predictor: thread start-up cost ~0.7 ms each
                     self._prep_pool = ThreadPoolExecutor(8)
-                px = list(self._prep_pool.map(self.resize_image, parts))    # PIL resizes release the GIL
+                for k, a in zip(on_host, self._prep_pool.map(self.resize_image, [parts[k] for k in on_host])):   # PIL releases the GIL
+                    px[k] = a
             else:
-                px = [self.resize_image(p_) for p_ in parts]
+                for k in on_host:
+                    px[k] = self.resize_image(parts[k])
+            for k, pl in enumerate(plans):
+                if pl is not None:
+                    px[k] = page_pixels(parts[k])                           # source pixels; resized on the device below
             # RGBX views of PIL's own memory where it can export them (page_pixels), else repacked RGB; one stride per batch
-            pix = 4 if all(a.shape[2] == 4 for a in px) else 3
+            ready = [k for k, pl in enumerate(plans) if pl is None or not pl]          # already at the processor size
+            pix = 4 if all(px[k].shape[2] == 4 for k in ready) else 3
             host = torch.empty((len(parts), ph, pw, pix), dtype=torch.uint8, pin_memory=True)   # caching host allocator
             hv = host.numpy()
-            for k, a in enumerate(px):
-                hv[k] = a if a.shape[2] == pix else a[..., :3]
+            for k in ready:
+                hv[k] = px[k] if px[k].shape[2] == pix else px[k][..., :3]
+            dev_batch = host.to(self.model.device, non_blocking=True)
+            for k, pl in enumerate(plans):
+                if not pl:
+                    continue
+                if getattr(self, "_resampler", None) is None:
+                    self._resampler = DeviceResampler(self.model.device)
+                a = px[k]
+                stage = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+                stage.numpy()[...] = a
+                cur = stage.to(self.model.device, non_blocking=True)
+                for i, tgt in enumerate(pl):                                # thumbnail's size, then the processor size
+                    cur = self._resampler.resize(cur, tgt, out=dev_batch[k] if i == len(pl) - 1 else None)
             heat_parts = []
             for s in range(0, len(parts), self.model.max_batch):            # a single page may exceed max_batch tiles
-                chunk = host[s: s + self.model.max_batch].to(self.model.device, non_blocking=True)
-                heat_parts.append(self.model.forward_u8(chunk, self.processor.image_mean, self.processor.image_std))
+                heat_parts.append(self.model.forward_u8(dev_batch[s: s + self.model.max_batch], self.processor.image_mean,
+                                                        self.processor.image_std))
             heat = heat_parts[0] if len(heat_parts) == 1 else torch.cat(heat_parts, 0)
             yield heat, split_index, [min(h, ph) for h in split_heights], [orig_sizes[j] for j in idxs]
 

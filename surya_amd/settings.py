@@ -36,6 +36,7 @@ class Settings:
                                                             min(8, os.cpu_count() or 1))
         self.DETECTOR_MIN_PARALLEL_THRESH: int = _env("DETECTOR_MIN_PARALLEL_THRESH", int, 3)
         self.DETECTOR_POSTPROCESS_HOST: bool = _env("DETECTOR_POSTPROCESS_HOST", bool, False)   # this implementation only
+        self.DETECTOR_RESIZE_HOST: bool = _env("DETECTOR_RESIZE_HOST", bool, False)   # this implementation only
         self.DETECTOR_BOX_Y_EXPAND_MARGIN: float = _env("DETECTOR_BOX_Y_EXPAND_MARGIN", float, 0.05)
         # recognition (settings.py:77-94)
         self.RECOGNITION_MAX_TOKENS: Optional[int] = _env("RECOGNITION_MAX_TOKENS", int, None)
