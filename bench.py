@@ -24,7 +24,9 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
+import traceback
 
 import numpy as np
 import torch
@@ -62,6 +64,9 @@ def parse():
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
+    ap.add_argument("--aux-timeout", type=float, default=None,
+                    help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
+                         "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo)")
     return ap.parse_args()
@@ -554,39 +559,67 @@ def main():
                 "launches_per_step": dom["launches"],
                 "all_gemm_configs": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in cats]}
 
-    cpu, parity = None, None
+    # The timed main leg is done: from here on the ONE JSON line is guaranteed. The auxiliary legs run under try/except (their
+    # object becomes {"error": ...}) and under a watchdog: a leg that hangs (e.g. a collective of the sharded e2e leg on a node
+    # where one rank died) makes every rank print / exit after --aux-timeout instead of losing the measured main-leg number.
+    lines_total = args.lines * world * args.steps
+    out = {
+        "metric": "text-lines/sec recognised (whole node)", "value": round(lines_total / dt, 2), "unit": "lines/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"RecognitionPredictor device loop, {args.lines} ragged 64x{{128..512}} crops/GPU, batch {args.batch}, "
+                               f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
+                   "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
+                   "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
+        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None,
+    }
+    emit_lock = threading.Lock()
+    emitted = [False]
+
+    def emit():
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+
+    aux_timeout = args.aux_timeout if args.aux_timeout is not None else (900.0 if world == 1 else 240.0)
+
+    def watchdog():
+        out["aux_timeout"] = f"auxiliary legs did not finish within {aux_timeout:.0f} s; unfinished ones are null"
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    timer = threading.Timer(aux_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except Exception as e:          # an auxiliary leg must never cost the main-leg line
+            traceback.print_exc()
+            return {"error": f"{name}: {type(e).__name__}: {str(e)[:300]}"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(cfg, sd, prep, min(args.cpu_lines, args.lines), args.max_tokens, toks)
-
-    det = None
+        r = leg("cpu_baseline", lambda: cpu_baseline(cfg, sd, prep, min(args.cpu_lines, args.lines), args.max_tokens, toks))
+        out["cpu_baseline"], out["parity"] = r if isinstance(r, tuple) else (r, None)
     if not args.no_det:
-        det = bench_det(args, local_rank, world, rank, barrier)
-    e2e = None
+        out["detection"] = leg("detection", lambda: bench_det(args, local_rank, world, rank, barrier))
     if not args.no_e2e:
-        e2e = bench_e2e(args, pred, local_rank, world, rank, barrier)
-
-    tex = None
+        out["e2e"] = leg("e2e", lambda: bench_e2e(args, pred, local_rank, world, rank, barrier))
     if rank == 0 and world == 1 and not args.no_texify:
         del pred
         torch.cuda.empty_cache()
-        tex = bench_texify(args, cfg, sd, local_rank)
+        out["texify"] = leg("texify", lambda: bench_texify(args, cfg, sd, local_rank))
 
-    if rank == 0:
-        lines_total = args.lines * world * args.steps
-        out = {
-            "metric": "text-lines/sec recognised (whole node)", "value": round(lines_total / dt, 2), "unit": "lines/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"RecognitionPredictor device loop, {args.lines} ragged 64x{{128..512}} crops/GPU, batch {args.batch}, "
-                                   f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
-                       "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
-                       "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "detection": det, "e2e": e2e, "texify": tex,
-        }
-        print(json.dumps(out), flush=True)
+    emit()
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # still under the watchdog: a dead peer must not hang the exit
+    timer.cancel()
 
 
 if __name__ == "__main__":

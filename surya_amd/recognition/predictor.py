@@ -29,7 +29,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-from ..common.geometry import PolygonBox
+from ..common.geometry import PolygonBox, coerce_polygon
 from ..common.imageops import fill_poly_mask
 from ..common.predictor import BasePredictor, ModelLoader, gc_paused
 from ..config import RecConfig, rec_config
@@ -55,6 +55,24 @@ def _text_char(polygon, confidence, text, bbox_valid) -> TextChar:
     m = _new_char(TextChar)
     _set(m, "__dict__", {"polygon": polygon, "confidence": confidence, "text": text, "bbox_valid": bbox_valid})
     _set(m, "__pydantic_fields_set__", set(_CHAR_FIELDS))
+    _set(m, "__pydantic_extra__", None)
+    _set(m, "__pydantic_private__", None)
+    return m
+
+
+_LINE_FIELDS = ("polygon", "confidence", "text", "chars", "original_text_good", "words")
+assert frozenset(_LINE_FIELDS) == frozenset(TextLine.model_fields), "TextLine fields changed: update _text_line"
+_new_line = TextLine.__new__
+_BLANK_POLY = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float64)
+
+
+def _text_line(polygon, confidence, text, chars, words) -> TextLine:
+    """TextLine(...) for values that are already in validated form (polygon = coerce_polygon(...), confidence not NaN, chars a
+    list of TextChar): the object state validation would produce, without walking the character list again."""
+    m = _new_line(TextLine)
+    _set(m, "__dict__", {"polygon": polygon, "confidence": confidence, "text": text, "chars": chars,
+                         "original_text_good": False, "words": words})
+    _set(m, "__pydantic_fields_set__", {"polygon", "confidence", "text", "chars", "words"})     # as TextLine(text=, polygon=, ...)
     _set(m, "__pydantic_extra__", None)
     _set(m, "__pydantic_private__", None)
     return m
@@ -384,9 +402,10 @@ class RecognitionPredictor(BasePredictor):
         return {"prompts": prompts, "max_tokens": max_tokens, "tiles": tiles, "tile_offs": tile_offs, "grids": grids,
                 "prompt_ids": prompt_ids}
 
-    def generate(self, prep: dict, recognition_batch_size: int | None = None, on_done=None) -> tuple:
+    def generate(self, prep: dict, recognition_batch_size: int | None = None, on_done=None, on_flush=None) -> tuple:
         """Device half: continuous batching over KV slots until every line stopped (reference :501-607).
-        on_done(line, tokens, scores, bbox_rows[T, 6]) is called once per line, as soon as its stream is final."""
+        on_done(line, tokens, scores, bbox_rows[T, 6]) is called once per line, as soon as its stream is final; on_flush() after
+        every host synchronisation point that finished at least one line (so a caller can hand the lines over in batches)."""
         prompts, batch_max_tokens = prep["prompts"], prep["max_tokens"]
         tiles, tile_offs, grids, prompt_ids = prep["tiles"], prep["tile_offs"], prep["grids"], prep["prompt_ids"]
         n = len(prompts)
@@ -399,22 +418,38 @@ class RecognitionPredictor(BasePredictor):
         self.prompt_queue.extend(prompts)
         overall_max_tokens = max(batch_max_tokens.values())
         batch_bboxes = np.zeros((n, overall_max_tokens, 6), np.float32)
-        batch_pos = [0] * n
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
         steps_per_sync = max(1, min(settings.RECOGNITION_STEPS_PER_SYNC, 8))
         max_prefill = self.model.c.max_prefill_tokens
-
-        def record(p_idx, tok, score, bbox):
-            predicted_tokens[p_idx].append(int(tok))
-            if batch_pos[p_idx] < overall_max_tokens:
-                batch_bboxes[p_idx, batch_pos[p_idx]] = bbox
-            batch_pos[p_idx] += 1
-            scores[p_idx].append(float(score))
+        # Token bookkeeping in array form: one row per line, written for all active slots of a step at once (the per-token Python
+        # loop cost 1.2-1.6 us per token, a third of the device's own time per decode call, and fought the assembly thread for
+        # the GIL). batch_prompt_mapping stays the slot table the scheduling decisions read; slot_line mirrors it as an array.
+        cap = max(1, overall_max_tokens) + 1
+        tok_mat = np.zeros((n, cap), np.int64)
+        sc_mat = np.zeros((n, cap), np.float32)
+        line_len = np.zeros(n, np.int64)
+        max_tok = np.asarray([batch_max_tokens[i] for i in range(n)], np.int64)
+        slot_line = np.full(recognition_batch_size, -1, np.int64)
+        REP = 40                                               # detect_repeat_token's window
+        rep_cols = np.arange(-REP, 0)
 
         def finished(p_idx):
+            L_ = int(line_len[p_idx])
+            predicted_tokens[p_idx] = tok_mat[p_idx, :L_].tolist()
+            scores[p_idx] = sc_mat[p_idx, :L_].tolist()
             if on_done is not None:
-                n_ = min(batch_pos[p_idx], overall_max_tokens)
-                on_done(p_idx, predicted_tokens[p_idx], scores[p_idx], batch_bboxes[p_idx, :max(n_, 1)])
+                on_done(p_idx, predicted_tokens[p_idx], scores[p_idx], batch_bboxes[p_idx, :max(min(L_, overall_max_tokens), 1)])
+
+        def put(p, pos, t, s_, b_):
+            """Token t / score s_ / box b_ of lines p at positions pos (arrays over the lines of one step)."""
+            tok_mat[p, pos] = t
+            sc_mat[p, pos] = s_
+            m = pos < overall_max_tokens
+            if m.all():
+                batch_bboxes[p, pos] = b_
+            elif m.any():
+                batch_bboxes[p[m], pos[m]] = b_[m]
+            line_len[p] = pos + 1
 
         def absorb(call):
             """Host half of one decode call: append its tokens, apply the stop rules (reference :583-595)."""
@@ -422,18 +457,35 @@ class RecognitionPredictor(BasePredictor):
             tok, sc, bb = self.model.wait_outputs(k, ring)
             changed = False
             for step in range(k):
-                for s, p_idx in self.batch_prompt_mapping.items():
-                    if p_idx is None:
-                        continue
-                    record(p_idx, tok[step, s], sc[step, s], bb[step, s])
-                    toks = predicted_tokens[p_idx]
-                    stop = len(toks) >= batch_max_tokens[p_idx] or detect_repeat_token(toks)
-                    if toks[-1] in (eos, pad) or stop:
-                        self.batch_prompt_mapping[s] = None
-                        changed = True
-                        finished(p_idx)
+                s_idx = np.flatnonzero(slot_line >= 0)
+                if s_idx.size == 0:
+                    break
+                p = slot_line[s_idx]
+                pos = line_len[p]
+                t = tok[step, s_idx]
+                put(p, pos, t, sc[step, s_idx], bb[step, s_idx])
+                new_len = pos + 1
+                stop = (t == eos) | (t == pad) | (new_len >= max_tok[p])
+                # repeat rule: <= 5 distinct ids in the last 40 and the last u ids equal to the u before; the distinct count is
+                # screened in array form, only the few candidate lines run the exact rule
+                c = np.flatnonzero(~stop & (new_len >= REP))
+                if c.size:
+                    win = np.sort(tok_mat[p[c, None], new_len[c, None] + rep_cols], axis=1)
+                    few = c[(np.diff(win, axis=1) != 0).sum(axis=1) + 1 <= 5]
+                    for ci in few.tolist():
+                        if detect_repeat_token(tok_mat[p[ci], :new_len[ci]].tolist()):
+                            stop[ci] = True
+                if stop.any():
+                    changed = True
+                    for ci in np.flatnonzero(stop).tolist():
+                        s_ = int(s_idx[ci])
+                        slot_line[s_] = -1
+                        self.batch_prompt_mapping[s_] = None
+                        finished(int(p[ci]))
             if changed:
                 self.model.set_active([k_ for k_, v in self.batch_prompt_mapping.items() if v is not None])
+                if on_flush is not None:
+                    on_flush()
 
         # Look-ahead encoding (RECOGNITION_ENCODE_AHEAD, default on): the vision encoder of the next up-to-batch-size queued
         # lines runs on the model's second stream while the current lines decode; prefill then only scatters the finished
@@ -486,17 +538,22 @@ class RecognitionPredictor(BasePredictor):
                 else:
                     self.model.prefill(tiles[a:b], [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
                 tok, sc, bb = self.model.read_outputs(1)
-                for p, s in zip(take, slots):
-                    record(p.id, tok[0, s], sc[0, s], bb[0, s])
-                    if predicted_tokens[p.id][-1] not in (eos, nop):       # prefill stop rule (reference :559-563)
-                        self.batch_prompt_mapping[s] = p.id
+                ids_, sl_ = np.asarray([p.id for p in take], np.int64), np.asarray(slots, np.int64)
+                first = tok[0, sl_]
+                put(ids_, np.zeros(len(take), np.int64), first, sc[0, sl_], bb[0, sl_])
+                for p_id, s, go in zip(ids_.tolist(), slots, ((first != eos) & (first != nop)).tolist()):
+                    if go:                                                  # prefill stop rule (reference :559-563)
+                        self.batch_prompt_mapping[s] = p_id
+                        slot_line[s] = p_id
                     else:
-                        finished(p.id)
+                        finished(p_id)
                 self.model.set_active([k for k, v in self.batch_prompt_mapping.items() if v is not None])
+                if on_flush is not None:
+                    on_flush()
             else:
                 # steps some active line can still need once the call in flight is done (token budgets are known up front)
-                budget = max((batch_max_tokens[p] - len(predicted_tokens[p]) for p in self.batch_prompt_mapping.values()
-                              if p is not None), default=0) - (inflight[0] if inflight else 0)
+                act = slot_line[slot_line >= 0]
+                budget = (int((max_tok[act] - line_len[act]).max()) if act.size else 0) - (inflight[0] if inflight else 0)
                 if budget <= 0 and not inflight and self.num_active_slots > 0:
                     budget = 1                         # a line admitted with a one-token budget still gets its stop-rule step
                 nxt = None
@@ -556,9 +613,7 @@ class RecognitionPredictor(BasePredictor):
         Array form of the reference's per-token loop: run boundaries, close-polygon filtering and the
         char -> box index map are numpy expressions per line; Python only walks the (few) runs of a line. Lines come back as
         None (<NOP>), or a tuple that `_chars_of` turns into TextChars after the geometry has been applied in bulk."""
-        tk = self.processor.ocr_tokenizer
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
-        q_off, s_off = tk.qwen_offset, tk.special_token_offset
         blank = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float64)
         out = []
         for tokens, polys, sc in zip(predicted_tokens, predicted_polygons, scores):
@@ -578,35 +633,9 @@ class RecognitionPredictor(BasePredictor):
             tid = tid[:n]
             P = np.asarray(polys[:n], np.float64)
             conf = np.asarray(sc[:n], np.float64)
-            ids = tid.tolist()
-            kind = [0 if t < q_off else (1 if t < s_off else 2) for t in ids]
             # clean_close_polygons: a box is dropped when all 4 corners sit within 0.1 of the PREVIOUS box of its run (util.py:100-120)
             far = (np.abs(P[1:] - P[:-1]).reshape(n - 1, 8).max(axis=1) > 0.1).tolist() if n > 1 else []
-            # per output char: its text, the token whose BOX it takes, the token whose CONFIDENCE it takes, bbox_valid. The
-            # reference indexes the run's unfiltered confidences with the index into its FILTERED boxes (:700-712): kept as is.
-            texts, src, csrc, valid = [], [], [], []
-            a_ = 0
-            while a_ < n:
-                k = kind[a_]
-                b_ = a_ + 1
-                if k != 1:
-                    while b_ < n and kind[b_] == k:
-                        b_ += 1
-                if k == 2:
-                    # a run of UTF-16 code units decodes in one piece (tokenizer._decode_ocr's flush of a non-math buffer)
-                    text = array("H", [t - s_off for t in ids[a_:b_]]).tobytes().decode("utf-16le", errors="ignore")
-                    if text:
-                        boxes = [a_] + [j for j in range(a_ + 1, b_) if far[j - 1]]
-                        L, nb = len(text), len(boxes)
-                        texts.extend(text)
-                        src.extend(boxes[:L] if L <= nb else boxes + [boxes[-1]] * (L - nb))      # char i -> box min(i, nb - 1)
-                        csrc.extend(range(a_, a_ + L) if L <= nb else list(range(a_, a_ + nb)) + [a_ + nb - 1] * (L - nb))
-                        valid.extend([True] * L)
-                else:
-                    text = tk.decode(ids[a_:b_], task=TaskNames.ocr_without_boxes if k == 1 else TaskNames.block_without_boxes)
-                    if not (k == 1 and (text == NOMATH_TOKEN or _SCRIPT_TAG.match(text))):
-                        texts.append(text); src.append(a_); csrc.append(a_); valid.append(False)
-                a_ = b_
+            texts, src, csrc, valid = self._line_runs(tid.tolist(), far)
             if not texts:
                 out.append(([], np.zeros(0), np.zeros(0, bool), np.zeros((0, 4, 2))))
             else:
@@ -615,6 +644,45 @@ class RecognitionPredictor(BasePredictor):
                 pp[~v] = blank
                 out.append((texts, conf[csrc], v, pp))
         return out
+
+    def _line_runs(self, ids: list, far: list):
+        """The runs of one token stream (already cut at eos / pad): per output char its text, the token whose BOX it takes, the
+        token whose CONFIDENCE it takes, bbox_valid. `far[j]`: box j + 1 differs from box j by more than 0.1 in some corner. The
+        reference indexes a run's unfiltered confidences with the index into its FILTERED boxes (:700-712): kept as is."""
+        tk = self.processor.ocr_tokenizer
+        q_off, s_off = tk.qwen_offset, tk.special_token_offset
+        n = len(ids)
+        texts, src, csrc, valid = [], [], [], []
+        if n and min(ids) >= s_off:
+            kind = None                                  # one UTF-16 run (the usual line of text)
+        else:
+            kind = [0 if t < q_off else (1 if t < s_off else 2) for t in ids]
+        a_ = 0
+        while a_ < n:
+            if kind is None:
+                k, b_ = 2, n
+            else:
+                k = kind[a_]
+                b_ = a_ + 1
+                if k != 1:
+                    while b_ < n and kind[b_] == k:
+                        b_ += 1
+            if k == 2:
+                # a run of UTF-16 code units decodes in one piece (tokenizer._decode_ocr's flush of a non-math buffer)
+                text = array("H", [t - s_off for t in ids[a_:b_]]).tobytes().decode("utf-16le", errors="ignore")
+                if text:
+                    boxes = [a_] + [j for j in range(a_ + 1, b_) if far[j - 1]]
+                    L, nb = len(text), len(boxes)
+                    texts.extend(text)
+                    src.extend(boxes[:L] if L <= nb else boxes + [boxes[-1]] * (L - nb))      # char i -> box min(i, nb - 1)
+                    csrc.extend(range(a_, a_ + L) if L <= nb else list(range(a_, a_ + nb)) + [a_ + nb - 1] * (L - nb))
+                    valid.extend([True] * L)
+            else:
+                text = tk.decode(ids[a_:b_], task=TaskNames.ocr_without_boxes if k == 1 else TaskNames.block_without_boxes)
+                if not (k == 1 and (text == NOMATH_TOKEN or _SCRIPT_TAG.match(text))):
+                    texts.append(text); src.append(a_); csrc.append(a_); valid.append(False)
+            a_ = b_
+        return texts, src, csrc, valid
 
     @staticmethod
     def _chars_of(line, res_scale, line_bbox) -> List[TextChar]:
@@ -647,6 +715,85 @@ class RecognitionPredictor(BasePredictor):
         text = clean_math_tags(unwrap_math("".join(c.text for c in chars)))
         return TextLine(text=text, polygon=polygon, chars=chars, confidence=confidence,
                         words=words_from_chars(chars, box) if return_words else [])
+
+    def _assemble_batch(self, flat, items, drop_repeated_text, return_words, bbox_size) -> List[TextLine]:
+        """TextLines of several finished lines at once; items = [(sorted_pos, orig, tokens, scores, bbox_rows[T, 6])]. The same
+        result as `_assemble_line` per item (tests/test_assemble_cpu.py compares the two), but the numpy work -- box tokens ->
+        polygons, close-box filter, per-char rescale / shift / clamp -- is done ONCE for the whole batch instead of ~25 small
+        array calls per line, and TextLine is built from values that are already in validated form. Python walks only the token
+        runs (`_line_runs`) and creates the character objects. ~430 -> ~130 us per 45-character line (tools/hostbench)."""
+        eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
+        out: List[Optional[TextLine]] = [None] * len(items)
+        work, t_max = [], 0
+        for i, (sp, orig, tokens, sc, rows) in enumerate(items):
+            if nop in tokens or (drop_repeated_text and detect_repeat_token(tokens)):
+                out[i] = self._assemble_line(flat, sp, orig, tokens, sc, rows, drop_repeated_text, return_words, bbox_size)
+                continue
+            n = len(tokens)
+            for j, t in enumerate(tokens):
+                if t == eos or t == pad:
+                    n = j
+                    break
+            n = min(n, len(rows), len(sc))
+            if n == 0:
+                out[i] = TextLine(text="", polygon=flat["polygons"][orig], chars=[], confidence=1, original_text_good=True)
+                continue
+            work.append((i, n))
+            t_max = max(t_max, n)
+        if not work:
+            return out
+        W = len(work)
+        R = np.zeros((W, t_max, 6), np.float32)
+        for w, (i, n) in enumerate(work):
+            R[w, :n] = items[i][4][:n]
+        P = prediction_to_polygon_batch(R, [flat["slices"][items[i][0]].shape for i, _ in work], bbox_size,
+                                        bbox_size // 2).astype(np.float64)                       # [W, t_max, 4, 2]
+        far = (np.abs(P[:, 1:] - P[:, :-1]).reshape(W, t_max - 1, 8).max(axis=2) > 0.1).tolist() if t_max > 1 else [[]] * W
+        keep, all_w, all_src, all_conf, all_valid, counts, geo = [], [], [], [], [], [], []
+        for w, (i, n) in enumerate(work):
+            sp, orig, tokens, sc, rows = items[i]
+            texts, src, csrc, valid = self._line_runs(tokens[:n], far[w])
+            if not texts:                      # nothing decoded (reference :889-899)
+                out[i] = TextLine(text="", polygon=flat["polygons"][orig], chars=[], confidence=1, original_text_good=True)
+                continue
+            polygon = coerce_polygon(flat["polygons"][orig])
+            xs, ys = [p[0] for p in polygon], [p[1] for p in polygon]
+            bbox = [min(xs), min(ys), max(xs), max(ys)]
+            rs = flat["res_scales"][orig]
+            keep.append((i, texts, valid, polygon, bbox))
+            all_w.extend([w] * len(src)); all_src.extend(src); all_valid.extend(valid)
+            all_conf.extend([sc[j] for j in csrc])
+            counts.append(len(src))
+            geo.append((1.0 / rs[0], 1.0 / rs[1], bbox[0], bbox[1], bbox[2], bbox[3]))
+        if not keep:
+            return out
+        PP = P[all_w, all_src]                                                                    # [C, 4, 2]
+        v_all = np.asarray(all_valid, bool)
+        PP[~v_all] = _BLANK_POLY
+        g = np.repeat(np.asarray(geo, np.float64), counts, axis=0)[:, :, None]                    # [C, 6, 1]
+        PP[..., 0] = np.minimum(np.maximum(np.trunc(PP[..., 0] * g[:, 0]) + g[:, 2], g[:, 2]), g[:, 4])
+        PP[..., 1] = np.minimum(np.maximum(np.trunc(PP[..., 1] * g[:, 1]) + g[:, 3], g[:, 3]), g[:, 5])
+        polys = PP.tolist()
+        conf_arr = np.asarray(all_conf, np.float64)
+        special = self.processor.ocr_tokenizer.special_tokens
+        a = 0
+        for (i, texts, valid, polygon, bbox), c in zip(keep, counts):
+            b = a + c
+            confidence = float(np.mean(conf_arr[a:b]))
+            if confidence != confidence:
+                confidence = 0                                   # BaseChar's NaN -> 0 rule
+            chars = [_text_char(pg, 0 if cf != cf else cf, t, v) for pg, cf, t, v in zip(polys[a:b], all_conf[a:b], texts, valid)]
+            a = b
+            if not all(valid):                                   # tags only come from special / math runs (bbox_valid False)
+                chars = fix_unbalanced_tags(chars, special)
+                text = "".join(ch.text for ch in chars)
+            else:
+                text = "".join(texts)
+            if "<" in text:
+                text = clean_math_tags(unwrap_math(text))
+            words = words_from_chars(chars, PolygonBox(polygon=polygon)) if return_words else []
+            out[i] = _text_line(polygon, confidence, text, chars, words)
+        return out
 
     def __call__(self, images: List[Image.Image], task_names: List[str] | None = None, det_predictor=None,
                  detection_batch_size: int | None = None, recognition_batch_size: int | None = None,
@@ -697,31 +844,43 @@ class RecognitionPredictor(BasePredictor):
         orig_of = order
         bbox_size = self.model.cfg.bbox_size
 
-        def assemble(sorted_pos, tokens, sc, bbox_rows):
-            return self._assemble_line(flat, sorted_pos, orig_of[sorted_pos], tokens, sc, bbox_rows, drop_repeated_text,
-                                       return_words, bbox_size)
+        def assemble(batch):
+            # batch = [(sorted_pos, tokens, scores, bbox_rows)]: the lines that stopped at one synchronisation point
+            return self._assemble_batch(flat, [(k, orig_of[k], t, sc, bb) for k, t, sc, bb in batch], drop_repeated_text,
+                                        return_words, bbox_size)
 
         text_lines = [None] * len(order)                      # by ORIGINAL position
         if self.shard_lines:
             predicted_tokens, batch_bboxes, scores = self.sharded_prediction_loop(flat, recognition_batch_size, math_mode)
             bb = batch_bboxes.numpy()
-            for k in range(len(order)):
-                text_lines[orig_of[k]] = assemble(k, predicted_tokens[k], scores[k], bb[k])
+            for a in range(0, len(order), 256):
+                ks = range(a, min(a + 256, len(order)))
+                for k, line in zip(ks, assemble([(k, predicted_tokens[k], scores[k], bb[k]) for k in ks])):
+                    text_lines[orig_of[k]] = line
         else:
-            # Output assembly is host work of the same order as the device loop itself (~7 us per character object); it runs on
-            # one worker thread WHILE the device decodes the next lines: a line is handed over the moment its stream stops. The
-            # scheduler thread spends most of its time blocked in hipEventSynchronize (GIL released), which is when the worker runs.
-            futures = {}
+            # Output assembly is host work of the same order as the device loop itself; it runs on one worker thread WHILE the
+            # device decodes the next lines: the lines that stopped at a synchronisation point are handed over together as soon
+            # as it is over (batched numpy work, `_assemble_batch`). The scheduler thread spends most of its time blocked in
+            # hipEventSynchronize (GIL released), which is when the worker runs.
+            futures, pending = [], []
             with ThreadPoolExecutor(1) as pool:
                 def on_done(k, tokens, sc, bbox_rows):
-                    futures[k] = pool.submit(assemble, k, list(tokens), list(sc), bbox_rows.copy())
+                    pending.append((k, list(tokens), list(sc), bbox_rows.copy()))
+
+                def on_flush():
+                    if pending:
+                        batch = pending[:]
+                        pending.clear()
+                        futures.append(([b[0] for b in batch], pool.submit(assemble, batch)))
                 t0 = time.perf_counter()
                 prep = self.prepare_lines(flat, math_mode)
                 t1 = time.perf_counter()
-                self.generate(prep, recognition_batch_size, on_done=on_done)
+                self.generate(prep, recognition_batch_size, on_done=on_done, on_flush=on_flush)
+                on_flush()
                 t2 = time.perf_counter()
-                for k, f in futures.items():
-                    text_lines[orig_of[k]] = f.result()
+                for ks, f in futures:
+                    for k, line in zip(ks, f.result()):
+                        text_lines[orig_of[k]] = line
                 stamps.update(prepare_ms=(t1 - t0) * 1e3, device_loop_ms=(t2 - t1) * 1e3,
                               assemble_tail_ms=(time.perf_counter() - t2) * 1e3)
             assert all(t is not None for t in text_lines)

@@ -28,6 +28,8 @@ def script(line, t):
     stop = [5, 0, 11, None, 2, 17, None, 9, 1, 30][line % 10]
     if stop is not None and t >= stop:
         return EOS
+    if line % 10 == 6:
+        return 100 + line + (t % 3)         # a 3-cycle: trips detect_repeat_token once 40 tokens are out
     return 100 + (line * 37 + t * 11) % 9000
 
 
@@ -130,7 +132,8 @@ def make(n_lines, max_tokens, slots):
 
 
 @pytest.mark.parametrize("n_lines,max_tokens,slots,sps,ahead", [(23, 12, 4, 4, True), (23, 12, 4, 3, False), (9, 40, 16, 8, True),
-                                                                 (40, 6, 7, 1, True), (5, 1, 2, 4, True), (64, 20, 8, 4, True)])
+                                                                 (40, 6, 7, 1, True), (5, 1, 2, 4, True), (64, 20, 8, 4, True),
+                                                                 (30, 64, 8, 4, True), (27, 90, 5, 3, False)])
 def test_device_loop_matches_scripted_streams(n_lines, max_tokens, slots, sps, ahead):
     old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD)
     settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = sps, ahead
