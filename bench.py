@@ -551,7 +551,7 @@ def main():
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
                 "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic_for(dom["kernel"]),
                 "traffic_source": "profiles/hbm_traffic.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  "(profiles/r02_n_rec_hbm_traffic_pmc.md), bytes per launch of this bucket; not re-measured in this run",
+                                  "(profiles/r02_t_rec_hbm_traffic_pmc.md), bytes per launch of this bucket; not re-measured in this run",
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 # an event pair around an EMPTY kernel costs this much: rocprofv3's begin->end duration of the same launches
                 # lies between avg_launch_ms - event_pair_null_ms and avg_launch_ms
