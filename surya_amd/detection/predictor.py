@@ -41,12 +41,13 @@ def get_total_splits(image_size, height):              # surya/detection/util.py
     return math.ceil(image_size[1] / height) if image_size[1] > settings.DETECTOR_IMAGE_CHUNK_HEIGHT else 1
 
 
-def split_image(img: Image.Image, height: int):
+def split_image(img: Image.Image, height: int, copy: bool = True):
     """Tall pages (> DETECTOR_IMAGE_CHUNK_HEIGHT px) are cut into `height`-px strips, the last one white-padded
-    (surya/detection/util.py:16-36)."""
+    (surya/detection/util.py:16-36). copy=False hands a page that needs no cutting back as it is (for callers that only read
+    its pixels: the reference copies because its prepare_image resizes in place)."""
     ih = img.size[1]
     if ih <= settings.DETECTOR_IMAGE_CHUNK_HEIGHT:
-        return [img.copy()], [ih]
+        return [img.copy() if copy else img], [ih]
     parts, heights = [], []
     for i in range(math.ceil(ih / height)):
         top, bottom = i * height, min((i + 1) * height, ih)
@@ -196,6 +197,7 @@ class DetectionPredictor(BasePredictor):
         """The reference's double LANCZOS resize to the processor size (surya/detection/__init__.py:50-57), uint8 HWC."""
         new_size = (self.processor.size["width"], self.processor.size["height"])
         if img.size != new_size:
+            img = img.copy()                                          # thumbnail() works in place; the page may be the caller's
             img.thumbnail(new_size, Image.Resampling.LANCZOS)
             img = img.resize(new_size, Image.Resampling.LANCZOS)
         return page_pixels(img)
@@ -228,10 +230,13 @@ class DetectionPredictor(BasePredictor):
         if cur:
             batches.append(cur)
         for idxs in batches:
-            batch_images = [images[j].convert("RGB") for j in idxs]
+            # the device path only READS the pages (zero-copy pixel views, resize on the device): no defensive copies of pages that
+            # already are RGB (convert() and split_image() each copied 4 MB per 1024^2 page under the GIL; the Pillow resize of
+            # the host path, which works in place, copies for itself in resize_image)
+            batch_images = [images[j] if images[j].mode == "RGB" else images[j].convert("RGB") for j in idxs]
             split_index, split_heights, parts = [], [], []
             for k, im in enumerate(batch_images):
-                ps, hs = split_image(im, ph)
+                ps, hs = split_image(im, ph, copy=False)
                 parts.extend(ps)
                 split_index.extend([k] * len(ps))
                 split_heights.extend(hs)
