@@ -38,3 +38,37 @@ def install():
 
     mru.ROPE_INIT_FUNCTIONS.setdefault("default", _default_rope)
     return True
+
+
+def import_recognition():
+    """The reference's `surya.recognition` package itself (its __init__ imports `QuantizedCacheConfig` / `HQQQuantizedCache`, which
+    transformers 5.x no longer has, and transformers' lazy module forgets attributes set on it by hand): placeholder classes are
+    injected at the moment `from transformers import ...` asks for them. Only host logic of that package is usable this way
+    (`RecognitionPredictor.get_bboxes_text` and friends as plain functions); the quantised-cache code paths are not."""
+    import builtins
+    install()
+
+    class _Missing:
+        def __init__(self, *a, **k):
+            pass
+
+    names = {"QuantizedCacheConfig", "HQQQuantizedCache"}
+    orig = builtins.__import__
+
+    def hook(name, globals=None, locals=None, fromlist=(), level=0):
+        m = orig(name, globals, locals, fromlist, level)
+        if name == "transformers" and fromlist:
+            for n in fromlist:
+                if n in names and n not in m.__dict__:
+                    object.__setattr__(m, n, _Missing)
+        return m
+
+    for name, m in list(sys.modules.items()):         # bare namespaces registered to import submodules without their package
+        if name.startswith("surya.") and hasattr(m, "__path__") and getattr(m, "__spec__", None) is None:   # __init__ (tests)
+            del sys.modules[name]
+    builtins.__import__ = hook
+    try:
+        import surya.recognition as sr
+    finally:
+        builtins.__import__ = orig
+    return sr

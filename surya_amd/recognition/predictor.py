@@ -698,7 +698,7 @@ class RecognitionPredictor(BasePredictor):
         np.clip(P[..., 0], line_bbox[0], line_bbox[2], out=P[..., 0])
         np.clip(P[..., 1], line_bbox[1], line_bbox[3], out=P[..., 1])
         polys = P.tolist()
-        conf = [0 if c != c else c for c in conf.tolist()]
+        conf = [0.0 if c != c else c for c in conf.tolist()]               # BaseChar: NaN -> 0, stored as a float
         return [_text_char(pg, c, t, v) for pg, c, t, v in zip(polys, conf, texts, valid.tolist())]
 
     def _assemble_line(self, flat, sorted_pos, orig, tokens, sc, bbox_rows, drop_repeated_text, return_words, bbox_size) -> TextLine:
@@ -708,7 +708,8 @@ class RecognitionPredictor(BasePredictor):
         chars = self.get_bboxes_text(flat, [tokens], [sc], polys, drop_repeated_text)[0]
         if chars is None or not chars[0]:      # <NOP> (input text was good) or nothing decoded (reference :889-899)
             return TextLine(text="", polygon=polygon, chars=[], confidence=1, original_text_good=True)
-        confidence = float(np.mean(chars[1]))
+        # mean of the characters' confidences as the TextChar objects hold them (NaN -> 0, schema.py), reference :899-903
+        confidence = float(np.mean(np.where(np.isnan(chars[1]), 0.0, chars[1])))
         box = PolygonBox(polygon=polygon)
         chars = self._chars_of(chars, res_scale, box.bbox)
         chars = fix_unbalanced_tags(chars, self.processor.ocr_tokenizer.special_tokens)
@@ -762,7 +763,7 @@ class RecognitionPredictor(BasePredictor):
             rs = flat["res_scales"][orig]
             keep.append((i, texts, valid, polygon, bbox))
             all_w.extend([w] * len(src)); all_src.extend(src); all_valid.extend(valid)
-            all_conf.extend([sc[j] for j in csrc])
+            all_conf.extend([0.0 if sc[j] != sc[j] else sc[j] for j in csrc])          # TextChar's NaN -> 0 rule
             counts.append(len(src))
             geo.append((1.0 / rs[0], 1.0 / rs[1], bbox[0], bbox[1], bbox[2], bbox[3]))
         if not keep:
@@ -780,9 +781,7 @@ class RecognitionPredictor(BasePredictor):
         for (i, texts, valid, polygon, bbox), c in zip(keep, counts):
             b = a + c
             confidence = float(np.mean(conf_arr[a:b]))
-            if confidence != confidence:
-                confidence = 0                                   # BaseChar's NaN -> 0 rule
-            chars = [_text_char(pg, 0 if cf != cf else cf, t, v) for pg, cf, t, v in zip(polys[a:b], all_conf[a:b], texts, valid)]
+            chars = [_text_char(pg, cf, t, v) for pg, cf, t, v in zip(polys[a:b], all_conf[a:b], texts, valid)]
             a = b
             if not all(valid):                                   # tags only come from special / math runs (bbox_valid False)
                 chars = fix_unbalanced_tags(chars, special)
