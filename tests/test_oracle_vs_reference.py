@@ -379,3 +379,184 @@ def test_live_process_outputs_against_reference():
     for n in names:
         r = getattr(ref, n)
         assert got[n].shape == r.shape and torch.equal(got[n], r), n
+
+
+def test_live_tokenizer_against_reference_inner_ocr_tokenizer():
+    """SURVEY 8(a) R5 (prompt ids) / R16 (decode): our OCRTokenizer against the reference's own InnerOCRTokenizer
+    (common/surya/processor/tokenizer.py:26-221) built on the SAME stand-in math tokenizer and tag table: token ids of random
+    strings with formatting / math / system tags, html entities, astral characters and math spans (terminated ones: the reference
+    never returns on an unterminated <math>, see tokenizer.py note), and decode of random id streams from all three ranges."""
+    import random
+    rt = _ref("surya.common.surya.processor.tokenizer")
+    from surya_amd.recognition.tokenizer import ByteMathTokenizer, OCRTokenizer, DEFAULT_SPECIAL_TOKENS
+    math_tok = ByteMathTokenizer(300)
+    ours = OCRTokenizer(DEFAULT_SPECIAL_TOKENS, math_tok)
+    ref = rt.InnerOCRTokenizer(special_tokens=DEFAULT_SPECIAL_TOKENS, qwen_tokenizer=math_tok)
+    assert ours.qwen_offset == ref.qwen_token_offset and ours.special_token_offset == ref.qwen_token_offset + ref.SPECIAL_TOKEN_OFFSET
+    assert ours.SPECIAL_TOKEN_MAPPING == ref.SPECIAL_TOKEN_MAPPING and ours.vocab_size == ref.vocab_size + ref.qwen_token_offset
+    rng = random.Random(11)
+    tags = [t for k in ("formatting", "math_external", "system") for t in DEFAULT_SPECIAL_TOKENS.get(k, [])]
+    pieces = list("abc xyz0189.,;-ÄøЖ漢字😀🧪") + ["&lt;", "&amp;", "&gt;", "<", ">", "x^2", "\\frac{a}{b}", "<br>", "</"]
+    for _ in range(1500):
+        parts = []
+        for _ in range(rng.randint(0, 12)):
+            r = rng.random()
+            if r < 0.25:
+                parts.append(rng.choice(tags))
+            elif r < 0.35:
+                parts.append("<math>" + "".join(rng.choice(pieces) for _ in range(rng.randint(0, 5))) + "</math>")
+            else:
+                parts.append(rng.choice(pieces))
+        text = "".join(parts)
+        if text.count("<math") > text.count("</math>"):
+            text += "</math>"                               # keep spans terminated (the reference loops forever otherwise)
+        assert ours._tokenize_ocr(text) == ref._tokenize(text), text
+    specials = sorted(ref.REVERSE_SPECIAL_TOKEN_MAPPING)
+    for _ in range(1500):
+        ids = []
+        for _ in range(rng.randint(0, 30)):
+            r = rng.random()
+            if r < 0.5:
+                ids.append(ours.special_token_offset + rng.choice([rng.randint(0x20, 0x7e), rng.randint(0xa0, 0xd7ff), rng.randint(0xd800, 0xdfff)]))
+            elif r < 0.75:
+                ids.append(rng.choice(specials))
+            else:
+                ids.append(rng.randint(0, 255))
+        assert ours._decode_ocr(ids) == ref.decode(ids), ids
+
+
+def test_live_processor_call_against_reference():
+    """the reference's own SuryaOCRProcessor.__call__ (common/surya/processor/__init__.py:330-420, with
+    _process_ocr_with_boxes / _process_text_input / _process_image_input / _process_and_tile) and RecognitionPredictor.prepare_input
+    (:259-292) against ours on crops that need no cv2 resize (sides already multiples of 28, area inside the task's bounds): image
+    tiles bit for bit, grids, and per sequence the prompt ids (the reference's left-padded rows with the pad stripped), for all
+    three tasks, with and without input text, math mode on and off. The reference's position ids are what packed prompts imply."""
+    import numpy as np
+    from types import SimpleNamespace
+    sr = ref_shim.import_recognition()
+    rp = _ref("surya.common.surya.processor")
+    from surya_amd.recognition.processor import SuryaOCRProcessor
+    from surya_amd.recognition.tokenizer import ByteMathTokenizer, OCRTokenizer
+    from surya_amd.recognition.predictor import RecognitionPredictor
+    tok = OCRTokenizer(None, ByteMathTokenizer(256), reserve_special=64)
+    ours = SuryaOCRProcessor(tok)
+    ref = rp.SuryaOCRProcessor(ocr_tokenizer=tok, blank_bbox_token_id=1025, num_register_tokens=4, patch_size=14, merge_size=2,
+                               model_device="cpu")
+    for name in ("image_token_id", "pad_token_id", "eos_token_id", "eoi_token_id", "no_output_token", "image_rotated_token", "nomath_token"):
+        assert getattr(ours, name) == getattr(ref, name), name
+    assert ours.bos_token_id == ref.bos_token_id and ours.register_token_ids == ref.register_token_ids
+    rng = np.random.default_rng(3)
+    shapes = [(56, 504), (168, 168), (84, 532), (196, 336), (392, 392), (28 * 7, 28 * 9)]
+    tasks = ["ocr_with_boxes", "ocr_without_boxes", "block_without_boxes", "ocr_with_boxes", "ocr_with_boxes", "block_without_boxes"]
+    texts = [None, "ab <b>c</b>", "", "x <math>a^2</math> y", "  padded  ", None]
+    maths = [True, False, True, True, False, False]
+    images = [rng.integers(0, 256, size=(h, w, 3)).astype(np.float32) for h, w in shapes]
+    ours_pred = object.__new__(RecognitionPredictor)
+    ours_pred.processor = ours
+    ref_self = SimpleNamespace(processor=ref, tasks=sr.RecognitionPredictor.tasks)
+    ref_batch = sr.RecognitionPredictor.prepare_input(ref_self, tasks, images, texts, maths)
+    our_batch = ours_pred.prepare_input(tasks, images, texts, maths)
+    for rb, ob in zip(ref_batch, our_batch):
+        assert rb["task"] == ob["task"] and rb["inputs"][1] == ob["inputs"][1]
+        assert np.array_equal(rb["inputs"][0]["image"], ob["inputs"][0]["image"])
+    r = ref(ref_batch, padding_side="left")
+    o = ours(our_batch)
+    assert np.array_equal(r["image_tiles"].numpy(), o["image_tiles"])
+    assert np.array_equal(r["grid_thw"].numpy()[:, 1:], o["grid_hw"]) and (r["grid_thw"].numpy()[:, 0] == 1).all()
+    for i, seq in enumerate(o["input_ids"]):
+        row, am, pos = r["input_ids"][i], r["attention_mask"][i], r["position_ids"][i]
+        assert row[am].tolist() == list(seq), i
+        assert pos[am].tolist() == list(range(len(seq))), i           # packed prompts: positions 0..L-1 of the real tokens
+
+
+@pytest.mark.parametrize("sort_lines,return_words", [(False, False), (True, True)])
+def test_live_recognition_call_against_reference_call(sort_lines, return_words):
+    """SURVEY 8(a) R1 + R2 (bbox slicing) + R16 end to end on the host: the reference's own RecognitionPredictor.__call__
+    (recognition/__init__.py:773-942) -- slice_bboxes, widest-first sort, restore order, polygons, get_bboxes_text, per-page
+    regrouping, sort_text_lines, OCRResult -- runs with its prediction_loop replaced by a scripted one (tokens / scores / boxes
+    are a function of each crop's pixels, so they do not depend on the order lines are processed in); ours runs with the same
+    scripted device loop behind prepare_lines / generate. The OCRResults must be identical, field for field."""
+    import numpy as np
+    from types import SimpleNamespace
+    from PIL import Image
+    sr = ref_shim.import_recognition()
+    R = sr.RecognitionPredictor
+    from surya_amd.recognition.predictor import RecognitionPredictor
+    from surya_amd.recognition.processor import SuryaOCRProcessor
+    from surya_amd.recognition.tokenizer import ByteMathTokenizer, OCRTokenizer
+    tok = OCRTokenizer(None, ByteMathTokenizer(256), reserve_special=64)
+    proc = SuryaOCRProcessor(tok)
+    sysm = tok.system_tokens
+    specials = [v for k, v in tok.SPECIAL_TOKEN_MAPPING.items() if k not in sysm] + [sysm["<NO-MATH>"]]
+    T_MAX, bbox_size = 40, 1025
+
+    def scripted(crop):
+        rng = np.random.default_rng(int(crop.sum()) % (2 ** 31) + 7 * crop.shape[1] + crop.shape[0])
+        T = int(rng.integers(1, T_MAX))
+        toks = []
+        while len(toks) < T:
+            r = rng.random()
+            if r < 0.6:
+                for ch in rng.choice(list("abc xyzÄ漢😀"), size=int(rng.integers(1, 6))):
+                    raw = ch.encode("utf-16le")
+                    toks += [raw[i] + (raw[i + 1] << 8) + tok.special_token_offset for i in range(0, len(raw), 2)]
+            elif r < 0.8:
+                toks.append(int(rng.choice(specials)))
+            elif r < 0.95:
+                toks += [int(x) for x in rng.integers(32, 127, size=int(rng.integers(1, 5)))]
+            else:
+                toks.append(int(proc.eos_token_id))
+        toks = toks[:T]
+        rows = np.sort(rng.integers(0, bbox_size, size=(T, 6)), axis=0).astype(np.float32)
+        return toks, rng.random(T).astype(np.float32).tolist(), rows
+
+    class RefCall:
+        __call__ = R.__call__
+        slice_bboxes = R.slice_bboxes
+        get_bboxes_text = R.get_bboxes_text
+        tasks = R.tasks
+
+        def __init__(self):
+            self.processor = proc
+            self.model = SimpleNamespace(config=SimpleNamespace(bbox_size=bbox_size))
+
+        def prediction_loop(self, flat, recognition_batch_size=None, math_mode=True):
+            n = len(flat["slices"])
+            boxes = torch.zeros(n, T_MAX, 6)
+            toks, scores = [], []
+            for k, crop in enumerate(flat["slices"]):
+                t, s, rows = scripted(crop)
+                toks.append(t); scores.append(s); boxes[k, : len(t)] = torch.from_numpy(rows)
+            return toks, boxes, scores
+
+    ours = object.__new__(RecognitionPredictor)
+    ours.processor = proc
+    ours.model = SimpleNamespace(cfg=SimpleNamespace(bbox_size=bbox_size))
+    ours.device_preprocess = False
+    ours.shard_lines = False
+    ours.prepare_lines = lambda flat, math_mode=True: flat
+
+    def generate(prep, recognition_batch_size=None, on_done=None, on_flush=None):
+        n = len(prep["slices"])
+        boxes = np.zeros((n, T_MAX, 6), np.float32)
+        toks, scores = [], []
+        for k, crop in enumerate(prep["slices"]):
+            t, s, rows = scripted(crop)
+            toks.append(t); scores.append(s); boxes[k, : len(t)] = rows
+            on_done(k, t, s, boxes[k, : len(t)])
+            if k % 5 == 4:
+                on_flush()
+        return toks, torch.from_numpy(boxes), scores
+    ours.generate = generate
+
+    rng = np.random.default_rng(1)
+    pages = [Image.fromarray(rng.integers(0, 256, size=(300, 420, 3), dtype=np.uint8)) for _ in range(3)]
+    bboxes = [[[10, 10, 200, 40], [15, 60, 400, 95], [5, 120, 90, 150], [0, 0, 0, 0]],
+              [],
+              [[30, 200, 410, 260], [30, 20, 100, 50], [120, 20, 300, 52], [500, 400, 900, 800]]]
+    kw = dict(bboxes=bboxes, sort_lines=sort_lines, return_words=return_words)
+    ref_out = RefCall()(pages, **kw)
+    our_out = ours(pages, **kw)
+    assert len(ref_out) == len(our_out) == 3
+    for a, b in zip(our_out, ref_out):
+        assert a.model_dump() == b.model_dump()
