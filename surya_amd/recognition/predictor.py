@@ -36,7 +36,7 @@ from ..config import RecConfig, rec_config
 from ..settings import settings
 from .model import HipRecModel
 from .preprocess_gpu import DevicePreprocessor, LineRef, bbox_ref, page_pixels, poly_ref
-from .postprocess import (clean_close_polygons, clean_math_tags, detect_repeat_token, fix_unbalanced_tags,
+from .postprocess import (clean_math_tags, detect_repeat_token, fix_unbalanced_tags,
                           prediction_to_polygon_batch, sort_text_lines, unwrap_math, words_from_chars)
 from .processor import NOMATH_TOKEN, SuryaOCRProcessor
 from .schema import OCRResult, TaskNames, TextChar, TextLine
