@@ -134,6 +134,6 @@ def normalise_pages(pages) -> torch.Tensor:
     std = np.array([0.229, 0.224, 0.225], np.float32)
     out = []
     for p in pages:
-        a = (p.astype(np.float32) * np.float32(1 / 255.0) - mean) / std
+        a = ((p.astype(np.float64) * (1 / 255)).astype(np.float32) - mean) / std     # rescale in float64, then float32 (HF image_transforms.rescale)
         out.append(torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))))
     return torch.stack(out)

@@ -92,7 +92,11 @@ def golden_det(name: str, size: int, n: int):
     m = EfficientViTForSemanticSegmentation(rc).eval()
     sd = make_det_weights(c, 0)
     m.load_state_dict(sd, strict=True)
-    x = normalise_pages(make_pages(n, size, seed=1234))
+    pages = make_pages(n, size, seed=1234)
+    x = normalise_pages(pages)
+    from surya.detection.processor import SegformerImageProcessor            # the reference's own rescale + normalise
+    rp = SegformerImageProcessor(size={"height": size, "width": size})
+    assert all(np.array_equal(rp(pg)["pixel_values"][0], x[i].numpy()) for i, pg in enumerate(pages)), "normalise_pages != reference processor"
     with torch.inference_mode():
         out = m(pixel_values=x)
         up = F.interpolate(out.logits, size=(size, size), mode="bilinear", align_corners=False)   # detection/__init__.py:121-129

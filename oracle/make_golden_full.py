@@ -138,7 +138,11 @@ def det1024():
                             num_labels=c.num_labels)
     m = EfficientViTForSemanticSegmentation(rc).eval()
     m.load_state_dict(make_det_weights(c, 0), strict=True)
-    x = normalise_pages(make_pages(16, 1024, seed=1234)[:1])          # page 0 of bench.py's detection leg
+    pages = make_pages(16, 1024, seed=1234)[:1]                          # page 0 of bench.py's detection leg
+    x = normalise_pages(pages)
+    from surya.detection.processor import SegformerImageProcessor            # the reference's own rescale + normalise
+    rp = SegformerImageProcessor(size={"height": 1024, "width": 1024})
+    assert np.array_equal(rp(pages[0])["pixel_values"][0], x[0].numpy()), "normalise_pages != reference processor"
     with torch.inference_mode():
         t0 = time.time()
         out = m(pixel_values=x).logits

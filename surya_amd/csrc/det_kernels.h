@@ -31,11 +31,13 @@ __global__ void u8_to_nhwc_kernel(const unsigned char* __restrict__ in, T* __res
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;      // pixel index over B*H*W
     if (p >= P) return;
     const unsigned char* px = in + p * pix;                           // 3 = RGB, 4 = RGBX (PIL's in-memory layout)
-    const float k = 1.0f / 255.0f;                                    // np.float32(1 / 255.0)
+    // the reference's rescale: float64 product rounded to float32 once (transformers image_transforms.rescale), then the float32
+    // normalisation -- px * float32(1 / 255) is one ulp off for some pixel values
+    const double k = 1.0 / 255.0;
     T* o = out + p * CP;
-    Ty<T>::st(o + 0, ((float)px[0] * k - m0) / s0);
-    Ty<T>::st(o + 1, ((float)px[1] * k - m1) / s1);
-    Ty<T>::st(o + 2, ((float)px[2] * k - m2) / s2);
+    Ty<T>::st(o + 0, ((float)((double)px[0] * k) - m0) / s0);
+    Ty<T>::st(o + 1, ((float)((double)px[1] * k) - m1) / s1);
+    Ty<T>::st(o + 2, ((float)((double)px[2] * k) - m2) / s2);
     for (int c = 3; c < CP; ++c) Ty<T>::st(o + c, 0.f);
 }
 

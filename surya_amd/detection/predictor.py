@@ -25,7 +25,10 @@ from .model import DeviceResampler, HipDetModel, HipDetPost
 
 
 class SegformerImageProcessor:
-    """rescale 1/255 + ImageNet normalise -> CHW float32 (surya/detection/processor.py:126-146); `size` from the checkpoint."""
+    """rescale 1/255 + ImageNet normalise -> CHW float32 (surya/detection/processor.py:126-146); `size` from the checkpoint.
+    The reference's rescale step multiplies in float64 and rounds to float32 once (transformers' image_transforms.rescale), so the
+    scaled pixel is the correctly rounded px / 255; a float32 product px * float32(1/255) is one ulp off for some pixel values
+    (found by the live cross-check against the reference's own processor, tests/test_oracle_vs_reference.py)."""
     image_mean = np.array([0.485, 0.456, 0.406], np.float32)
     image_std = np.array([0.229, 0.224, 0.225], np.float32)
 
@@ -33,7 +36,7 @@ class SegformerImageProcessor:
         self.size = size or {"height": 512, "width": 512}
 
     def __call__(self, image: np.ndarray):
-        a = (image.astype(np.float32) * np.float32(1 / 255.0) - self.image_mean) / self.image_std
+        a = ((image.astype(np.float64) * (1 / 255)).astype(np.float32) - self.image_mean) / self.image_std
         return {"pixel_values": [np.ascontiguousarray(a.transpose(2, 0, 1))]}
 
 
@@ -315,7 +318,9 @@ class DetectionPredictor(BasePredictor):
             tiles = torch.stack([self.prepare_image(p) for p in parts], 0).contiguous()
             heat_parts = []
             for s in range(0, tiles.shape[0], self.model.max_batch):        # a single page may exceed max_batch tiles
-                chunk = tiles[s: s + self.model.max_batch].pin_memory().to(self.model.device, non_blocking=True)
+                chunk = tiles[s: s + self.model.max_batch]
+                if torch.device(self.model.device).type == "cuda":           # (a stand-in model on the CPU in the live cross-check)
+                    chunk = chunk.pin_memory().to(self.model.device, non_blocking=True)
                 heat_parts.append(self.model.forward(chunk))
             logits = torch.cat(heat_parts, 0).cpu().numpy()                 # fp32, one D2H per batch (:132)
             preds: List[List[np.ndarray]] = []

@@ -560,3 +560,64 @@ def test_live_recognition_call_against_reference_call(sort_lines, return_words):
     assert len(ref_out) == len(our_out) == 3
     for a, b in zip(our_out, ref_out):
         assert a.model_dump() == b.model_dump()
+
+
+def test_live_detection_batching_against_reference_batch_detection():
+    """the reference's own DetectionPredictor.batch_detection (detection/__init__.py:64-155: greedy packing by
+    strip count, convert, split_image, the double LANCZOS prepare_image, stacking, stitching the strips' maps back per page with the
+    last strip's padding cut) runs unmodified with a stand-in model whose "logits" are a fixed function of the pixel values; our
+    reference-layout path (DetectionPredictor.batch_detection, the checker of the device path) runs with the same stand-in. Pages of
+    mixed sizes incl. tall ones that are cut into strips, several batch sizes: identical per-page maps and sizes, batch by batch."""
+    import numpy as np
+    from types import SimpleNamespace
+    from PIL import Image
+    ref_shim.install()
+    import surya.detection as sd
+    from surya.detection.processor import SegformerImageProcessor as RefProc
+    from surya_amd.detection.predictor import DetectionPredictor, SegformerImageProcessor as OurProc
+    size = 256
+
+    def fake_logits(x):                                     # [B, 3, H, W] normalised pixels -> [B, 2, H, W]
+        x = x.float()
+        return torch.stack([x.mean(1) * 0.5 + x[:, 0] * 0.25, x[:, 2] - x[:, 1]], 1)
+
+    class RefModel:
+        dtype, device = torch.float32, torch.device("cpu")
+        config = SimpleNamespace(num_labels=2)
+        def __call__(self, pixel_values):
+            return SimpleNamespace(logits=fake_logits(pixel_values))
+
+    class RefStub:
+        batch_detection = sd.DetectionPredictor.batch_detection
+        prepare_image = sd.DetectionPredictor.prepare_image
+        disable_tqdm = True
+        def __init__(self):
+            self.model = RefModel()
+            self.processor = RefProc(size={"height": size, "width": size})
+        def get_batch_size(self):
+            return 4
+
+    ours = object.__new__(DetectionPredictor)
+    ours.processor = OurProc({"height": size, "width": size})
+    ours.model = SimpleNamespace(max_batch=64, cfg=SimpleNamespace(num_labels=2), device="cpu", forward=lambda chunk: fake_logits(chunk))
+    rng = np.random.default_rng(2)
+    from surya_amd.settings import settings as our_settings
+    from surya.settings import settings as ref_settings
+    old = (our_settings.DETECTOR_IMAGE_CHUNK_HEIGHT, ref_settings.DETECTOR_IMAGE_CHUNK_HEIGHT)
+    our_settings.DETECTOR_IMAGE_CHUNK_HEIGHT = ref_settings.DETECTOR_IMAGE_CHUNK_HEIGHT = 300
+    try:
+        shapes = [(256, 256), (200, 310), (640, 250), (90, 700), (301, 256), (1000, 120), (256, 256)]          # (h, w)
+        pages = [Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in shapes]
+        pages[3] = pages[3].convert("L")                                                                   # a non-RGB page
+        for bs in (1, 3, 4, 16):
+            ref_gen = list(RefStub().batch_detection([p.copy() for p in pages], batch_size=bs))
+            our_gen = list(ours.batch_detection([p.copy() for p in pages], batch_size=bs))
+            assert len(ref_gen) == len(our_gen)
+            for (rp, rs), (op, os_) in zip(ref_gen, our_gen):
+                assert list(rs) == list(os_) and len(rp) == len(op)
+                for a, b in zip(rp, op):
+                    assert len(a) == len(b) == 2
+                    for k in range(2):
+                        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k])
+    finally:
+        our_settings.DETECTOR_IMAGE_CHUNK_HEIGHT, ref_settings.DETECTOR_IMAGE_CHUNK_HEIGHT = old
