@@ -40,6 +40,14 @@ def install():
     return True
 
 
+def purge_bare_namespaces():
+    """Forget `surya.*` packages that tests registered as bare namespaces (to import one submodule without running the package's
+    __init__), so that the real package can be imported afterwards."""
+    for name, m in list(sys.modules.items()):
+        if name.startswith("surya.") and hasattr(m, "__path__") and getattr(m, "__spec__", None) is None:
+            del sys.modules[name]
+
+
 def import_recognition():
     """The reference's `surya.recognition` package itself (its __init__ imports `QuantizedCacheConfig` / `HQQQuantizedCache`, which
     transformers 5.x no longer has, and transformers' lazy module forgets attributes set on it by hand): placeholder classes are
@@ -63,9 +71,7 @@ def import_recognition():
                     object.__setattr__(m, n, _Missing)
         return m
 
-    for name, m in list(sys.modules.items()):         # bare namespaces registered to import submodules without their package
-        if name.startswith("surya.") and hasattr(m, "__path__") and getattr(m, "__spec__", None) is None:   # __init__ (tests)
-            del sys.modules[name]
+    purge_bare_namespaces()
     builtins.__import__ = hook
     try:
         import surya.recognition as sr

@@ -621,3 +621,67 @@ def test_live_detection_batching_against_reference_batch_detection():
                         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k])
     finally:
         our_settings.DETECTOR_IMAGE_CHUNK_HEIGHT, ref_settings.DETECTOR_IMAGE_CHUNK_HEIGHT = old
+
+
+def test_live_heatmap_to_boxes_glue_against_reference_with_stand_in_cv2():
+    """SURVEY 8(a) D8, the part that CAN be pinned without OpenCV: the reference's own detect_boxes / get_detected_boxes /
+    get_and_clean_boxes / clean_boxes / parallel_get_boxes (detection/heatmap.py:14-184, common/util.py:9-36) run unmodified with a
+    stand-in `cv2` whose five primitives are OUR restatements (4-connected labelling + statistics, rectangular dilation with the
+    centre anchor, minimum-area rectangle, clockwise boxPoints) -- so everything around those primitives is the reference's code:
+    dynamic thresholds, the area-10 filter, niter / buffer windows, the per-component maximum, the near-square rule, the start-corner
+    roll, confidence normalisation, rescale to the page, fit_to_bounds, the containment filter, the y-expansion. Against our
+    parallel_get_boxes on the same maps: identical polygons, confidences and page boxes. (The primitives themselves stay pinned to
+    hand-derived vectors, tests/test_cv2_conventions.py: OpenCV is not in this image.)"""
+    import sys
+    import numpy as np
+    from scipy import ndimage
+    ref_shim.install()
+    import cv2 as cv2_stub
+    from surya_amd.detection import heatmap as ours
+
+    def cc_with_stats(img, connectivity=4):
+        assert connectivity == 4
+        labels, count = ndimage.label(img > 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+        stats = np.zeros((count + 1, 5), np.int32)
+        for k, sl in enumerate(ndimage.find_objects(labels), start=1):
+            stats[k] = [sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start, int((labels[sl] == k).sum())]
+        return count + 1, labels.astype(np.int32), stats, None
+
+    def box_points(rect):
+        box = rect[1]
+        c = box.mean(0)
+        return box[np.argsort(np.arctan2(box[:, 1] - c[1], box[:, 0] - c[0]))].astype(np.float32)      # clockwise on screen
+
+    added = dict(CC_STAT_LEFT=0, CC_STAT_TOP=1, CC_STAT_WIDTH=2, CC_STAT_HEIGHT=3, CC_STAT_AREA=4, MORPH_RECT=0,
+                 connectedComponentsWithStats=cc_with_stats,
+                 getStructuringElement=lambda shape, ksize: np.ones((ksize[1], ksize[0]), np.uint8),
+                 dilate=lambda src, kernel: ours.dilate_rect(src, kernel.shape[0]),
+                 minAreaRect=lambda pts: ("rect", ours.min_area_rect_points(np.asarray(pts))),
+                 boxPoints=box_points)
+    for k, v in added.items():
+        setattr(cv2_stub, k, v)
+    try:
+        ref_shim.purge_bare_namespaces()
+        import surya.detection.heatmap as rh
+        rng = np.random.default_rng(4)
+        n_boxes = 0
+        for trial in range(6):
+            H, W = (96, 160) if trial % 2 else (128, 128)
+            m = ndimage.gaussian_filter(rng.random((H, W)), sigma=[1.5, 4.0][trial % 2] if trial < 4 else 1.0)
+            m = (m - m.min()) / (m.max() - m.min())
+            m = np.clip((m - 0.45) * 3.0, 0, 1).astype(np.float32)
+            if trial == 5:
+                m[:] = 0.0                                                  # blank page
+                m[10:14, 10:14] = 0.9                                       # + a 16-pixel square component
+            aff = rng.random((H, W)).astype(np.float32)
+            orig = (W * 3 + 7, H * 2 + 5) if trial % 3 else (W, H)
+            ref_res = rh.parallel_get_boxes([m.copy(), aff], orig)
+            our_res = ours.parallel_get_boxes([m.copy(), aff], orig)
+            assert [b.polygon for b in our_res.bboxes] == [b.polygon for b in ref_res.bboxes], trial
+            assert [b.confidence for b in our_res.bboxes] == [float(b.confidence) for b in ref_res.bboxes], trial
+            assert our_res.image_bbox == ref_res.image_bbox
+            n_boxes += len(ref_res.bboxes)
+        assert n_boxes > 20
+    finally:
+        for k in added:
+            delattr(cv2_stub, k)
