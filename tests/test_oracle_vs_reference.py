@@ -685,3 +685,100 @@ def test_live_heatmap_to_boxes_glue_against_reference_with_stand_in_cv2():
     finally:
         for k in added:
             delattr(cv2_stub, k)
+
+
+def test_live_crop_and_resize_glue_against_reference_with_stand_in_cv2():
+    """SURVEY 8(a) R2 / R4 / R5, the part that can be pinned without OpenCV: the reference's own slice_polys_from_image /
+    slice_and_pad_poly (input/processing.py:57-101) and prepare_input -> SuryaOCRProcessor.__call__ (scale_to_fit, the round-up to
+    multiples of 28, normalise, patchify) run unmodified with a stand-in `cv2` whose fillPoly / resize are OUR restatements of
+    those primitives -- so the crop box, pad value, validity rules, the area clamp's floor / ceil arithmetic and the tiling
+    are the reference's code. Against ours: identical crops; identical tiles, grids and prompt ids for crops far below the minimum
+    area, far above the task's maximum, and with sides that are no multiple of 28."""
+    import numpy as np
+    from types import SimpleNamespace
+    ref_shim.install()
+    import cv2 as cv2_stub
+    from surya_amd.common import imageops
+    from surya_amd.recognition import predictor as op
+
+    def fill_poly(mask, polys, value):
+        for pts in polys:
+            mask[imageops.fill_poly_mask(mask.shape[0], mask.shape[1], np.asarray(pts)) > 0] = value
+        return mask
+
+    added = dict(INTER_LANCZOS4=4, INTER_CUBIC=2, ROTATE_90_COUNTERCLOCKWISE=2, fillPoly=fill_poly,
+                 resize=lambda img, size, interpolation=None: imageops.resize(img, size[0], size[1], "lanczos4" if interpolation == 4 else "cubic"))
+    for k, v in added.items():
+        setattr(cv2_stub, k, v)
+    try:
+        ref_shim.purge_bare_namespaces()
+        sr = ref_shim.import_recognition()
+        import surya.input.processing as rip
+        import surya.common.surya.processor as rp
+        from surya_amd.recognition.processor import SuryaOCRProcessor
+        from surya_amd.recognition.tokenizer import ByteMathTokenizer, OCRTokenizer
+        rng = np.random.default_rng(9)
+        page = rng.integers(0, 256, size=(200, 300, 3)).astype(np.float32)
+        polys = [[[10, 20], [120, 22], [118, 60], [12, 58]], [[50, 100], [200, 90], [120, 150]], [[5, 5], [40, 5], [40, 30], [5, 30]],
+                 [[100, 100], [100, 100], [100, 100], [100, 100]], [[250, 150], [299, 160], [290, 199], [240, 190]], [[30, 70], [90, 70]]]
+        for a, b in zip(op.slice_polys_from_image(page, polys), rip.slice_polys_from_image(page, polys)):
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+        tok = OCRTokenizer(None, ByteMathTokenizer(256), reserve_special=64)
+        ours = SuryaOCRProcessor(tok)
+        ref = rp.SuryaOCRProcessor(ocr_tokenizer=tok, blank_bbox_token_id=1025, num_register_tokens=4, patch_size=14, merge_size=2,
+                                   model_device="cpu")
+
+        # detect_and_slice_bboxes (:138-198): detector polygons -> crops, with and without a high-resolution copy of the page
+        from PIL import Image
+        from surya.common.polygon import PolygonBox as RefBox
+        from surya_amd.common.geometry import PolygonBox as OurBox
+        pages = [Image.fromarray(rng.integers(0, 256, size=(200, 300, 3), dtype=np.uint8)) for _ in range(3)]
+        highres = [None, pages[1].resize((750, 450)), None]
+        det_polys = [[[[10, 20], [120, 22], [118, 60], [12, 58]], [[50, 100], [200, 90], [210, 140], [60, 150]]], [],
+                     [[[5, 5], [40, 5], [40, 30], [5, 30]]]]
+        det_polys[1] = [[[30, 40], [250, 44], [248, 90], [28, 86]]]
+
+        def fake_det(box_cls):
+            def det(images, batch_size=None):
+                out = []
+                for polys in det_polys:
+                    boxes = [box_cls(polygon=p) for p in polys]
+                    for bx in boxes:
+                        bx.rescale((1, 1), (1, 1))            # as in get_and_clean_boxes: leaves int corners (heatmap.py:131-133)
+                    out.append(SimpleNamespace(bboxes=boxes))
+                return out
+            return det
+        ref_flat = sr.RecognitionPredictor.detect_and_slice_bboxes(SimpleNamespace(processor=ref), pages, ["ocr_with_boxes"] * 3,
+                                                                   fake_det(RefBox), highres_images=highres)
+        our_pred0 = object.__new__(op.RecognitionPredictor)
+        our_pred0.processor, our_pred0.device_preprocess = ours, False
+        our_flat = our_pred0.detect_and_slice_bboxes(pages, ["ocr_with_boxes"] * 3, fake_det(OurBox), highres_images=highres)
+        assert set(ref_flat) == set(our_flat)
+        for key in ("slice_map", "polygons", "task_names", "input_text"):
+            assert ref_flat[key] == our_flat[key], key
+        assert [tuple(x) for x in ref_flat["res_scales"]] == [tuple(x) for x in our_flat["res_scales"]]
+        for x, y in zip(ref_flat["slices"], our_flat["slices"]):
+            assert x.shape == y.shape and np.array_equal(x, y)
+
+        shapes = [(9, 31), (40, 333), (64, 513), (300, 2000), (1200, 90), (57, 57), (168, 169), (27, 1100)]
+        tasks = ["ocr_with_boxes", "ocr_without_boxes", "block_without_boxes", "ocr_with_boxes", "block_without_boxes", "ocr_with_boxes",
+                 "ocr_with_boxes", "ocr_without_boxes"]
+        images = [rng.integers(0, 256, size=(h, w, 3)).astype(np.float32) for h, w in shapes]
+        texts, maths = [None] * len(shapes), [True] * len(shapes)
+        our_pred = object.__new__(op.RecognitionPredictor)
+        our_pred.processor = ours
+        ref_self = SimpleNamespace(processor=ref, tasks=sr.RecognitionPredictor.tasks)
+        rb = sr.RecognitionPredictor.prepare_input(ref_self, tasks, images, texts, maths)
+        ob = our_pred.prepare_input(tasks, images, texts, maths)
+        for x, y in zip(rb, ob):
+            assert x["inputs"][0]["image"].shape == y["inputs"][0]["image"].shape
+            assert np.array_equal(x["inputs"][0]["image"], y["inputs"][0]["image"])
+        r, o = ref(rb, padding_side="left"), ours(ob)
+        assert np.array_equal(r["grid_thw"].numpy()[:, 1:], o["grid_hw"])
+        assert np.array_equal(r["image_tiles"].numpy(), o["image_tiles"])
+        for i, seq in enumerate(o["input_ids"]):
+            assert r["input_ids"][i][r["attention_mask"][i]].tolist() == list(seq), i
+    finally:
+        for k in added:
+            delattr(cv2_stub, k)
