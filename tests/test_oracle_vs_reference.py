@@ -782,3 +782,48 @@ def test_live_crop_and_resize_glue_against_reference_with_stand_in_cv2():
     finally:
         for k in added:
             delattr(cv2_stub, k)
+
+
+def test_live_device_path_geometry_against_reference_shapes():
+    """The host integers of the DEVICE pre-processing path (recognition/preprocess_gpu.py: LineRef rectangles and fit_sizes, which
+    size the kernels' work) against the shapes the reference's own functions produce: slice_bboxes_from_image / slice_and_pad_poly
+    crop shapes for random boxes and quadrilaterals (incl. out-of-page and degenerate ones), and scale_to_fit -> _process_and_tile
+    sizes for random crop sizes under every task's bounds (cv2.resize stood in by an allocator of the requested size: only the
+    size arithmetic is under test)."""
+    import numpy as np
+    ref_shim.install()
+    import cv2 as cv2_stub
+    from surya_amd.recognition.preprocess_gpu import bbox_ref, poly_ref, fit_sizes
+    added = dict(INTER_LANCZOS4=4, INTER_CUBIC=2, fillPoly=lambda mask, polys, value: mask,
+                 resize=lambda img, size, interpolation=None: np.zeros((size[1], size[0], 3), np.float32))
+    for k, v in added.items():
+        setattr(cv2_stub, k, v)
+    try:
+        ref_shim.purge_bare_namespaces()
+        sr = ref_shim.import_recognition()
+        import surya.input.processing as rip
+        import surya.common.surya.processor as rp
+        rng = np.random.default_rng(21)
+        H, W = 180, 260
+        page = np.zeros((H, W, 3), np.float32)
+        for _ in range(400):
+            b = [int(v) for v in rng.integers(-20, 300, size=4)]
+            assert bbox_ref(0, W, H, b).shape == rip.slice_bboxes_from_image(page, [b])[0].shape, b
+        for _ in range(400):
+            pts = [[int(rng.integers(0, W + 30)), int(rng.integers(0, H + 30))] for _ in range(4)]
+            assert poly_ref(0, W, H, pts).shape == rip.slice_and_pad_poly(page, pts).shape, pts
+        proc = object.__new__(rp.SuryaOCRProcessor)
+        proc.patch_size, proc.merge_size = 14, 2
+        proc.rescale_factor = rp.SuryaOCRProcessor.rescale_factor
+        proc.image_mean = np.array(rp.SuryaOCRProcessor.image_mean, np.float32)
+        proc.image_std = np.array(rp.SuryaOCRProcessor.image_std, np.float32)
+        for task, spec in sr.RecognitionPredictor.tasks.items():
+            for _ in range(150):
+                h, w = int(rng.integers(1, 1500)), int(rng.integers(1, 2500))
+                mid = rp.SuryaOCRProcessor.scale_to_fit(np.zeros((h, w, 3), np.float32), spec["img_size"])
+                _, (t, gh, gw) = proc._process_and_tile(mid)
+                (mh, mw), (oh, ow) = fit_sizes(h, w, spec["img_size"])
+                assert (mh, mw) == mid.shape[:2] and (oh, ow) == (gh * 14, gw * 14) and t == 1, (task, h, w)
+    finally:
+        for k in added:
+            delattr(cv2_stub, k)
