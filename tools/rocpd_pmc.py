@@ -2,6 +2,7 @@
 """Per-kernel means of the PMC counter(s) in a rocprofv3 rocpd database (one `--pmc` pass = one database).
 
     python tools/rocpd_pmc.py gpurun_out/r01d_fetch.db [gpurun_out/r01d_write.db ...] > profiles/r01_d_hbm_traffic.md
+    python tools/rocpd_pmc.py --raw some_sq_counters.db          (any counters: mean raw value per kernel, tools/profile_decode_pmc.sh)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch. On gfx950 FETCH_SIZE counts 128-byte requests
 as 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section): the `x2` column applies that correction.
@@ -72,8 +73,16 @@ def det_json(rows):
 def main(paths):
     js = "--json" in paths
     dj = "--det-json" in paths
-    paths = [p for p in paths if p not in ("--json", "--det-json")]
+    raw = "--raw" in paths
+    paths = [p for p in paths if p not in ("--json", "--det-json", "--raw")]
     rows = [r for p in paths for r in load(p)]
+    if raw:                     # any counter, no unit interpretation: mean value per dispatch (summed over the counter's instances)
+        rows.sort(key=lambda r: (-r[5] * r[2], r[0], r[1]))
+        print("| kernel | counter | dispatches | mean value / dispatch | mean us (under PMC) |")
+        print("|---|---|---|---|---|")
+        for name, ctr, n, mean, tot, dur in rows:
+            print(f"| `{short(name)}` | {ctr} | {n} | {mean:.1f} | {dur / 1e3:.2f} |")
+        return
     if dj:
         return det_json(rows)
     if js:
