@@ -157,3 +157,36 @@ def test_det_default_1024_oracle_matches_reference():
     assert torch.equal(out, g["logits"])
     up = do.heatmaps(sd, cfg, x)
     assert torch.equal(up[:, :, ::4, ::4], g["upsampled_sample"])
+
+
+def test_host_assembly_and_tokenizer_match_reference_vectors():
+    """tests/golden/host_reference.json (oracle/make_golden_host.py: the REAL reference's get_bboxes_text + __call__ tail and
+    InnerOCRTokenizer, recorded in the build container) against our batched output assembly and tokenizer -- the travelling form
+    of the live cross-checks in tests/test_oracle_vs_reference.py: runs wherever the repo goes."""
+    import json
+    import math
+    import numpy as np
+    from surya_amd.recognition.predictor import RecognitionPredictor
+    from surya_amd.recognition.processor import SuryaOCRProcessor
+    from surya_amd.recognition.tokenizer import ByteMathTokenizer, OCRTokenizer, DEFAULT_SPECIAL_TOKENS
+    with open(os.path.join(GOLD, "host_reference.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    a = g["assembly"]
+    tok = OCRTokenizer(None, ByteMathTokenizer(a["tokenizer"]["math_size"]), reserve_special=a["tokenizer"]["reserve_special"])
+    pred = object.__new__(RecognitionPredictor)
+    pred.processor = SuryaOCRProcessor(tok)
+    for words in (False, True):
+        idx = [i for i, ln in enumerate(a["lines"]) if ln["return_words"] == words]
+        flat = {"polygons": [a["lines"][i]["polygon"] for i in idx], "res_scales": [tuple(a["lines"][i]["res_scale"]) for i in idx],
+                "slices": [np.zeros(a["lines"][i]["slice_shape"], np.uint8) for i in idx]}
+        items = [(k, k, a["lines"][i]["tokens"], a["lines"][i]["scores"], np.asarray(a["lines"][i]["rows"], np.float32))
+                 for k, i in enumerate(idx)]
+        got = pred._assemble_batch(flat, items, False, words, a["bbox_size"])
+        for k, i in enumerate(idx):
+            assert json.loads(json.dumps(got[k].model_dump())) == a["lines"][i]["expected"], i
+    t = g["tokenizer"]
+    ours = OCRTokenizer(DEFAULT_SPECIAL_TOKENS, ByteMathTokenizer(t["math_size"]))
+    for e in t["encode"]:
+        assert ours._tokenize_ocr(e["text"]) == e["ids"], e["text"]
+    for d in t["decode"]:
+        assert ours._decode_ocr(d["ids"]) == d["text"], d["ids"]
