@@ -722,7 +722,7 @@ class RecognitionPredictor(BasePredictor):
         result as `_assemble_line` per item (tests/test_assemble_cpu.py compares the two), but the numpy work -- box tokens ->
         polygons, close-box filter, per-char rescale / shift / clamp -- is done ONCE for the whole batch instead of ~25 small
         array calls per line, and TextLine is built from values that are already in validated form. Python walks only the token
-        runs (`_line_runs`) and creates the character objects. ~430 -> ~130 us per 45-character line (tools/hostbench)."""
+        runs (`_line_runs`) and creates the character objects. ~430 -> 80-90 us per 45-character line (tools/hostbench/assemble_cost.py)."""
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
         out: List[Optional[TextLine]] = [None] * len(items)
         work, t_max = [], 0
