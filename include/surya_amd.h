@@ -203,6 +203,25 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream);
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,
                      void* stream);
+/* Attention kernels by themselves (tests against fp32 PyTorch SDPA; synchronous -- the call returns after the kernel ran).
+ * surya_op_attn: segment attention = the vision encoder's window / whole-image attention (non-causal varlen,
+ * surya/common/surya/encoder/__init__.py:238-261) and the decoder prefill's causal GQA (decoder/__init__.py:101-128).
+ * dtype bf16 runs attn_mfma_kernel<head_dim>, fp32 runs attn_valu_kernel (reference mode). Segment s has seg_len[s] queries
+ * and keys; its first query / key / value / output row starts at element offset q_off / k_off / v_off / o_off[s] (host
+ * arrays) of q / k / v / out (device), rows `*_row` elements apart, heads `*_head` elements apart; query head h reads kv
+ * head h / group. head_dim in {32, 64, 80, 128}.
+ * surya_op_decode_attn: one decode step's attention launch exactly as RecModel::decode_layer issues it: row r = active slot
+ * active_slots[r] with row_len[r] cached tokens; q|k|v of the new token = sum of n_slabs fp32 split-K slabs
+ * qkv_part[slab][rows][(heads + 2 kv_heads) * head_dim] + qkv_bias, rounded to the storage dtype; RoPE from the (cos, sin) table
+ * rope_cs[max_kv_len][head_dim / 2][2]; k, v appended to the caches [slot][kv_head][max_kv_len][head_dim] at row_len[r];
+ * out[r][heads * head_dim] = attention over row_len[r] + 1 keys (decoder/__init__.py:193-234). bf16 runs
+ * decode_attn_flash_kernel, fp32 decode_attn_mfma_kernel. All pointers device. Enqueue only. */
+int surya_op_attn(int dtype, int head_dim, const void* q, const void* k, const void* v, void* out, const int32_t* seg_len,
+                  const int64_t* q_off, const int64_t* k_off, const int64_t* v_off, const int64_t* o_off, int n_seg, int heads, int group,
+                  int causal, float scale, long q_row, long q_head, long k_row, long k_head, long o_row, long o_head, void* stream);
+int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_slabs, const void* qkv_bias, void* out, void* kcache,
+                         void* vcache, const int32_t* active_slots, const int32_t* row_len, const float* rope_cs, int rows, int heads,
+                         int kv_heads, int max_kv_len, float scale, void* stream);
 /* MXFP8 ops (csrc/gemm_mx.h). quantize: fp32 rows [rows][K], K % 128 == 0 -> e4m3 [rows][K] + e8m0 scales K-tile-major
  * [K / 128][rows][4], with the rule every producer kernel uses (block scale = smallest power of two that keeps absmax <=
  * 448, round to nearest even). gemm_mx: C[M,N] fp32 = X W^T from MXFP8 operands (scales K-tile-major with M resp. N rows),

@@ -1,6 +1,6 @@
 """Generate the BASELINE-configuration fixtures from the REAL reference modules (build container only; takes minutes).
 
-    python oracle/make_golden_full.py [rec8] [rec256] [small256] [det1024]
+    python oracle/make_golden_full.py [rec8] [rec256] [small256] [det1024] [rec8c] [rec256c]
 
 Like oracle/make_golden.py this imports VikParuchuri/surya @ v0.14.6 from /root/reference through oracle/ref_shim and
 loads the seeded synthetic weights into the reference's own nn.Modules. What it records is the bench's own workload:
@@ -11,6 +11,9 @@ loads the seeded synthetic weights into the reference's own nn.Modules. What it 
                         rounding model the bf16 HIP path is held to)
   rec_full_bench256.pt  REC-FULL, all 256 bench crops in one left-padded batch: prefill + 3 decode steps (M = 256 tiles,
                         split-K with 4 M-tiles, the 128x128 fused-argmax lm_head) -- tokens, bbox ints, top-8 logits
+  rec_full_cond8.pt     the same 8 crops x 48 tokens on the CONDITIONED weight set (rec8c): a model whose bf16 run is a small
+                        perturbation of its fp32 run, + the reference's own free-running bf16 stream
+  rec_full_cond256.pt   all 256 crops, conditioned weights, prefill + 3 steps, with the reference's bf16 deviation (rec256c)
   rec_small_256.pt      REC-SMALL, 256 ragged synthetic prompts, 12 steps (same tile paths, deeper)
   det_default_1024.pt   DET-DEFAULT, one synthetic 1024^2 page: the module's [1, 2, 256, 256] output, the x4 upsample
                         subsampled, and the reference's own bf16-vs-fp32 deviation
@@ -95,6 +98,52 @@ def rec8():
     torch.save(g, os.path.join(GOLD, "rec_full_bench8.pt"))
 
 
+def rec8c():
+    """The same 8 bench crops on the CONDITIONED weight set (surya_amd.synth.make_rec_weights_conditioned): the reference's own
+    bf16 run stays within ~1-2 % of max|logit| of its fp32 run there, so the bf16 HIP path can be held to a tolerance that a wrong
+    kernel fails, and to an argmax check that covers most positions. Also records the reference's OWN free-running bf16 greedy
+    stream: how far bf16 token agreement can be expected to go at all."""
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0, recipe="conditioned")
+    tiles, grids, seqs = bench_line_inputs(cfg, 256, seed=1234, pick=BENCH8)
+    ref = build_reference_rec(cfg, sd, "eager")
+    t0 = time.time()
+    lg, bb, tk = run_reference(ref, cfg, tiles, grids, seqs, 48)
+    print(f"rec8c fp32 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "REC-FULL", "recipe": "conditioned", "attn": "eager", "lines": 256, "line_seed": 1234, "pick": BENCH8, "grids": grids,
+         "tiles_sum": float(tiles.double().sum()), **pack(cfg, lg, bb, tk, 32)}
+    t0 = time.time()
+    refb = ref.bfloat16()
+    lgb, _, _ = run_reference(refb, cfg, tiles, grids, seqs, 48, forced=tk)
+    g["bf16_dev"] = (lgb - lg).abs().amax(-1)
+    g["bf16_dev_top"] = (torch.gather(lgb, -1, g["logits_top"]["indices"]) - g["logits_top"]["values"]).abs().amax(-1)
+    _, _, tkb = run_reference(refb, cfg, tiles, grids, seqs, 48)
+    g["bf16_free_tokens"] = tkb                                  # [steps, B]
+    print(f"rec8c bf16 reference (teacher forced + free running): {time.time() - t0:.1f}s", flush=True)
+    same = (tkb == tk).all(0)
+    print(f"rec8c: reference bf16 free-running == fp32 on {int(same.sum())}/{len(same)} lines; bf16 dev / max = "
+          f"{float((g['bf16_dev'].amax(-1) / g['logits_absmax'].amax(-1)).max()):.4f}", flush=True)
+    torch.save(g, os.path.join(GOLD, "rec_full_cond8.pt"))
+
+
+def rec256c():
+    """All 256 bench crops, conditioned weights, prefill + 3 steps (the M = 256 launch shapes), with the reference's bf16 deviation."""
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0, recipe="conditioned")
+    tiles, grids, seqs = bench_line_inputs(cfg, 256, seed=1234)
+    ref = build_reference_rec(cfg, sd, "sdpa")
+    t0 = time.time()
+    lg, bb, tk = run_reference(ref, cfg, tiles, grids, seqs, 4)
+    print(f"rec256c fp32 reference: {time.time() - t0:.1f}s", flush=True)
+    g = {"config": "REC-FULL", "recipe": "conditioned", "attn": "sdpa", "lines": 256, "line_seed": 1234, "grids": grids,
+         "tiles_sum": float(tiles.double().sum()), **pack(cfg, lg, bb, tk, 8)}
+    t0 = time.time()
+    lgb, _, _ = run_reference(ref.bfloat16(), cfg, tiles, grids, seqs, 4, forced=tk)
+    print(f"rec256c bf16 reference: {time.time() - t0:.1f}s", flush=True)
+    g["bf16_dev"] = (lgb - lg).abs().amax(-1)
+    torch.save(g, os.path.join(GOLD, "rec_full_cond256.pt"))
+
+
 def rec256():
     cfg = rec_config("REC-FULL")
     sd = make_rec_weights(cfg, 0)
@@ -161,7 +210,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["rec8", "rec256", "small256", "det1024"]
     for w in which:
-        {"rec8": rec8, "rec256": rec256, "small256": small256, "det1024": det1024}[w]()
+        {"rec8": rec8, "rec256": rec256, "small256": small256, "det1024": det1024, "rec8c": rec8c, "rec256c": rec256c}[w]()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

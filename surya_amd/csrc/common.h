@@ -160,16 +160,19 @@ struct Tuning {
 };
 inline Tuning& tuning() { static Tuning t; return t; }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember it per device, not per process.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember, per device, the largest size
+// already granted, and raise it when a later launch of the same kernel needs more (kernels whose dynamic LDS depends on the
+// problem -- post_boxes_kernel sizes it by the page height -- would otherwise keep the first call's limit).
 struct AttrOnce {
-    unsigned long long done = 0;
+    size_t granted[64] = {};
     template <typename F> void ensure(F kern, size_t lds) {
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done & bit)) {
+        size_t& g = granted[dev & 63];
+        if (lds > g || g == 0) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            done |= bit;
+            g = lds > g ? lds : g;
+            if (g == 0) g = 1;
         }
     }
 };

@@ -1059,6 +1059,117 @@ int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, cons
     return SA_ERR_UNSUPPORTED;
 }
 
+// ---- op-level attention hooks (tests of the attention kernels against fp32 PyTorch; synchronous, not for timed code) ---------
+namespace {
+struct DevSegs {     // device copies of a host segment list for one op-level call
+    void* mem = nullptr;
+    sa::AttnSegs a{};
+    int n_tiles = 0;
+    int init(const int32_t* seg_len, const int64_t* q_off, const int64_t* k_off, const int64_t* v_off, const int64_t* o_off, int n_seg) {
+        std::vector<int> tile_seg, tile_q0;
+        for (int s = 0; s < n_seg; ++s) {
+            if (seg_len[s] <= 0) return SA_ERR_ARG;
+            for (int q0 = 0; q0 < seg_len[s]; q0 += 64) { tile_seg.push_back(s); tile_q0.push_back(q0); }
+        }
+        n_tiles = (int)tile_seg.size();
+        const size_t ib = ((size_t)(2 * n_tiles + n_seg) * sizeof(int) + 15) & ~(size_t)15, lb = (size_t)n_seg * sizeof(long);
+        std::vector<char> host(ib + 4 * lb);
+        int* hi = reinterpret_cast<int*>(host.data());
+        memcpy(hi, tile_seg.data(), n_tiles * sizeof(int));
+        memcpy(hi + n_tiles, tile_q0.data(), n_tiles * sizeof(int));
+        memcpy(hi + 2 * n_tiles, seg_len, n_seg * sizeof(int));
+        const int64_t* offs[4] = {q_off, k_off, v_off, o_off};
+        for (int i = 0; i < 4; ++i) memcpy(host.data() + ib + i * lb, offs[i], lb);
+        SA_HIP(hipMalloc(&mem, host.size()));
+        SA_HIP(hipMemcpy(mem, host.data(), host.size(), hipMemcpyHostToDevice));
+        char* d = reinterpret_cast<char*>(mem);
+        a.tile_seg = reinterpret_cast<const int*>(d); a.tile_q0 = a.tile_seg + n_tiles; a.seg_len = a.tile_seg + 2 * n_tiles;
+        a.q_off = reinterpret_cast<const long*>(d + ib); a.k_off = a.q_off + n_seg; a.v_off = a.q_off + 2 * n_seg; a.o_off = a.q_off + 3 * n_seg;
+        return SA_OK;
+    }
+    ~DevSegs() { if (mem) (void)hipFree(mem); }
+};
+}  // namespace
+
+int surya_op_attn(int dtype, int head_dim, const void* q, const void* k, const void* v, void* out, const int32_t* seg_len,
+                  const int64_t* q_off, const int64_t* k_off, const int64_t* v_off, const int64_t* o_off, int n_seg, int heads, int group,
+                  int causal, float scale, long q_row, long q_head, long k_row, long k_head, long o_row, long o_head, void* stream) {
+    if (!q || !k || !v || !out || !seg_len || !q_off || !k_off || !v_off || !o_off || n_seg <= 0 || heads <= 0 || group <= 0) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DevSegs sg;
+    int rc = sg.init(seg_len, q_off, k_off, v_off, o_off, n_seg);
+    if (rc) return rc;
+    dim3 grid(sg.n_tiles, heads);
+#define SA_OPA_M(DD) hipLaunchKernelGGL((attn_mfma_kernel<DD>), grid, dim3(128), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                                        (bf16_t*)out, sg.a, q_row, q_head, k_row, k_head, o_row, o_head, group, causal, scale)
+#define SA_OPA_V(DD) hipLaunchKernelGGL((attn_valu_kernel<float, DD>), grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v, \
+                                        (float*)out, sg.a, q_row, q_head, k_row, k_head, o_row, o_head, group, causal, scale)
+    if (dtype == SA_DTYPE_BF16) {
+        switch (head_dim) {
+            case 32: SA_OPA_M(32); break;
+            case 64: SA_OPA_M(64); break;
+            case 80: SA_OPA_M(80); break;
+            case 128: SA_OPA_M(128); break;
+            default: return SA_ERR_UNSUPPORTED;
+        }
+    } else if (dtype == SA_DTYPE_F32) {
+        switch (head_dim) {
+            case 32: SA_OPA_V(32); break;
+            case 64: SA_OPA_V(64); break;
+            case 80: SA_OPA_V(80); break;
+            case 128: SA_OPA_V(128); break;
+            default: return SA_ERR_UNSUPPORTED;
+        }
+    } else {
+        return SA_ERR_UNSUPPORTED;
+    }
+#undef SA_OPA_M
+#undef SA_OPA_V
+    SA_HIP(hipGetLastError());
+    SA_HIP(hipStreamSynchronize(s));          // the segment tables above are freed on return
+    return SA_OK;
+}
+
+int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_slabs, const void* qkv_bias, void* out, void* kcache,
+                         void* vcache, const int32_t* active_slots, const int32_t* row_len, const float* rope_cs, int rows, int heads,
+                         int kv_heads, int max_kv_len, float scale, void* stream) {
+    if (!qkv_part || !qkv_bias || !out || !kcache || !vcache || !active_slots || !row_len || !rope_cs) return SA_ERR_ARG;
+    if (rows <= 0 || n_slabs < 1 || n_slabs > 8 || kv_heads <= 0 || heads % kv_heads) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = heads / kv_heads, d = head_dim;
+    dim3 grid(rows, kv_heads), block(256);
+    const float2* cs = reinterpret_cast<const float2*>(rope_cs);
+#define SA_OPD(KERN, LDS, TT, ...)                                                                                              \
+    {                                                                                                                           \
+        auto kern = KERN;                                                                                                       \
+        static AttrOnce attr;                                                                                                   \
+        attr.ensure(kern, LDS);                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, qkv_part, n_slabs, (const TT*)qkv_bias, (TT*)out, (TT*)kcache, (TT*)vcache, \
+                           active_slots, row_len, cs, heads, kv_heads, max_kv_len, scale, ##__VA_ARGS__);                       \
+    }
+#define SA_OPD_FLASH(DD, GG) SA_OPD((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+#define SA_OPD_MFMA(DD, GG) SA_OPD((decode_attn_mfma_kernel<float, DD, GG>), (decode_attn_mfma_lds<float, DD, GG>()), float)
+    if (dtype == SA_DTYPE_BF16) {          // the dispatch of RecModel::decode_layer
+        if (d == 128 && G <= 5) SA_OPD_FLASH(128, 5)
+        else if (d == 128 && G <= 8) SA_OPD_FLASH(128, 8)
+        else if (d == 64 && G <= 8) SA_OPD_FLASH(64, 8)
+        else if (d == 32 && G <= 8) SA_OPD_FLASH(32, 8)
+        else return SA_ERR_UNSUPPORTED;
+    } else if (dtype == SA_DTYPE_F32) {
+        if (d == 128 && G <= 5) SA_OPD_MFMA(128, 5)
+        else if (d == 128 && G <= 8) SA_OPD_MFMA(128, 8)
+        else if (d == 64 && G <= 8) SA_OPD_MFMA(64, 8)
+        else if (d == 32 && G <= 8) SA_OPD_MFMA(32, 8)
+        else return SA_ERR_UNSUPPORTED;
+    } else {
+        return SA_ERR_UNSUPPORTED;
+    }
+#undef SA_OPD_FLASH
+#undef SA_OPD_MFMA
+#undef SA_OPD
+    return (int)hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void mx_quantize_rows_kernel(const float* __restrict__ x, int K, uint8_t* __restrict__ q,
                                                                uint8_t* __restrict__ sc) {
     const long row = blockIdx.x, rows = gridDim.x;

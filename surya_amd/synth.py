@@ -21,8 +21,12 @@ def _normal(gen, shape, std):
     return torch.randn(shape, generator=gen, dtype=torch.float32) * std
 
 
-def make_rec_weights(cfg: RecConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """fp32 CPU state dict for SuryaModel (surya/common/surya/__init__.py:71-109 lists the sub-modules)."""
+def make_rec_weights(cfg: RecConfig, seed: int = 0, recipe: str = "default") -> Dict[str, torch.Tensor]:
+    """fp32 CPU state dict for SuryaModel (surya/common/surya/__init__.py:71-109 lists the sub-modules).
+    recipe "conditioned": see make_rec_weights_conditioned."""
+    if recipe == "conditioned":
+        return make_rec_weights_conditioned(cfg, seed)
+    assert recipe == "default", recipe
     g = torch.Generator().manual_seed(seed)
     e, d = cfg.encoder, cfg.decoder
     sd: Dict[str, torch.Tensor] = {}
@@ -72,6 +76,76 @@ def make_rec_weights(cfg: RecConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
     # untied, separately seeded head: with a tied random embedding the model only repeats its input
     sd["lm_head.weight"] = _normal(g, (d.vocab_size, Hd), 0.2)
     sd["lm_head.bias"] = _normal(g, (d.vocab_size,), 0.6)
+    return sd
+
+
+def make_rec_weights_conditioned(cfg: RecConfig, seed: int = 0, embed_rms: float = 2.0, q_gain: float = 0.35, beta: float = 10.0, r_gain: float = 8.0,
+                                 top_logit: float = 16.0) -> Dict[str, torch.Tensor]:
+    """A second seeded weight set on which reduced precision is a small perturbation, for parity tests of the bf16 path that can fail.
+
+    The default recipe (gain 1.7 in every linear layer, residual branches as loud as the stream they add to, attention logits of
+    std ~3) amplifies every rounding: the REFERENCE's own bf16 run sits 12-21 % of max|logit| away from its fp32 run and no argmax
+    survives a tolerance built on that. Here
+      * every residual-branch output projection (encoder attn.proj / mlp.down_proj, decoder o_proj / down_proj) is scaled by
+        1 / sqrt(2 L) (L = depth of its stack), the query projections by `q_gain` (attention logits of std ~1 instead of ~3) and the
+        token embedding has rms `embed_rms`, so the residual stream is a sum of comparable, non-amplifying contributions;
+      * the (untied) lm_head is built so that a greedy step is CONFIDENT and still depends on what the network computed: with e_t the
+        unit direction of the current token's embedding and r one fixed random unit direction,
+            row[pi_plus(t)] += a e_t + b r,      row[pi_minus(t)] += a e_t - b r            (b = beta a)
+        (pi_plus / pi_minus: seeded maps of the tokens that can occur into the even / odd half of the printable UTF-16 range), every
+        other row is near zero. The current token's two rows win by a e_t . h; which of the two wins is the sign of r . h -- a
+        function of the image, the attention and every layer. Top-2 margin = min(2 b |r . h|, ~a e_t . h): large except where
+        r . h ~ 0.
+    Nothing maps to </S> or <PAD>, so every line runs to its token limit."""
+    sd = make_rec_weights(cfg, seed + 1000)
+    e, d = cfg.encoder, cfg.decoder
+    g = torch.Generator().manual_seed(seed + 2000)
+    se, sdec = 1.0 / math.sqrt(2 * e.depth), 1.0 / math.sqrt(2 * d.num_hidden_layers)
+    for i in range(e.depth):
+        p = f"vision_encoder.blocks.{i}."
+        for nm in ("attn.proj", "mlp.down_proj"):
+            sd[p + nm + ".weight"] *= se
+            sd[p + nm + ".bias"] *= se
+        sd[p + "attn.qkv.weight"][: e.hidden_size] *= q_gain
+        sd[p + "attn.qkv.bias"][: e.hidden_size] *= q_gain
+    for i in range(d.num_hidden_layers):
+        p = f"decoder.layers.{i}."
+        sd[p + "self_attn.o_proj.weight"] *= sdec
+        sd[p + "mlp.down_proj.weight"] *= sdec
+        sd[p + "self_attn.q_proj.weight"] *= q_gain
+        sd[p + "self_attn.q_proj.bias"] *= q_gain
+    V, Hd = d.vocab_size, d.hidden_size
+    r = _normal(g, (Hd,), 1.0)
+    r = r / r.norm()
+    for i in range(d.num_hidden_layers):     # the MLPs write nothing along r either: only attention (what a step READS from the image
+        w = sd[f"decoder.layers.{i}.mlp.down_proj.weight"]          # and the earlier tokens) decides the sign of r . h
+        w -= r[:, None] * (r @ w)[None, :]
+        w = sd[f"decoder.layers.{i}.self_attn.o_proj.weight"]       # ... and attention writes along r with gain r_gain, so that
+        w += (r_gain - 1.0) * r[:, None] * (r @ w)[None, :]         # r . h is O(1), far above the rounding noise of the stream
+    emb = _normal(g, (V, Hd), embed_rms)
+    emb -= (emb @ r)[:, None] * r            # embeddings carry nothing along r: r . h comes from the attention / MLP branches only
+    sd["embedder.token_embed.weight"] = emb
+    ehat = emb / emb.norm(dim=1, keepdim=True)
+    off = cfg.special_token_offset
+    lo, hi = off + 0x20, min(off + 0xD800, V)                   # printable BMP units below the surrogates
+    if hi - lo < 64:                                            # tiny vocabularies (REC-TINY): whatever UTF-16 units exist
+        lo, hi = off, V
+    live = torch.arange(lo, hi)
+    plus, minus = live[0::2], live[1::2]
+    # tokens that can be the CURRENT token of a step: the live ones and the tags a prompt can end with
+    dom = torch.cat([torch.arange(cfg.qwen_offset, off), live])
+    pi_p = plus[torch.randperm(len(dom), generator=g) % len(plus)]
+    pi_m = minus[torch.randperm(len(dom), generator=g) % len(minus)]
+    # the final-norm hidden state has unit rms; its projection on e_t was measured at ~0.6 sqrt(Hd) for embed_rms = 2 (REC-FULL)
+    a = top_logit / (0.6 * math.sqrt(Hd))
+    W = _normal(g, (V, Hd), 0.003)
+    W.index_add_(0, pi_p, a * ehat[dom])
+    W.index_add_(0, pi_m, a * ehat[dom])
+    W[plus] += beta * a * r
+    W[minus] -= beta * a * r
+    sd["lm_head.weight"] = W
+    sd["lm_head.bias"] = _normal(g, (V,), 0.05)
+    make_rec_weights_conditioned.aux = {"r": r, "pi_plus": pi_p, "pi_minus": pi_m, "domain": dom, "a": a}    # diagnostics only
     return sd
 
 

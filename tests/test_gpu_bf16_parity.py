@@ -1,0 +1,170 @@
+"""GPU: the TIMED dtype (bf16) against the real reference on a weight set where that comparison can fail.
+
+On the default synthetic weights the reference's own bf16 run sits 12-21 % of max|logit| away from its fp32 run, so a tolerance
+built on that deviation accepts almost anything and no argmax position survives it (round-2 verdict). The fixtures used here
+(`oracle/make_golden_full.py rec8c / rec256c`) were recorded from the reference's own `SuryaModel` on bench.py's line crops with
+`surya_amd.synth.make_rec_weights_conditioned`: residual branches scaled 1/sqrt(2L), attention logits of unit scale, and a
+confident but content-dependent lm_head. There the reference's bf16 deviation is <= 1.8 % of max|logit|, and:
+
+  * teacher-forced bf16 logits (top-32 + logsumexp) must sit within 2 x that deviation + 5e-3 x max|logit| of the reference's fp32
+    logits at every one of 48 steps;
+  * the argmax must equal the reference token wherever the reference's top-2 margin exceeds 2 x tol (a flip there would need a
+    logit error above tol) -- and that check must COVER >= 90 % of the positions (printed as checked / positions);
+  * free-running bf16 greedy decoding may leave the reference's fp32 stream only at a near-tie (margin <= 2 x tol at the first
+    difference), and most lines must not leave it at all (the reference's own bf16 run: 6 of 8 lines identical over 48 tokens);
+  * fp32 mode stays bit-exact on this weight set too.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from surya_amd.config import rec_config
+from surya_amd.synth import make_rec_weights
+from util import bench_line_inputs
+from test_gpu_baseline_parity import _free_run_fp32, _subset, _check_inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cond_sd():
+    return make_rec_weights(rec_config("REC-FULL"), 0, recipe="conditioned")
+
+
+def _model(sd, dtype, slots=256, max_kv=160):
+    from surya_amd.recognition.model import HipRecModel
+    cfg = rec_config("REC-FULL")
+    return cfg, HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                            dtype=dtype, device="cuda:0", max_slots=slots, max_kv_len=max_kv, max_patches=65536,
+                            max_prefill_tokens=slots * 72)
+
+
+@pytest.fixture(scope="module")
+def cond_bf16(hip_lib, cond_sd):
+    return _model(cond_sd, torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def cond_fp32(hip_lib, cond_sd):
+    return _model(cond_sd, torch.float32)
+
+
+@pytest.fixture(scope="module")
+def bench_inputs():
+    return bench_line_inputs(rec_config("REC-FULL"), 256, seed=1234)
+
+
+def _tols(g, dev):
+    """Per-step tolerance 2 x (reference's own bf16 deviation, worst line of the step) + 5e-3 x max|logit| of the step."""
+    scale = g["logits_absmax"].amax(-1)
+    return 2 * dev + 5e-3 * scale, scale
+
+
+def teacher_forced(m, g, tiles, grids, seqs, dev):
+    n, steps = len(seqs), g["tokens"].shape[0]
+    slots = list(range(n))
+    tol, scale = _tols(g, dev)
+    m.prefill(tiles.cuda().contiguous(), grids, seqs, slots)
+    m.set_active(slots)
+    worst, mism, checked = 0.0, 0, 0
+    for step in range(steps):
+        lg = m.last_logits().cpu()
+        idx, val = g["logits_top"]["indices"][step], g["logits_top"]["values"][step]
+        err = (torch.gather(lg, -1, idx) - val).abs().max().item()
+        lse_err = (torch.logsumexp(lg, -1) - g["logits_lse"][step]).abs().max().item()
+        worst = max(worst, max(err, lse_err) / float(scale[step]))
+        assert err <= float(tol[step]) and lse_err <= float(tol[step]), (step, err, lse_err, float(tol[step]), float(scale[step]))
+        margin = val[:, 0] - val[:, 1]
+        sure = margin > 2 * tol[step]
+        checked += int(sure.sum())
+        mism += int((lg.argmax(-1)[sure] != g["tokens"][step][sure]).sum())
+        if step + 1 < steps:
+            m.set_next_tokens(slots, g["tokens"][step].tolist())
+            m.decode(1)
+    return worst, mism, checked, n * steps
+
+
+def test_cond8_bf16_teacher_forced_logits_and_argmax(cond_bf16, bench_inputs):
+    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
+    cfg, m = cond_bf16
+    tiles, grids, seqs = _subset(bench_inputs, g["pick"])
+    _check_inputs(g, tiles, grids)
+    worst, mism, checked, positions = teacher_forced(m, g, tiles, grids, seqs, g["bf16_dev"].amax(-1))
+    ref_rel = float((g["bf16_dev"].amax(-1) / g["logits_absmax"].amax(-1)).max())
+    print(f"REC-FULL conditioned, 8 bench crops x 48 tokens, bf16 teacher-forced vs the reference's fp32 run: worst logit error "
+          f"{worst:.4f} x max (reference's own bf16 run: {ref_rel:.4f}); argmax checked at {checked}/{positions} positions, {mism} mismatches")
+    assert checked >= 0.9 * positions, (checked, positions)
+    assert mism == 0, (mism, checked)
+
+
+def test_cond8_bf16_free_running_tokens(cond_bf16, bench_inputs):
+    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
+    cfg, m = cond_bf16
+    tiles, grids, seqs = _subset(bench_inputs, g["pick"])
+    n, steps = len(seqs), g["tokens"].shape[0]
+    slots = list(range(n))
+    tol, _ = _tols(g, g["bf16_dev"].amax(-1))
+    m.prefill(tiles.cuda().contiguous(), grids, seqs, slots)
+    tok, _, _ = m.read_outputs(1)
+    got = [tok[0][slots].copy()]
+    m.set_active(slots)
+    done = 1
+    while done < steps:
+        k = min(8, steps - done)
+        m.decode(k)
+        tok, _, _ = m.read_outputs(k)
+        got += [tok[s][slots].copy() for s in range(k)]
+        done += k
+    got = np.stack(got)                                   # [steps, n]
+    ref = g["tokens"].numpy()
+    same = got == ref
+    identical, first = 0, []
+    for i in range(n):
+        if same[:, i].all():
+            identical += 1
+            first.append(-1)
+            continue
+        s = int(np.nonzero(~same[:, i])[0][0])
+        first.append(s)
+        val = g["logits_top"]["values"][s, i]
+        idx = g["logits_top"]["indices"][s, i]
+        margin = float(val[0] - val[1])
+        # the prefix is identical, so the fixture's logits of step s are the reference's for exactly this context
+        assert margin <= 2 * float(tol[s]), f"line {i} leaves the reference stream at step {s} where its top-2 margin is {margin:.3f} > 2 tol {2 * float(tol[s]):.3f}"
+        assert int(got[s, i]) == int(idx[1]), f"line {i} step {s}: token {got[s, i]} is not the reference's runner-up {int(idx[1])}"
+    ref_same = int((g["bf16_free_tokens"] == g["tokens"]).all(0).sum())
+    print(f"REC-FULL conditioned bf16 free-running: {identical}/{n} lines token-identical to the reference's fp32 stream over {steps} tokens "
+          f"(first differences at steps {first}; the reference's own bf16 run: {ref_same}/{n}); every difference is a near-tie")
+    assert identical >= n // 2, (identical, first)
+
+
+def test_cond8_fp32_bit_exact(cond_fp32, bench_inputs):
+    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
+    cfg, m = cond_fp32
+    tiles, grids, seqs = _subset(bench_inputs, g["pick"])
+    worst, flips, alive = _free_run_fp32(cfg, m, g, tiles, grids, seqs, g["tokens"].shape[0], 32)
+    print(f"REC-FULL conditioned fp32 mode: tokens bit-exact over {g['tokens'].shape[0]} steps, worst logit err {worst:.2e} x max, {flips} bbox flips")
+
+
+def test_cond256_bf16_teacher_forced(cond_bf16, bench_inputs):
+    """All 256 bench lines in one batch: the M = 256 launch shapes the bench times."""
+    g = torch.load(os.path.join(GOLD, "rec_full_cond256.pt"))
+    cfg, m = cond_bf16
+    tiles, grids, seqs = bench_inputs
+    _check_inputs(g, tiles, grids)
+    worst, mism, checked, positions = teacher_forced(m, g, tiles, grids, seqs, g["bf16_dev"].amax(-1))
+    print(f"REC-FULL conditioned, 256 bench crops x {g['tokens'].shape[0]} steps, bf16 teacher-forced: worst logit error {worst:.4f} x max; "
+          f"argmax checked at {checked}/{positions} positions, {mism} mismatches")
+    assert checked >= 0.85 * positions, (checked, positions)
+    assert mism == 0, (mism, checked)
+
+
+def test_cond256_fp32_bit_exact(cond_fp32, bench_inputs):
+    g = torch.load(os.path.join(GOLD, "rec_full_cond256.pt"))
+    cfg, m = cond_fp32
+    tiles, grids, seqs = bench_inputs
+    worst, flips, alive = _free_run_fp32(cfg, m, g, tiles, grids, seqs, g["tokens"].shape[0], 8)
+    print(f"REC-FULL conditioned fp32 mode, 256 lines: tokens bit-exact, worst logit err {worst:.2e} x max, {flips} bbox flips")

@@ -135,6 +135,27 @@ def test_rec_full_bench_lines_oracle_matches_reference():
     _check_teacher_forced(cfg, sd, _subset_rows(g, rows), tiles, grids, seqs, 4)
 
 
+def test_rec_full_conditioned_fixture_premise_and_oracle():
+    """The conditioned REC-FULL fixture (make_golden_full.py rec8c; used by tests/test_gpu_bf16_parity.py): (1) its premise -- the
+    REFERENCE's own bf16 run stays within 2 % of max|logit| of its fp32 run at every step, and the argmax check at margin > 2 tol
+    covers >= 90 % of the positions; (2) the oracle reproduces the reference on this weight set too (2 lines, prefill + 3 steps)."""
+    from util import bench_line_inputs
+    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
+    scale = g["logits_absmax"].amax(-1)
+    dev = g["bf16_dev"].amax(-1)
+    assert float((dev / scale).max()) <= 0.02
+    tol = 2 * dev + 5e-3 * scale
+    val = g["logits_top"]["values"]
+    covered = ((val[..., 0] - val[..., 1]) > 2 * tol[:, None]).float().mean().item()
+    assert covered >= 0.9, covered
+    assert int((g["bf16_free_tokens"] == g["tokens"]).all(0).sum()) >= 4        # the reference's own bf16 greedy stream mostly holds
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0, recipe="conditioned")
+    rows = [0, 7]
+    tiles, grids, seqs = bench_line_inputs(cfg, g["lines"], seed=g["line_seed"], pick=[g["pick"][r] for r in rows])
+    _check_teacher_forced(cfg, sd, _subset_rows(g, rows), tiles, grids, seqs, 4)
+
+
 def test_rec_small_256_oracle_matches_reference():
     g = torch.load(os.path.join(GOLD, "rec_small_256.pt"))
     cfg = rec_config("REC-SMALL")
