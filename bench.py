@@ -7,8 +7,10 @@
 One "step" = one pass of RecognitionPredictor's device loop (prefill + continuous-batching greedy decode until every
 line stopped) over a batch of 256 synthetic ragged line crops per GPU (BASELINE.json configs[1]): REC-FULL synthetic
 weights (no checkpoints offline), bf16, crops 64 x {128..512}, tiles already resident in HBM when the clock starts.
-Weak scaling: every rank processes its own 256 lines; no data-path collective (lines are independent) and none after it --
-the aggregate is the per-rank line count times the world size over the slowest rank's time (all_reduce MAX of the wall time).
+Weak scaling: 256 x N lines (one width-sorted list) are dealt round-robin to the N ranks, rank 0 broadcasts the weights over RCCL at
+start-up, every rank decodes its 256 lines with no collective on the per-step data path, and each step ends with ONE all_gather of
+the token / score / bbox records (surya_amd.dist) so every rank holds all results; the aggregate is all lines over the slowest rank's
+time (all_reduce MAX). `python bench.py --gpus N` spawns the N ranks itself (torch.distributed.run) when no launcher is around it.
 The "e2e" object is BASELINE.json configs[3]: 128 synthetic pages through DetectionPredictor and RecognitionPredictor
 (__call__ to __call__, PIL pages in, OCRResult out), STRONG scaling: with N > 1 every rank passes the same pages, detection
 shards pages and recognition shards lines over the ranks (surya_amd.dist: fingerprint check, one all_gather of the outputs).
@@ -167,6 +169,71 @@ def fp32_mode_parity(cfg, sd, prep, n_lines, max_tokens, oracle_toks):
             "fp32_tokens_compared": int(sum(len(t) for t in oracle_toks))}
 
 
+def conditioned_parity(cfg, prep, max_tokens):
+    """bf16 token parity where it is a meaningful bar: the CONDITIONED weight set (surya_amd.synth.make_rec_weights_conditioned), on
+    which the reference's own bf16 run is a <= 2 % perturbation of its fp32 run. The timed bf16 HIP path decodes, free-running,
+    (a) the 8 bench crops of tests/golden/rec_full_cond8.pt for 48 tokens and (b) all 256 bench crops of rec_full_cond256.pt for 4
+    steps, and is compared token by token with what the REAL reference (fp32, CPU; oracle/make_golden_full.py) produced for them.
+    A stream may leave the reference's only at a near-tie; the reference's own bf16 greedy run is the yardstick (recorded in (a))."""
+    from surya_amd.recognition.model import HipRecModel
+    from surya_amd.synth import make_rec_weights
+    gold = os.path.join(ROOT, "tests", "golden")
+    g8 = torch.load(os.path.join(gold, "rec_full_cond8.pt"))
+    g256 = torch.load(os.path.join(gold, "rec_full_cond256.pt"))
+    sd = make_rec_weights(cfg, 0, recipe="conditioned")
+    n_all = len(prep["grids"])
+    m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    dtype=torch.bfloat16, device=prep["tiles"].device, max_slots=n_all, max_kv_len=64 + max_tokens + 32,
+                    max_patches=65536, max_prefill_tokens=n_all * 72)
+    offs = prep["tile_offs"]
+
+    def free_run(rows, steps):
+        tiles = torch.cat([prep["tiles"][int(offs[i]):int(offs[i + 1])] for i in rows]).contiguous()
+        slots = list(range(len(rows)))
+        m.prefill(tiles, [prep["grids"][i] for i in rows], [prep["prompt_ids"][i] for i in rows], slots)
+        tok, _, _ = m.read_outputs(1)
+        got = [tok[0][slots].copy()]
+        m.set_active(slots)
+        done = 1
+        while done < steps:
+            k = min(8, steps - done)
+            m.decode(k)
+            tok, _, _ = m.read_outputs(k)
+            got += [tok[j][slots].copy() for j in range(k)]
+            done += k
+        return np.stack(got), float(tiles.double().sum())
+
+    out = {}
+    got, tsum = free_run(list(g8["pick"]), g8["tokens"].shape[0])
+    if abs(tsum - g8["tiles_sum"]) > 1e-6 * abs(g8["tiles_sum"]) + 1e-3:
+        return {"error": "bench tiles differ from the fixture's (tiles_sum)"}
+    ref = g8["tokens"].numpy()
+    same = got == ref
+    first = [int(np.nonzero(~same[:, i])[0][0]) if not same[:, i].all() else None for i in range(same.shape[1])]
+    dev, scale = g8["bf16_dev"].amax(-1), g8["logits_absmax"].amax(-1)
+    near_tie = True
+    for i, s_ in enumerate(first):
+        if s_ is not None:
+            val = g8["logits_top"]["values"][s_, i]
+            near_tie &= bool(float(val[0] - val[1]) <= 2 * float(2 * dev[s_] + 5e-3 * scale[s_]))
+    out["bf16_lines_compared"] = int(same.shape[1])
+    out["bf16_lines_token_identical"] = int(same.all(0).sum())
+    out["bf16_tokens_identical"] = f"{int(same.sum())}/{same.size}"
+    out["bf16_first_divergence_steps"] = first
+    out["bf16_every_divergence_is_a_near_tie"] = near_tie
+    out["reference_own_bf16_lines_token_identical"] = int((g8["bf16_free_tokens"] == g8["tokens"]).all(0).sum())
+    out["reference_own_bf16_dev_rel_max"] = round(float((dev / scale).max()), 4)
+    got, _ = free_run(list(range(n_all)), g256["tokens"].shape[0])
+    same = got == g256["tokens"].numpy()
+    out["bf16_256_lines_x_4_steps_tokens_identical"] = f"{int(same.sum())}/{same.size}"
+    out["bf16_256_lines_identical"] = int(same.all(0).sum())
+    out["note"] = ("REC-FULL, conditioned synthetic weights, bench.py's own crops: bf16 HIP free-running greedy tokens vs the REAL reference's "
+                   "fp32 tokens (fixtures recorded by oracle/make_golden_full.py rec8c / rec256c); the reference's own bf16 run is the yardstick")
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def traffic_for(kernel):
     """HBM-side bytes per launch of the bucket from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this same
     command (gfx950 read correction applied), recorded in profiles/hbm_traffic.json by tools/rocpd_pmc.py --json; None if
@@ -251,11 +318,49 @@ def bench_det(args, local_rank, world, rank, barrier):
             err = float((heat[:1].float().cpu() - ref).abs().max())
             out["parity"] = {"max_abs_heatmap_err_vs_oracle": round(err, 5), "tol": 3e-2, "ok": err <= 3e-2,
                              "note": "bf16 HIP heat maps of page 0 vs the fp32 oracle on [0, 1] maps"}
+    if out is not None and world == 1:
+        out["postprocess"] = bench_det_post(args, heat, local_rank)
     del m
     torch.cuda.empty_cache()
     if out is not None and world == 1:
         out["e2e"] = bench_det_e2e(args, cfg, sd, pages, local_rank)
     return out
+
+
+def bench_det_post(args, model_heat, local_rank):
+    """surya_det_boxes (heat map -> boxes on the device) on maps that look like text: 30 / 100 / 300 line-shaped components per page
+    (surya_amd.synth.text_like_map), and on the random-weight model's own maps (one page-sized component per page -- the degenerate
+    case round 2 timed). 16 pages per call, maps resident in HBM, boxes copied back; wall time of launch + collect."""
+    from surya_amd.detection.model import HipDetPost
+    from surya_amd.detection import heatmap as hm
+    from surya_amd.settings import settings
+    from surya_amd.synth import text_like_map
+    post = HipDetPost(f"cuda:{local_rank}")
+    tt, lt = settings.DETECTOR_TEXT_THRESHOLD, settings.DETECTOR_BLANK_THRESHOLD
+    n, size = args.det_pages, args.det_size
+    res = {}
+    cases = [("model_maps_random_weights", model_heat)]
+    for k in (30, 100, 300):
+        maps = np.stack([text_like_map(size, size, k, seed=100 * k + i) for i in range(n)])
+        cases.append((f"text_like_{k}_lines", torch.from_numpy(maps).to(f"cuda:{local_rank}").contiguous()))
+    for name, heat in cases:
+        got = post(heat, tt, lt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            got = post(heat, tt, lt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = {"pages_per_s": round(n / dt, 1), "ms_per_call": round(dt * 1e3, 3), "boxes_per_page": round(sum(len(b) for b, _ in got) / n, 1)}
+        if name != "model_maps_random_weights":          # parity of the timed case: page 0 against the host implementation
+            ref_boxes, _ = hm.detect_boxes(heat[0].cpu().numpy(), tt, lt)
+            same = len(ref_boxes) == len(got[0][0]) and all(
+                float(np.abs(b - np.asarray(rb, np.float32)).max()) <= 1e-3 for b, rb in zip(got[0][0], ref_boxes))
+            res[name]["page0_equals_host"] = bool(same)
+    res["note"] = (f"{n} maps of {size}x{size} per call, HipDetPost.__call__ wall clock (17 launches + D2H of the box arrays + collect); "
+                   "per-kernel times: profiles/")
+    return res
 
 
 def bench_det_e2e(args, cfg, sd, pages, local_rank):
@@ -313,12 +418,14 @@ def bench_det_e2e(args, cfg, sd, pages, local_rank):
 
 
 def bench_e2e(args, pred, local_rank, world, rank, barrier):
-    """BASELINE.json configs[3]: args.e2e_pages synthetic 1024^2 pages, PIL in -> results out, both predictors' __call__:
-    DetectionPredictor (split, LANCZOS resize, H2D, forward, heat map -> boxes on the device, result assembly) then
-    RecognitionPredictor on the pages' text rows (page upload as uint8, crop / resize / normalise / patchify on the device,
-    continuous-batching decode with ~22 lines per page >> slots, detokenise, polygons, OCRResult). The recogniser is fed the rows
-    that were DRAWN (synth.make_pages_with_lines): a randomly initialised detector finds ~1 box per page, which would leave the
-    recognition stage idle; both stages run on the same pages inside the timed region. N > 1: pages / lines sharded over ranks."""
+    """BASELINE.json configs[3]: args.e2e_pages synthetic 1024^2 pages, PIL in -> OCRResult out, as ONE call of
+    RecognitionPredictor(images, det_predictor=...): DetectionPredictor.__call__ (split, LANCZOS resize, H2D, forward, heat map ->
+    boxes on the device, result assembly), then the detected polygons are cut out of the pages on the device (crop / pad / resize /
+    normalise / patchify), continuous-batching decode with ~22 lines per page >> slots, detokenise, polygons, OCRResult.
+    The detector's weights are random (no checkpoints offline), so its text map would hold one page-sized blob; AFTER each forward
+    (which stays inside the timed region) plane 0 of the heat maps is overwritten with a synthetic map of the text rows that were
+    drawn on that page (synth.make_pages_with_lines), so surya_det_boxes sees ~22 line-shaped components per page and the recogniser
+    is fed by the detector's own output boxes. N > 1: pages / lines sharded over the ranks."""
     from PIL import Image
     from surya_amd.config import det_config
     from surya_amd.detection.predictor import DetectionPredictor, DetectionModelLoader
@@ -328,61 +435,82 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
         def model(self, device=None, dtype=None, max_batch=None):
             return super().model(f"cuda:{local_rank}", torch.bfloat16, max_batch=16)
 
+    pages, rows = make_pages_with_lines(args.e2e_pages, args.det_size, seed=4321)      # same pages on every rank
+    imgs = [Image.fromarray(p) for p in pages]
+    page_of = {id(im): i for i, im in enumerate(imgs)}
+    # text maps of the drawn rows, resident on the device as uint8 masks (1 MB per page)
+    masks = np.zeros((len(pages), args.det_size, args.det_size), np.uint8)
+    for i, rr in enumerate(rows):
+        for x0, y0, x1, y1 in rr:
+            masks[i, y0 + 5:y1 - 5, x0 + 3:x1 - 3] = 1
+    masks_d = torch.from_numpy(masks).to(f"cuda:{local_rank}")
+
     class Det(DetectionPredictor):
         model_loader_cls = Loader
         batch_size = 16
 
+        def batch_heatmaps(self, images, batch_size=None):
+            off = 0
+            for heat, split_index, split_heights, sizes in super().batch_heatmaps(images, batch_size):
+                n = split_index[-1] + 1                                   # pages of this batch (none of them is split: 1024^2)
+                idx = torch.tensor([page_of[id(im)] for im in images[off:off + n]], device=heat.device)
+                heat[:, 0] = masks_d[idx].float() * 0.9 + 0.03
+                off += n
+                yield heat, split_index, split_heights, sizes
+
     dcfg = det_config(args.det_config)
     det = Det(checkpoint={"config": dcfg, "state_dict": make_det_weights(dcfg, 0), "size": args.det_size})
-    pages, rows = make_pages_with_lines(args.e2e_pages, args.det_size, seed=4321)      # same pages on every rank
-    imgs = [Image.fromarray(p) for p in pages]
     det.shard_pages = pred.shard_lines = world > 1
-    n_lines = sum(len(r) for r in rows)
 
     def one():
         t0 = time.perf_counter()
-        d = det(imgs)
+        o = pred(imgs, det_predictor=det)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        o = pred(imgs, bboxes=rows)
-        torch.cuda.synchronize()
-        return d, o, t1 - t0, time.perf_counter() - t1, dict(getattr(pred, "last_timing", {}))
+        return o, time.perf_counter() - t0, dict(getattr(pred, "last_timing", {}))
 
     one()                                                  # warm-up
     if args.host_profile and rank == 0:
         import cProfile, pstats
-        for name, fn in (("detect", lambda: det(imgs)), ("recognise", lambda: pred(imgs, bboxes=rows))):
-            pr = cProfile.Profile()
-            pr.enable(); fn(); torch.cuda.synchronize(); pr.disable()
-            print(f"---- e2e host profile: {name}", file=sys.stderr)
-            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
+        pr = cProfile.Profile()
+        pr.enable(); pred(imgs, det_predictor=det); torch.cuda.synchronize(); pr.disable()
+        print("---- e2e host profile", file=sys.stderr)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     passes = []
-    for _ in range(3):                                     # median of three whole passes (one pass is ~2 s of mixed host / device work)
+    for _ in range(3):                                     # median of three whole passes (one pass is ~1.5 s of mixed host / device work)
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        d, o, t_det, t_rec, phases = one()
+        o, _, phases = one()
         torch.cuda.synchronize(); barrier()
-        passes.append((time.perf_counter() - t0, t_det, t_rec, phases))
+        passes.append((time.perf_counter() - t0, phases))
     passes.sort(key=lambda x: x[0])
-    dt, t_det, t_rec, phases = passes[1]
+    dt, phases = passes[1]
+    # detection alone, for the split of the wall time (not part of the timed passes above)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d = det(imgs)
+    torch.cuda.synchronize()
+    t_det = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt, t_det, t_rec], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt, t_det], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, t_det, t_rec = (float(x) for x in t)
+        dt, t_det = (float(x) for x in t)
     det.shard_pages = pred.shard_lines = False
     if rank != 0:
         return None
-    assert len(o) == len(imgs) and sum(len(r.text_lines) for r in o) == n_lines
-    return {"metric": "end-to-end pages/s and lines/s, detect + recognise (whole node)", "pages": len(imgs), "lines": n_lines,
-            "pages_per_s": round(len(imgs) / dt, 2), "lines_per_s": round(n_lines / dt, 1), "wall_ms": round(dt * 1e3, 1),
-            "detect_ms": round(t_det * 1e3, 1), "recognise_ms": round(t_rec * 1e3, 1), "scaling": "strong",
+    n_lines = sum(len(r.text_lines) for r in o)
+    n_drawn = sum(len(r) for r in rows)
+    assert len(o) == len(imgs) and n_lines == sum(len(r.bboxes) for r in d)
+    return {"metric": "end-to-end pages/s and lines/s, detect -> crop -> recognise (whole node)", "pages": len(imgs), "lines": n_lines,
+            "lines_drawn": n_drawn, "pages_per_s": round(len(imgs) / dt, 2), "lines_per_s": round(n_lines / dt, 1), "wall_ms": round(dt * 1e3, 1),
+            "detect_ms_alone": round(t_det * 1e3, 1), "scaling": "strong",
             "wall_ms_all_passes": [round(x[0] * 1e3, 1) for x in passes],
             "recognise_phases_ms": {k: round(v, 1) for k, v in phases.items()},
             "tokens": int(sum(len(c.chars) for r in o for c in r.text_lines)),
             "detected_boxes": int(sum(len(r.bboxes) for r in d)),
-            "note": "wall clock of DetectionPredictor.__call__ + RecognitionPredictor.__call__(bboxes = the drawn rows), PIL pages in, "
-                    "OCRResult out; host pre/post-processing, H2D / D2H and continuous-batching refills included; max_tokens="
+            "note": "wall clock of ONE RecognitionPredictor.__call__(images, det_predictor=DetectionPredictor): PIL pages in, OCRResult out; "
+                    "the recogniser is fed by the detector's own boxes (heat-map plane 0 replaced by the drawn text rows after each forward, "
+                    "see docstring); host pre/post-processing, H2D / D2H and continuous-batching refills included; max_tokens="
                     f"{args.max_tokens}"}
 
 
@@ -450,8 +578,25 @@ def bench_texify(args, cfg, sd, local_rank):
     return out
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: re-run this command under torch.distributed.run, one rank per GPU
+    (the driver's own form of the N > 1 launch), on a free local port. Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -483,7 +628,11 @@ def main():
     settings.reload()
 
     cfg = rec_config(args.config)
-    sd = make_rec_weights(cfg, 0)
+    # N > 1: rank 0 builds / repacks the weights and every other rank receives the kernel-layout tensors over RCCL
+    # (surya_amd.dist.share_weights; north_star: "RCCL broadcast of weights")
+    if world > 1:
+        settings.SURYA_AMD_BROADCAST_WEIGHTS = True
+    sd = make_rec_weights(cfg, 0) if (rank == 0 or world == 1) else None
     # capacities: prompt <= 63 tokens for these crops; +16 slack for device-resident multi-step decode
     RecognitionPredictor.batch_size = args.batch
 
@@ -494,37 +643,65 @@ def main():
 
     RecognitionPredictor.model_loader_cls = Loader
     pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
-    crops = make_line_crops(args.lines, seed=1234 + rank)
-    crops.sort(key=lambda c: -c.shape[1])                       # the predictor's widest-first ordering
+    # The workload is ONE list of args.lines x world crops (seed 1234), widest first -- the predictor's own ordering -- dealt round-robin
+    # to the ranks exactly as RecognitionPredictor.sharded_prediction_loop deals them (surya_amd.dist.shard_indices): every rank
+    # gets args.lines lines of the same width mix (weak scaling). At N = 1 this is the round-2 workload unchanged.
+    from surya_amd import dist as sdist
+    n_global = args.lines * world
+    crops = make_line_crops(n_global, seed=1234)
+    crops.sort(key=lambda c: -c.shape[1])
+    mine = sdist.shard_indices(n_global, world, rank)
+    crops = [crops[i] for i in mine]
     flat = {"slices": [c.astype(np.float32) for c in crops], "input_text": [None] * len(crops),
             "task_names": [TaskNames.ocr_with_boxes] * len(crops)}
     prep = pred.prepare_lines(flat, math_mode=True)             # host pre-processing + H2D: outside the timed region
     n_patches = int(prep["tile_offs"][-1])
     torch.cuda.synchronize()
+    coll_dev = sdist.collective_device(pred.model.device) if world > 1 else None
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
+    def step():
+        """One pass of the hot path. N > 1: followed by the ONE collective of the sharded loop -- all_gather of every rank's token /
+        score / bbox records over RCCL (north_star: "all-gather of token outputs over xGMI"), so each rank ends the step holding
+        the results of all args.lines x world lines, as sharded_prediction_loop returns them."""
+        toks, boxes, scores = pred.generate(prep, args.batch)
+        if world > 1:
+            b = boxes.numpy()
+            if b.shape[1] < args.max_tokens:
+                b = np.pad(b, ((0, 0), (0, args.max_tokens - b.shape[1]), (0, 0)))
+            all_toks, _, _ = sdist.gather_line_outputs(toks, scores, b, mine, n_global, args.max_tokens, device=coll_dev)
+            assert len(all_toks) == n_global and all(len(t) for t in all_toks)
+        return toks
+
     total_tokens = 0
     for _ in range(args.warmup):
-        toks, _, _ = pred.generate(prep, args.batch)
+        toks = step()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        toks, _, _ = pred.generate(prep, args.batch)
+        toks = step()
         total_tokens += sum(len(t) for t in toks)
-    torch.cuda.synchronize(); barrier()
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0                  # this rank's own time, before it waits for the others
+    barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [round(dt_rank / args.steps * 1e3, 2)]
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tk = torch.tensor([total_tokens], device="cuda", dtype=torch.int64)
+        tk = torch.tensor([total_tokens], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(tk)
         total_tokens = int(tk.item())
+        tr = torch.tensor([dt_rank], device=coll_dev, dtype=torch.float64)
+        allr = [torch.empty_like(tr) for _ in range(world)]
+        dist.all_gather(allr, tr)
+        rank_ms = [round(float(x.item()) / args.steps * 1e3, 2) for x in allr]
 
     if args.host_profile and rank == 0:
         import cProfile, pstats
@@ -570,7 +747,10 @@ def main():
         "config": {"workload": f"RecognitionPredictor device loop, {args.lines} ragged 64x{{128..512}} crops/GPU, batch {args.batch}, "
                                f"max_tokens={args.max_tokens}, {args.config} synthetic weights (seed 0), tiles resident in HBM",
                    "patches_per_step_per_gpu": n_patches, "tokens_per_step_per_gpu": total_tokens // (args.steps * world),
-                   "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC, "parallelism": f"replica x{world}, lines sharded"},
+                   "steps_per_sync": settings.RECOGNITION_STEPS_PER_SYNC,
+                   "parallelism": (f"dp{world}: {args.lines * world} width-sorted lines dealt round-robin, one all_gather of the outputs per step, "
+                                   f"weights broadcast from rank 0 ({args.dist_backend})" if world > 1 else "1 GPU"),
+                   "rank_ms_per_step": rank_ms},
         "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None,
     }
     emit_lock = threading.Lock()
@@ -606,6 +786,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         r = leg("cpu_baseline", lambda: cpu_baseline(cfg, sd, prep, min(args.cpu_lines, args.lines), args.max_tokens, toks))
         out["cpu_baseline"], out["parity"] = r if isinstance(r, tuple) else (r, None)
+        if args.lines == 256 and args.config == "REC-FULL" and args.max_tokens == 48:
+            cp = leg("conditioned_parity", lambda: conditioned_parity(cfg, prep, args.max_tokens))
+            if isinstance(out["parity"], dict):
+                out["parity"]["conditioned_weights"] = cp
+            else:
+                out["parity"] = {"conditioned_weights": cp}
     if not args.no_det:
         out["detection"] = leg("detection", lambda: bench_det(args, local_rank, world, rank, barrier))
     if not args.no_e2e:

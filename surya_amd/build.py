@@ -33,8 +33,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # experiment knobs: extra compiler flags (-DSA_...=1) and an alternative output path, loaded through SURYA_AMD_LIB
     extra = os.environ.get("SURYA_AMD_CXXFLAGS", "").split()
     out = os.environ.get("SURYA_AMD_LIB_OUT", LIB)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-           *extra, *srcs, "-o", out + ".tmp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), *extra]
+    # one object per translation unit, compiled side by side (the two model files take ~40 s each), then one link
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    import zlib
+    tag = "%08x" % zlib.crc32((out + " ".join(extra)).encode())    # per output / flag set: A/B builds do not share objects
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + "." + tag + ".o")
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        if verbose:
+            print("[surya_amd.build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]
     if verbose:
         print("[surya_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -63,19 +63,35 @@ __global__ __launch_bounds__(128) void attn_mfma_kernel(const bf16_t* __restrict
     // h = gi >> 1; lane i of the group supplies the address of key (i >> 2), columns (i & 3) * 4 .. + 3
     const int tr_off = ((lane & 15) >> 2) * PK + ((lane >> 4) & 1) * 16 + (lane & 3) * 4 + h * 4 * PK;
 
+    // K/V chunks travel global -> registers -> LDS, one chunk AHEAD: the loads of chunk kc + KC are issued (all of them, unconditional,
+    // row index clamped) before chunk kc is multiplied and are written to LDS after it. Round 2 loaded each 16-byte piece under
+    // `if (r < nk)` right where it was stored: hipcc branched around every load and waited vmcnt(0) behind it -- 5-8 dependent
+    // round trips per chunk, all exposed (r03 ISA reading of gemm.h's epilogue; same pattern).
+    constexpr int NST = KC * CPR / 128;                    // 16-byte pieces per thread per chunk (per K and per V)
+    static_assert(KC * CPR % 128 == 0, "staging split");
+    u32x4 kreg[NST], vreg[NST];
+    auto fetch = [&](int kc) {
+        const int nk = min(KC, kend - kc);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int c = tid + it * 128, r = min(c / CPR, nk - 1), cc = c % CPR;
+            kreg[it] = *reinterpret_cast<const u32x4*>(kbase + (long)(kc + r) * k_row + cc * 8);
+            vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (long)(kc + r) * k_row + cc * 8);
+        }
+    };
+    if (kend > 0) fetch(0);
     for (int kc = 0; kc < kend; kc += KC) {
         const int nk = min(KC, kend - kc);
-        for (int c = tid; c < KC * CPR; c += 128) {
-            const int r = c / CPR, cc = c % CPR;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};      // rows past the segment are zero: 0 * garbage must not be NaN
-            if (r < nk) {
-                kv = *reinterpret_cast<const u32x4*>(kbase + (long)(kc + r) * k_row + cc * 8);
-                vv = *reinterpret_cast<const u32x4*>(vbase + (long)(kc + r) * k_row + cc * 8);
-            }
-            *reinterpret_cast<u32x4*>(ks + r * PK + cc * 8) = kv;
-            *reinterpret_cast<u32x4*>(vs + r * PK + cc * 8) = vv;
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int c = tid + it * 128, r = c / CPR, cc = c % CPR;
+            const bool in = r < nk;                          // rows past the segment are zero: 0 * garbage must not be NaN
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(ks + r * PK + cc * 8) = in ? kreg[it] : z;
+            *reinterpret_cast<u32x4*>(vs + r * PK + cc * 8) = in ? vreg[it] : z;
         }
         __syncthreads();
+        if (kc + KC < kend) fetch(kc + KC);                  // wave-uniform; in flight during the MFMAs below
 
         // scores: two 32-key blocks
         f32x16 sacc[2];

@@ -328,7 +328,10 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
         for (int sidx = 0; sidx < 8; ++sidx) val += (sidx < S) ? p8[k][sidx] : 0.f;
         if (tid + k * 256 < n_items) xrow[tid + k * 256] = Ty<T>::rnd(val);
     }
-    for (int i = tid; i < (32 - G) * D; i += 256) qT[G * D + i] = T(0);              // zero the padding heads of the q operand
+    // zero the padding heads of the q operand: whole rows, 16 bytes per store (2-byte stores here cost ~14 conflicting LDS
+    // writes per thread; r03 counters: two thirds of this kernel's LDS cycles were bank conflicts)
+    for (int i = tid; i < (32 - G) * CPR; i += 256)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(qT) + G * ROWB + i * 16) = u32x4{0u, 0u, 0u, 0u};
     SA_DA_STAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA rows of tile 0 (not tracked by the compiler)
     __syncthreads();
@@ -337,20 +340,28 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
     T* knew_dst = kc + (((long)slot * nkv + kvh) * Tmax + len) * D;
     T* vnew_dst = vc + (((long)slot * nkv + kvh) * Tmax + len) * D;
     const int new_tile = len / KT, new_row = len % KT;       // where the new token's row lives among the tiles
-    auto kput = [&](int e, float v) {
+    // q rows are stored with the K tile's chunk swizzle (chunk c of head row r at c ^ (r & XM)): the q fragment reads below take
+    // the same 16-byte chunk of 32 different rows at a 256-byte pitch -- 16-way bank conflicts on the plain layout.
+    // Two adjacent dims per thread -> 4-byte stores.
+    auto kput2 = [&](int e, float v0, float v1) {             // elements e, e + 1 of the new K row (e even)
         const int c = e / 8, w = e % 8;
-        Ty<T>::st(reinterpret_cast<T*>(Ks + new_row * ROWB + ((c ^ (new_row & XM)) << 4)) + w, v);
+        store2(reinterpret_cast<T*>(Ks + new_row * ROWB + ((c ^ (new_row & XM)) << 4)) + w, v0, v1);
     };
-    for (int it = tid; it < (G + 1) * half; it += 256) {
-        const int i = it % half, hh = it / half;
-        const float cs = csn.x, sn = csn.y;
-        const float x1 = xrow[hh * D + i], x2 = xrow[hh * D + i + half];
-        const float y1 = Ty<T>::rnd(x1 * cs - x2 * sn), y2 = Ty<T>::rnd(x2 * cs + x1 * sn);
+    auto qput2 = [&](int hh, int e, float v0, float v1) {
+        const int c = e / 8, w = e % 8;
+        store2(reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(qT) + hh * ROWB + ((c ^ (hh & XM)) << 4)) + w, v0, v1);
+    };
+    const float4 cs2 = *reinterpret_cast<const float4*>(rope_cs + (long)len * half + (tid % (half / 2)) * 2);   // (cos, sin) of dims i, i + 1
+    for (int it = tid; it < (G + 1) * (half / 2); it += 256) {
+        const int i = (it % (half / 2)) * 2, hh = it / (half / 2);          // it % (half / 2) == tid % (half / 2): 256 % (half / 2) == 0
+        const float xa1 = xrow[hh * D + i], xa2 = xrow[hh * D + i + half], xb1 = xrow[hh * D + i + 1], xb2 = xrow[hh * D + i + 1 + half];
+        const float ya1 = Ty<T>::rnd(xa1 * cs2.x - xa2 * cs2.y), ya2 = Ty<T>::rnd(xa2 * cs2.x + xa1 * cs2.y);
+        const float yb1 = Ty<T>::rnd(xb1 * cs2.z - xb2 * cs2.w), yb2 = Ty<T>::rnd(xb2 * cs2.z + xb1 * cs2.w);
         if (hh < G) {
-            Ty<T>::st(qT + hh * D + i, y1 * scale); Ty<T>::st(qT + hh * D + i + half, y2 * scale);
+            qput2(hh, i, ya1 * scale, yb1 * scale); qput2(hh, i + half, ya2 * scale, yb2 * scale);
         } else {
-            Ty<T>::st(knew_dst + i, y1); Ty<T>::st(knew_dst + i + half, y2);
-            if (new_tile == 0) { kput(i, y1); kput(i + half, y2); }
+            store2(knew_dst + i, ya1, yb1); store2(knew_dst + i + half, ya2, yb2);
+            if (new_tile == 0) { kput2(i, ya1, yb1); kput2(i + half, ya2, yb2); }
         }
     }
     for (int i = tid; i < D; i += 256) {
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
     u32x4 qf[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk)
-        qf[kk] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(qT) + hl * ROWB + ((kk * 2 + h) << 4));
+        qf[kk] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(qT) + hl * ROWB + (((kk * 2 + h) ^ (hl & XM)) << 4));
     f32x16 oacc[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -384,10 +395,11 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
             __syncthreads();
             if (new_tile == t) {                             // the new token's row falls into this tile
                 for (int i = tid; i < D; i += 256) Ty<T>::st(reinterpret_cast<T*>(Vs + new_row * ROWB) + i, xrow[(G + 1) * D + i]);
-                for (int it = tid; it < half; it += 256) {
-                    const float cs = csn.x, sn = csn.y;      // it % half == tid % half
-                    const float x1 = xrow[G * D + it], x2 = xrow[G * D + it + half];
-                    kput(it, Ty<T>::rnd(x1 * cs - x2 * sn)); kput(it + half, Ty<T>::rnd(x2 * cs + x1 * sn));
+                for (int it = tid; it < half / 2; it += 256) {
+                    const int i = it * 2;                    // it == tid here: cs2 holds dims i, i + 1
+                    const float xa1 = xrow[G * D + i], xa2 = xrow[G * D + i + half], xb1 = xrow[G * D + i + 1], xb2 = xrow[G * D + i + 1 + half];
+                    kput2(i, Ty<T>::rnd(xa1 * cs2.x - xa2 * cs2.y), Ty<T>::rnd(xb1 * cs2.z - xb2 * cs2.w));
+                    kput2(i + half, Ty<T>::rnd(xa2 * cs2.x + xa1 * cs2.y), Ty<T>::rnd(xb2 * cs2.z + xb1 * cs2.w));
                 }
                 __syncthreads();
             }

@@ -205,9 +205,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
 #undef SA_CFRAGS
 #undef SA_CMFMAS
 #undef SA_CSGB_PAIRS
+    // Epilogue. Bias (per (j, g), the same for every i) and the residual rows (per i) are fetched as BATCHES of unconditional
+    // loads with clamped addresses: loaded where they are used, under `if (p.bias)` / `if (p.res)` / `continue`, hipcc branches
+    // around every load and waits vmcnt(0) behind each -- 2 x FM x FN x 4 dependent L2 round trips per tile (gemm.h, r03 ISA).
+    const bool has_bias = p.bias != nullptr, has_res = p.res != nullptr;      // wave-uniform
+    using Raw = typename std::conditional<std::is_same<T, float>::value, float4, uint2>::type;   // 4 elements as loaded
+    Raw bias_raw[FN][4];
+    if (has_bias) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bias_raw[j][g] = *reinterpret_cast<const Raw*>(p.bias + min(n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4, p.Cout - 4));
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        Raw res_raw[FN][4];
+        if (has_res) {
+            const long mrow = (long)min(m, M - 1) * p.Cout;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    res_raw[j][g] = *reinterpret_cast<const Raw*>(p.res + mrow + min(n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4, p.Cout - 4));
+        }
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -216,9 +238,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
                 const int n = n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;
                 if (n >= p.Cout) continue;
                 float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                if (p.bias) {
+                if (has_bias) {
                     float b[4];
-                    load4(p.bias + n, b);
+                    load4(reinterpret_cast<const T*>(&bias_raw[j][g]), b);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += b[r];
                 }
@@ -229,9 +251,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                if (p.res) {
+                if (has_res) {
                     float r4[4];
-                    load4(p.res + (long)m * p.Cout + n, r4);
+                    load4(reinterpret_cast<const T*>(&res_raw[j][g]), r4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += r4[r];
                 }

@@ -435,22 +435,19 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs p) {
 
 // --------------------------------------------------------------------------------------------------------- 6. geometry
 // One wave per component. Lanes share the dilated-row sweep and the per-edge rectangle areas; the sequential parts (monotone
-// chain, the first-strictly-smaller tie rule of the calipers) run on lane 0 out of LDS.
-__global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.y, lane = threadIdx.x;
-    if (p.st[b].overflow) return;
-    __shared__ int m_sh;
-    for (int ci = blockIdx.x; ci < p.st[b].n_sel; ci += gridDim.x) {       // grid-stride over the page's components
-    __syncthreads();
-    const CompStats c = p.comp[b * p.max_boxes + ci];
+// chain, the first-strictly-smaller tie rule of the calipers) run on lane 0. The component's points / hull stack / edge areas
+// (64 bytes per dilated row) live in LDS for components of up to POST_LDS_ROWS dilated rows -- every text line -- and in a
+// per-workgroup slice of the caller's workspace for taller ones (a page-high blob on a 300-dpi scan: round 2 sized the LDS by
+// the PAGE height and refused pages of 2560 rows and more). BIG selects which of the two a launch handles.
+constexpr int POST_LDS_ROWS = 1024;
+constexpr int POST_BIG_BLOCKS = 8;                                // workgroups (scratch slices) per page of the tall-component launch
+static inline size_t post_scratch_bytes(int rows) { return (size_t)64 * rows + 64; }
+
+__device__ __forceinline__ void post_box_of(const PostArgs& p, int b, int ci, int lane, const CompStats& c, const Dil& d, int rows,
+                                            Pt* pts, Pt* stack, double* areas, int* m_sh) {
     const int* rmin = p.rmin + (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + ci];
     const int* rmax = p.rmax + (long)b * p.row_cap + p.comp_rowoff[b * p.max_boxes + ci];
-    const Dil d = dilation_of(c, p.H);
-    const int rows = d.Y1 - d.Y0 + 1, n = 2 * rows;
-    Pt* pts = reinterpret_cast<Pt*>(smem);                       // [2 rows]
-    Pt* stack = pts + n;                                         // [4 rows + 4]
-    double* areas = reinterpret_cast<double*>(stack + 2 * n + 4);   // [hull size <= 2 rows]
+    const int n = 2 * rows;
     int l = 0x7fffffff, r = -1;
     for (int k = lane; k < rows; k += 64) {
         int L, R;
@@ -462,9 +459,9 @@ __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l = min(l, __shfl_xor(l, o, 64)); r = max(r, __shfl_xor(r, o, 64)); }
     __syncthreads();
-    if (lane == 0) m_sh = hull_from_rows(pts, n, stack);
+    if (lane == 0) *m_sh = hull_from_rows(pts, n, stack);
     __syncthreads();
-    const int m = m_sh;
+    const int m = *m_sh;
     float* out = p.boxes + ((long)b * p.max_boxes + ci) * 8;
     if (m >= 3) {
         double e[6];
@@ -497,6 +494,32 @@ __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p) {
         const float mc = p.st[b].max_conf;
         p.conf[b * p.max_boxes + ci] = mc > 0.f ? c.maxv / mc : c.maxv;
     }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p, unsigned char* scratch, size_t scratch_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    if (p.st[b].overflow) return;
+    __shared__ int m_sh;
+    for (int ci = blockIdx.x; ci < p.st[b].n_sel; ci += gridDim.x) {       // grid-stride over the page's components
+        const CompStats c = p.comp[b * p.max_boxes + ci];
+        const Dil d = dilation_of(c, p.H);
+        const int rows = d.Y1 - d.Y0 + 1;
+        if ((rows > POST_LDS_ROWS) != BIG) continue;                       // wave-uniform: the other launch owns this component
+        __syncthreads();
+        if constexpr (BIG) {
+            unsigned char* base = scratch + ((size_t)b * gridDim.x + blockIdx.x) * scratch_stride;
+            Pt* pts = reinterpret_cast<Pt*>(base);                         // [2 rows]
+            Pt* stack = pts + 2 * rows;                                    // [4 rows + 4]
+            double* areas = reinterpret_cast<double*>(stack + 4 * rows + 4);   // [hull size <= 2 rows]
+            post_box_of(p, b, ci, lane, c, d, rows, pts, stack, areas, &m_sh);
+        } else {
+            Pt* pts = reinterpret_cast<Pt*>(smem);
+            Pt* stack = pts + 2 * rows;
+            double* areas = reinterpret_cast<double*>(stack + 4 * rows + 4);
+            post_box_of(p, b, ci, lane, c, d, rows, pts, stack, areas, &m_sh);
+        }
     }
 }
 
@@ -509,7 +532,7 @@ __global__ void post_count_out_kernel(PostArgs p) {             // pages without
 static inline size_t post_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PostLayout {
-    size_t st, hist, psum, pcnt, label, area, minx, maxx, miny, maxy, maxv, blk, comp, rowoff, rmin, rmax, total;
+    size_t st, hist, psum, pcnt, label, area, minx, maxx, miny, maxy, maxv, blk, comp, rowoff, rmin, rmax, big, big_stride, total;
     int n_blk, row_cap;
 };
 
@@ -529,6 +552,8 @@ static inline PostLayout post_layout(int B, int H, int W, int max_boxes) {
     L.comp = take((size_t)B * max_boxes * sizeof(CompStats));
     L.rowoff = take((size_t)B * max_boxes * 4);
     L.rmin = take((size_t)B * L.row_cap * 4); L.rmax = take((size_t)B * L.row_cap * 4);
+    L.big_stride = H > POST_LDS_ROWS ? post_align(post_scratch_bytes(H)) : 0;      // tall-component scratch: only pages that can hold one
+    L.big = take((size_t)B * POST_BIG_BLOCKS * L.big_stride);
     L.total = off;
     return L;
 }
@@ -570,12 +595,14 @@ static inline int post_run(const float* heat, long page_stride, int B, int H, in
     hipLaunchKernelGGL(post_scatter_kernel, scan, dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_rows_kernel, pix, dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_count_out_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, p);
-    // geometry: LDS = points (2 rows) + stack (4 rows + 4) + areas (2 rows doubles), rows <= H
-    const size_t lds = (size_t)(2 * H) * sizeof(Pt) + (size_t)(4 * H + 4) * sizeof(Pt) + (size_t)(2 * H) * sizeof(double);
-    if (lds > 160 * 1024) return SA_ERR_UNSUPPORTED;
+    // geometry: 64 bytes of LDS per dilated row (points 2 rows + stack 4 rows + 4 + areas 2 rows doubles) for components of up to
+    // POST_LDS_ROWS rows; a second, small launch takes taller components through workspace scratch (only on pages that can hold one)
+    const size_t lds = post_scratch_bytes(std::min(H, POST_LDS_ROWS));
     static AttrOnce attr;
-    attr.ensure(post_boxes_kernel, lds);
-    hipLaunchKernelGGL(post_boxes_kernel, dim3(std::min(max_boxes, 256), B), dim3(64), lds, s, p);
+    attr.ensure(post_boxes_kernel<false>, lds);
+    hipLaunchKernelGGL(post_boxes_kernel<false>, dim3(std::min(max_boxes, 256), B), dim3(64), lds, s, p, (unsigned char*)nullptr, (size_t)0);
+    if (H > POST_LDS_ROWS)
+        hipLaunchKernelGGL(post_boxes_kernel<true>, dim3(POST_BIG_BLOCKS, B), dim3(64), 0, s, p, (unsigned char*)(w + L.big), L.big_stride);
     return (int)hipGetLastError();
 }
 

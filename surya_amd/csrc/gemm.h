@@ -268,16 +268,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         __syncthreads();                                 \
     }
+            // (The refill after the last tile is skipped: round 2 re-fetched the last K-tile there, clamped, "so the loads in flight
+            // stay constant" -- a rule of the register-staged loop below that this loop, with its explicit vmcnt(0), never needed;
+            // it cost every workgroup one more K-tile of L2 traffic and the wait for it, ~0.8 us of a 20-step decode gate|up launch.)
             SA_ISSUE(0, 0);
             SA_LANDED();
             for (int pi = 0; pi < pairs; ++pi) {
                 const int kt = 2 * pi;
-                SA_ISSUE(BUF, min(kt + 1, last));
+                SA_ISSUE(BUF, kt + 1);                      // kt + 1 <= last inside the pair loop
                 __builtin_amdgcn_sched_barrier(0);
                 SA_COMPUTE(smem);
                 __builtin_amdgcn_sched_barrier(0);
                 SA_LANDED();
-                SA_ISSUE(0, min(kt + 2, last));
+                if (kt + 2 <= last) SA_ISSUE(0, kt + 2);    // wave-uniform
                 __builtin_amdgcn_sched_barrier(0);
                 SA_COMPUTE(smem + BUF);
                 __builtin_amdgcn_sched_barrier(0);
@@ -290,26 +293,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         // wait until this wave's loads of tile kt have landed (vmcnt leaves the GLDS-2 younger tiles outstanding), one
         // raw s_barrier (all waves' parts of tile kt are in LDS, and every wave is done with tile kt-1), refill the
         // buffer tile kt-1 occupied with tile kt+GLDS-1, multiply tile kt. __syncthreads() is avoided inside the loop: its
-        // fence makes hipcc drain vmcnt to 0, which would collapse the prefetch distance to one tile. Tile indices are
-        // clamped (redundant loads into a dead buffer at the tail) so the number of loads in flight is a constant.
+        // fence makes hipcc drain vmcnt to 0, which would collapse the prefetch distance to one tile.
         constexpr int LPT = XI + WI;                       // loads per tile per wave
-        static_assert((GLDS - 2) * LPT <= 63, "vmcnt range");
+        static_assert(GLDS <= 4 && (GLDS - 2) * LPT <= 63, "ring depth / vmcnt range");
+        // Only tiles that exist are fetched. The wait in front of tile kt leaves min(GLDS - 2, last - kt) younger tiles in flight, so
+        // the count is an immediate chosen by a (wave-uniform) branch on the tiles that remain. Round 2 kept the count constant by
+        // re-fetching the last tile GLDS - 1 times at the tail and waiting for all of it before the epilogue: 3 extra K-tiles of
+        // traffic and their latency per workgroup -- on the o-projection's 6-7 K-tiles per slice, +45 % bytes.
 #pragma unroll
-        for (int st = 0; st < GLDS - 1; ++st) SA_ISSUE(st * BUF, min(st, last));
+        for (int st = 0; st < GLDS - 1; ++st)
+            if (st <= last) SA_ISSUE(st * BUF, st);
         int rd = 0, wr = (GLDS - 1) * BUF;                 // byte offsets of the buffer to multiply / to refill
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GLDS - 2) * LPT) : "memory");
+            const int rem = last - kt;                     // younger tiles already requested: min(rem, GLDS - 2)
+            if (rem >= GLDS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GLDS - 2) * LPT) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            SA_ISSUE(wr, min(kt + GLDS - 1, last));
+            if (kt + GLDS - 1 <= last) SA_ISSUE(wr, kt + GLDS - 1);
             __builtin_amdgcn_sched_barrier(0);
             SA_COMPUTE(smem + rd);
             __builtin_amdgcn_sched_barrier(0);
             rd = rd + BUF == GLDS * BUF ? 0 : rd + BUF;
             wr = wr + BUF == GLDS * BUF ? 0 : wr + BUF;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: redundant loads must land before LDS is reused below
         }
 #undef SA_ISSUE
     } else {
@@ -388,26 +397,58 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
     // N = 1280 residual GEMMs ran at 400 TF/s on it). Instead the tile is staged in the (now idle) staging LDS with bias /
     // activation applied, then stored as whole 16-byte chunks of contiguous rows; the residual is added on the way out.
+    //
+    // Every global operand of the epilogue (bias, rotary table, residual) is fetched in BATCHES of unconditional loads with
+    // clamped addresses, one wait per batch. Round 2 loaded them where they were used, under `if (p.bias)` / `if (n < rope_cols)` /
+    // loop-`continue` conditions: hipcc then branches around every load and waits vmcnt(0) behind each -- 32 dependent L2 round
+    // trips for the bias of a 256x256 tile and 16 for its residual (r03 ISA), ~15-20 us of a ~50 us tile at K = 1280.
     __syncthreads();
     constexpr int OW = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;         // output columns of this tile
     using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
     constexpr int ROWB = OW * (int)sizeof(TS), CPR = ROWB / 16;              // bytes and 16-byte chunks per tile row
     constexpr int XM = CPR >= 8 ? 7 : CPR - 1;                               // chunk XOR mask (conflict-free b128 writes)
     static_assert(BM * ROWB <= 160 * 1024 && CPR >= 1, "output tile must fit LDS (launcher sizes it)");
+    const bool has_bias = !SPLIT && p.bias != nullptr;                       // wave-uniform
+    // the lane's 4 bias columns of (j, g), the same for every i; kept as loaded (packed bf16: 2 registers) until they are used
+    using BiasRaw = typename std::conditional<std::is_same<TI, float>::value, float4, uint2>::type;
+    [[maybe_unused]] BiasRaw bias_raw[FN][4];
+    if constexpr (!SPLIT) {
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bias_raw[j][g] = *reinterpret_cast<const BiasRaw*>(p.bias + min(n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4, p.N - 4));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = wm * WTM + i * 32 + (lane & 31);
+        constexpr int JG = FN >= 2 ? 2 : 1;                                  // rotary entries are fetched for JG column blocks at a time
+        [[maybe_unused]] float4 rope_v[JG][4];                               // (8 x 16 bytes in flight; all FN at once spilled at 256x256)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
+            if constexpr (EPI == EPI_ROPE && !SPLIT) {
+                if (j % JG == 0) {
+                    // (cos j, sin j, cos j+1, sin j+1) of this lane's row; columns past rope_cols read a clamped (unused) entry
+                    const int m = min(m0 + row, p.M - 1), half = p.rope_D >> 1;
+#pragma unroll
+                    for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = min(min(n0 + wn * WTN + (j + jj) * 32 + g * 8 + (lane >> 5) * 4, p.N - 4), p.rope_cols - 4);
+                            rope_v[jj][g] = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((n % p.rope_D) >> 1));
+                        }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ncol = wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;   // tile-local column of v[0]
                 float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                 if constexpr (!SPLIT) {
-                    if (p.bias) {
-                        const int n = min(n0 + ncol, p.N - 4);
+                    if (has_bias) {
                         float b[4];
-                        load4(p.bias + n, b);
+                        load4(reinterpret_cast<const TI*>(&bias_raw[j][g]), b);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += b[r];
                     }
@@ -427,8 +468,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                     if (n < p.rope_cols) {
                         // reference order (encoder/__init__.py:188-199): the projection output is rounded to the storage
                         // dtype, rotated in fp32, rounded once more (the store below)
-                        const int m = min(m0 + row, p.M - 1), j = (n % p.rope_D) >> 1, half = p.rope_D >> 1;
-                        const float4 cs = *reinterpret_cast<const float4*>(p.rope + (long)m * half + j);   // (cos j, sin j, cos j+1, sin j+1)
+                        const float4 cs = rope_v[j % JG][g];                                         // (cos j, sin j, cos j+1, sin j+1)
                         const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
                         // products and sums pinned (one rounded product, one fused multiply-add): left to the compiler, the
                         // 128x128 and 256x256 instantiations contracted these differently and the SAME patch got encoder features
@@ -493,10 +533,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     constexpr int EPC = 16 / (int)sizeof(TS);                                // elements per 16-byte chunk
     const int n_out = (EPI == EPI_SWIGLU && !SPLIT) ? p.N / 2 : p.N;
     const int n0_out = (EPI == EPI_SWIGLU && !SPLIT) ? n0 / 2 : n0;
-    for (int id = tid; id < BM * CPR; id += NT) {
-        const int row = id / CPR, c = id % CPR;
+    constexpr int ITERS = (BM * CPR + NT - 1) / NT;                          // 16-byte chunks per thread
+    [[maybe_unused]] u32x4 res[ITERS];
+    if constexpr (EPI == EPI_RESIDUAL && !SPLIT) {                           // the whole tile's residual in one batch of loads
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int id = min(tid + it * NT, BM * CPR - 1), row = id / CPR, c = id % CPR;
+            const int m = min(m0 + row, p.M - 1), n = min(n0_out + c * EPC, n_out - EPC);
+            res[it] = *reinterpret_cast<const u32x4*>(p.R + (long)m * p.ldr + n);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int id = tid + it * NT, row = id / CPR, c = id % CPR;
         const int m = m0 + row, n = n0_out + c * EPC;
-        if (m >= p.M || n >= n_out) continue;
+        if (id >= BM * CPR || m >= p.M || n >= n_out) continue;              // stores only: nothing below waits on memory
         u32x4 raw = *reinterpret_cast<const u32x4*>(smem + row * ROWB + ((c ^ (row & XM)) << 4));
         if constexpr (SPLIT) {
             *reinterpret_cast<u32x4*>(p.part + ((long)ks * p.M + m) * p.N + n) = raw;
@@ -505,7 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                 float a[EPC], r[EPC];
                 const uint4 raw4 = make_uint4(raw[0], raw[1], raw[2], raw[3]);
                 unpack16(raw4, a, (TO*)nullptr);
-                unpack16(*reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n), r, (TO*)nullptr);
+                unpack16(make_uint4(res[it][0], res[it][1], res[it][2], res[it][3]), r, (TO*)nullptr);
                 TO* dst = p.C + (long)m * p.ldc + n;
 #pragma unroll
                 for (int e = 0; e < EPC; e += 4) store4(dst + e, a[e] + r[e], a[e + 1] + r[e + 1], a[e + 2] + r[e + 2], a[e + 3] + r[e + 3]);

@@ -145,23 +145,28 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs p) {
                 acc[j][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], xf[i], acc[j][i], 0, 0, 2, swd[j], 2, sxd[i]); \
     }
     // STAGES-deep ring, exactly as gemm.h's GLDS ring: tiles kt .. kt + STAGES - 2 in flight or resident while tile kt is
-    // multiplied; one raw s_barrier per K-tile; tile indices clamped so the loads in flight are a constant.
+    // multiplied; one raw s_barrier per K-tile; only tiles that exist are fetched and the wait count follows the tiles that
+    // remain (round 2 re-fetched the last tile STAGES - 1 times at the tail and waited for it: see gemm.h).
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st) SA_MX_ISSUE(st * BUF, min(st, last));
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st <= last) SA_MX_ISSUE(st * BUF, st);
     int rd = 0, wr = (STAGES - 1) * BUF;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        const int rem = last - kt;
+        if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        SA_MX_ISSUE(wr, min(kt + STAGES - 1, last));
+        if (kt + STAGES - 1 <= last) SA_MX_ISSUE(wr, kt + STAGES - 1);
         __builtin_amdgcn_sched_barrier(0);
         SA_MX_COMPUTE(smem + rd);
         __builtin_amdgcn_sched_barrier(0);
         rd = rd + BUF == STAGES * BUF ? 0 : rd + BUF;
         wr = wr + BUF == STAGES * BUF ? 0 : wr + BUF;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // redundant tail loads must land before LDS is reused below
 #undef SA_MX_COMPUTE
 #undef SA_MX_FRAG
 #undef SA_MX_ISSUE
@@ -171,6 +176,18 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs p) {
     constexpr bool SWIGLU = (EPI == MX_EPI_SWIGLU && !SPLIT);
     constexpr int OW = SWIGLU ? BN / 2 : BN;
     constexpr int ROWB = OW * 4, CPR = ROWB / 16, XM = CPR >= 8 ? 7 : CPR - 1;
+    // bias of the lane's columns in one batch of loads (see gemm.h: loaded at the point of use, each load is its own round trip)
+    const bool has_bias = !SPLIT && !SWIGLU && p.bias != nullptr;
+    [[maybe_unused]] uint2 bias_raw[FN][4];
+    if constexpr (!SPLIT && !SWIGLU) {
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bias_raw[j][g] = *reinterpret_cast<const uint2*>(p.bias + min(n0 + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4, p.N - 4));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = wm * WTM + i * 32 + (lane & 31);
@@ -181,9 +198,9 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxArgs p) {
                 const int ncol = wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4;
                 float v0 = acc[j][i][4 * g], v1 = acc[j][i][4 * g + 1], v2 = acc[j][i][4 * g + 2], v3 = acc[j][i][4 * g + 3];
                 if constexpr (!SPLIT && !SWIGLU) {
-                    if (p.bias) {
+                    if (has_bias) {
                         float b[4];
-                        load4(p.bias + min(n0 + ncol, p.N - 4), b);
+                        load4(reinterpret_cast<const bf16_t*>(&bias_raw[j][g]), b);
                         v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
                     }
                 }

@@ -146,16 +146,28 @@ class HipDetPost:
         hn = torch.empty(count.shape, dtype=torch.int32, pin_memory=True).copy_(count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return (ev, hb, hc, hn, heat)                    # `heat` rides along so its memory is not reused before the kernels ran
+        return (ev, hb, hc, hn, heat, (text_threshold, low_text))     # `heat` rides along: its memory must outlive the kernels
 
     def collect(self, pending):
-        ev, hb, hc, hn, _ = pending
+        ev, hb, hc, hn, heat, thr = pending
         ev.synchronize()
         n = hn.numpy()
-        if (n < 0).any():
-            raise L.SuryaAmdError(f"surya_det_boxes: a page has more than max_boxes = {self.max_boxes} text components")
         bh, ch = hb.numpy(), hc.numpy()
-        return [(bh[b, : n[b]].copy(), ch[b, : n[b]].copy()) for b in range(len(n))]
+        out = [(bh[b, : n[b]].copy(), ch[b, : n[b]].copy()) if n[b] >= 0 else None for b in range(len(n))]
+        over = [b for b in range(len(n)) if n[b] < 0]
+        if over:
+            # a noisy / very dense page: more kept components than the (fixed-size, copied-whole) output holds. The reference has
+            # no cap, so run those pages again, alone, with room for 16 x as many boxes; only past that give up loudly.
+            if self.max_boxes >= 1 << 16:
+                self._raise_overflow()
+            big = HipDetPost(self.device, max_boxes=self.max_boxes * 16)
+            redo = big(heat[over].contiguous(), *thr)
+            for b, r in zip(over, redo):
+                out[b] = r
+        return out
+
+    def _raise_overflow(self):
+        raise L.SuryaAmdError(f"surya_det_boxes: a page has more than max_boxes = {self.max_boxes} text components")
 
     def __call__(self, heat: torch.Tensor, text_threshold: float, low_text: float):
         """heat: cuda fp32, [B, H, W] contiguous, or a [B, labels, H, W] tensor whose plane 0 is the text map (then the page

@@ -165,8 +165,11 @@ class DetectionPredictor(BasePredictor):
                 bx, cf, psize = res[pg]
                 hi = ai = None
                 if include_maps:
-                    hm = np.vstack([maps[t, 0, : split_heights[t]] for t in tiles_of[pg]])
-                    am = np.vstack([maps[t, 1, : split_heights[t]] for t in tiles_of[pg]])
+                    # the reference keeps a page's FIRST tile whole -- an unsplit page shorter than the processor height still gets
+                    # its full map -- and trims only the later strips of a split page to their valid rows (detection/__init__.py:134-151)
+                    rows = [maps.shape[2] if k == 0 else split_heights[t] for k, t in enumerate(tiles_of[pg])]
+                    hm = np.vstack([maps[t, 0, :r] for t, r in zip(tiles_of[pg], rows)])
+                    am = np.vstack([maps[t, 1, :r] for t, r in zip(tiles_of[pg], rows)])
                     hi, ai = Image.fromarray((hm * 255).astype(np.uint8)), Image.fromarray((am * 255).astype(np.uint8))
                 out.append(result_from_device_boxes(bx, cf, list(psize), sizes[pg], hi, ai))
 

@@ -171,9 +171,15 @@ class RecognitionModelLoader(ModelLoader):
             if not self._special_tokens or not self._special_tokens.get("all"):
                 raise ValueError(f"{self.checkpoint}/config.json has no special_ocr_tokens; cannot lay out token ids")
             tok = OCRTokenizer(self._special_tokens, math_tok, reserve_special=0)
-            if tok.vocab_size != self._cfg.decoder.vocab_size:
+            # the lm_head may be PADDED beyond the tokenizer (the reference never ties the two sizes); ids the tokenizer does not
+            # know can then be emitted and decode to nothing. A tokenizer LARGER than the head cannot be right.
+            if tok.vocab_size > self._cfg.decoder.vocab_size:
                 raise ValueError(f"token-id layout mismatch: qwen_offset {tok.qwen_offset} + {tok.num_special} tags + 65536 "
-                                 f"UTF-16 units = {tok.vocab_size}, but decoder.vocab_size = {self._cfg.decoder.vocab_size}")
+                                 f"UTF-16 units = {tok.vocab_size} > decoder.vocab_size = {self._cfg.decoder.vocab_size}")
+            if tok.vocab_size < self._cfg.decoder.vocab_size:
+                import warnings
+                warnings.warn(f"decoder.vocab_size {self._cfg.decoder.vocab_size} exceeds the tokenizer's {tok.vocab_size} ids "
+                              "(padded lm_head); ids beyond the tokenizer decode to nothing")
             return tok
         # synthetic configs only: one id per UTF-8 byte stands in for the BPE, and the tag range is padded to the
         # config's fixed width (a randomly initialised model can emit any id)
@@ -306,8 +312,10 @@ class RecognitionPredictor(BasePredictor):
     def slice_bboxes(self, images, task_names, bboxes=None, polygons=None, input_text=None) -> dict:
         assert bboxes is not None or polygons is not None
         flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
+        # ONE decision for the whole call (prepare_lines dispatches on the type of the first slice): the device path takes 4-point
+        # polygons only, so a single polygon with another vertex count anywhere sends every image of the call down the host path
+        dev = self.device_preprocess and (polygons is None or all(len(pl) == 4 for page in polygons for pl in page))
         for idx, image in enumerate(images):
-            dev = self.device_preprocess and (polygons is None or all(len(pl) == 4 for pl in polygons[idx]))
             arr = None if dev else self.processor.image_processor(image)
             pg = self._page(flat, image) if dev else -1
             if polygons is not None:
@@ -669,7 +677,9 @@ class RecognitionPredictor(BasePredictor):
                         b_ += 1
             if k == 2:
                 # a run of UTF-16 code units decodes in one piece (tokenizer._decode_ocr's flush of a non-math buffer)
-                text = array("H", [t - s_off for t in ids[a_:b_]]).tobytes().decode("utf-16le", errors="ignore")
+                # (ids above the tokenizer's range -- a checkpoint with a padded lm_head -- wrap into 16 bits like the byte masking
+                # of tokenizer._decode_ocr instead of raising OverflowError)
+                text = array("H", [(t - s_off) & 0xFFFF for t in ids[a_:b_]]).tobytes().decode("utf-16le", errors="ignore")
                 if text:
                     boxes = [a_] + [j for j in range(a_ + 1, b_) if far[j - 1]]
                     L, nb = len(text), len(boxes)

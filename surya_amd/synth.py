@@ -298,3 +298,38 @@ def make_pages_with_lines(n: int, size: int = 1024, seed: int = 1234):
         pages.append(img)
         boxes.append(rows)
     return pages, boxes
+
+
+def text_like_map(h: int, w: int, n_lines: int, seed: int = 0) -> np.ndarray:
+    """A text heat map as a trained detector draws it: `n_lines` soft line-shaped blobs (height 8-20 px, length 6-60 % of the page
+    width, a few slightly rotated) laid out in rows over a low noise floor, values in (0, 1). float32 [h, w].
+    Used to time / test surya_det_boxes on realistic component counts (a randomly initialised detector yields one page-sized blob)."""
+    rng = np.random.default_rng(seed)
+    m = rng.random((h, w), dtype=np.float32) * 0.1
+    per_row = max(1, int(np.ceil(n_lines / max(1, (h - 40) // 30))))
+    n_rows = int(np.ceil(n_lines / per_row))
+    pitch = (h - 40) / n_rows
+    done = 0
+    for r in range(n_rows):
+        cy = 20 + (r + 0.5) * pitch
+        x = rng.uniform(10, 40)
+        for _ in range(per_row):
+            if done == n_lines:
+                break
+            half_len = rng.uniform(0.03, 0.3) * w / per_row
+            half_h = rng.uniform(4, min(10, pitch / 2 - 3))
+            cx = x + half_len
+            if cx + half_len > w - 8:
+                half_len = max(6.0, (w - 8 - x) / 2)
+                cx = x + half_len
+            th = rng.choice([0.0, 0.0, 0.0, rng.uniform(-0.03, 0.03)])
+            y0, y1 = int(max(0, cy - half_h - half_len * abs(th) - 14)), int(min(h, cy + half_h + half_len * abs(th) + 14))
+            x0, x1 = int(max(0, cx - half_len - 14)), int(min(w, cx + half_len + 14))
+            yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+            u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+            v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+            blob = np.exp(-np.maximum(np.abs(u) / half_len, np.abs(v) / half_h) ** 4) * rng.uniform(0.7, 0.98)
+            m[y0:y1, x0:x1] = np.maximum(m[y0:y1, x0:x1], blob.astype(np.float32))
+            x = cx + half_len + rng.uniform(12, 40)
+            done += 1
+    return np.ascontiguousarray(np.clip(m, 0.001, 0.999).astype(np.float32))

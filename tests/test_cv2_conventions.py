@@ -128,3 +128,22 @@ def test_components_are_4_connected_and_raster_ordered():
     assert len(boxes) == 2               # A has 9 px (< 10, dropped), the diagonal pixel too; B (16 px) and C (12 px) stay
     assert boxes[0][:, 1].min() < boxes[1][:, 1].min()        # B before C: raster order of the first pixel
     assert abs(conf[0] - 0.8 / 0.85) < 1e-6 and abs(conf[1] - 1.0) < 1e-6
+
+
+# ---- the one resampling pin this image offers: INTER_CUBIC vs torch's bicubic (same Keys a = -0.75 kernel, half-pixel centres,
+# replicate border, no antialiasing). Every real line crop passes through this stage (the x28 round-up, processor/__init__.py:193-212).
+CUBIC_GEOMETRIES = [((64, 512), (84, 532)), ((119, 238), (140, 252)), ((64, 333), (84, 336)), ((57, 411), (84, 420)), ((71, 129), (84, 140))]
+
+
+@pytest.mark.parametrize("src,dst", CUBIC_GEOMETRIES)
+def test_cubic_resize_matches_torch_bicubic(src, dst):
+    import torch
+    import torch.nn.functional as F
+    from surya_amd.common import imageops
+    rng = np.random.default_rng(src[1])
+    img = rng.integers(0, 256, size=src + (3,)).astype(np.float32)
+    ours = imageops.resize(img, dst[1], dst[0], "cubic")
+    ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=dst, mode="bicubic", align_corners=False)[0]
+    ref = ref.permute(1, 2, 0).numpy()
+    err = float(np.abs(ours - ref).max())
+    assert err <= 2e-2, err              # on a 0-255 scale

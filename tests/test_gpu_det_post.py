@@ -41,6 +41,44 @@ def test_device_boxes_equal_host_on_synthetic_maps(hip_lib, shape, seeds):
     assert n > 0
 
 
+def test_device_boxes_tall_page_and_tall_component(hip_lib):
+    """A page taller than any LDS sizing by page height allowed (round 2 refused H >= 2560) with a component of ~2000 dilated rows
+    (> POST_LDS_ROWS: the workspace-scratch launch) next to ordinary line-shaped ones (the LDS launch), and a normal page after it
+    through the same HipDetPost (the dynamic-LDS attribute must follow the larger request)."""
+    from surya_amd.detection.model import HipDetPost
+    post = HipDetPost()
+    h, w = 3200, 512
+    m = synth_map(h, w, 41)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    bar = np.exp(-np.maximum(np.abs(xx - 400) / 9.0, np.abs(yy - 1500) / 1000.0) ** 4) * 0.9      # a vertical rule, ~2000 rows
+    m = np.ascontiguousarray(np.maximum(m, bar.astype(np.float32)))
+    ref_boxes, _ = hm.detect_boxes(m, 0.6, 0.35)
+    assert max(np.ptp(np.asarray(b)[:, 1]) for b in ref_boxes) > 1500          # the tall component is there
+    assert _compare(post, [m]) >= 3
+    assert _compare(post, [synth_map(1024, 1024, 6)]) > 0
+
+
+def test_device_boxes_text_like_pages(hip_lib):
+    """Pages that look like text (surya_amd.synth.text_like_map: 30 / 100 / 300 line-shaped components per 1024^2 page) -- the
+    shapes bench.py times surya_det_boxes on."""
+    from surya_amd.detection.model import HipDetPost
+    from surya_amd.synth import text_like_map
+    post = HipDetPost()
+    for n_lines in (30, 100, 300):
+        maps = [text_like_map(1024, 1024, n_lines, seed=s) for s in (1, 2)]
+        n = _compare(post, maps)
+        assert n >= 1.6 * n_lines, (n_lines, n)
+
+
+def test_device_boxes_more_components_than_max_boxes(hip_lib):
+    """A page with more kept components than the fixed-size output holds is run again with a larger one (the reference has no cap)."""
+    from surya_amd.detection.model import HipDetPost
+    from surya_amd.synth import text_like_map
+    post = HipDetPost(max_boxes=64)
+    maps = [text_like_map(1024, 1024, 100, seed=3), text_like_map(1024, 1024, 30, seed=4)]
+    assert _compare(post, maps) == 130
+
+
 def test_device_boxes_noise_map_and_empty_page(hip_lib):
     """Hundreds of small components (noise around the threshold), a page with nothing above the threshold, repeatability."""
     from scipy.ndimage import convolve

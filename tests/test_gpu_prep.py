@@ -134,3 +134,32 @@ def test_rgbx_pages_give_the_same_tiles_as_rgb(hip_lib):
     assert g3 == g4 and np.array_equal(o3, o4) and torch.equal(t3, t4)
     tm, om, gm = pre([pages[0], rgbx[1]], lines, sizes)              # mixed strides: repacked to RGB on the host
     assert torch.equal(tm, t3)
+
+
+def test_device_cubic_stage_matches_torch_bicubic(hip_lib):
+    """The device CUBIC stage (every line's x28 round-up) against torch's bicubic interpolation of the same crop: the one pin of the
+    restated OpenCV resampling that this image offers (same Keys a = -0.75 kernel / half-pixel geometry). Crops whose area is
+    above 168^2, so only the cubic stage runs: the three bench geometries and odd widths; <= 2e-2 on the 0-255 scale."""
+    import torch.nn.functional as F
+    from surya_amd.recognition.preprocess_gpu import DevicePreprocessor, LineRef
+    proc = _processor()
+    rng = np.random.default_rng(12)
+    shapes = [(64, 512), (119, 238), (64, 457), (64, 511), (75, 401), (90, 333)]
+    crops = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]
+    pre = DevicePreprocessor("cuda:0")
+    refs = [LineRef(i, 0, 0, c.shape[1], c.shape[0]) for i, c in enumerate(crops)]
+    tiles, offs, grids = pre(crops, refs, [(1024, 256)] * len(crops))
+    tiles = tiles.cpu().numpy()
+    std = np.asarray(proc.image_std, np.float32).max() if hasattr(proc, "image_std") else 0.27
+    worst = 0.0
+    for i, c in enumerate(crops):
+        gh, gw = grids[i]
+        H, W = gh * 14, gw * 14
+        assert (H, W) != c.shape[:2]
+        up = F.interpolate(torch.from_numpy(c.astype(np.float32)).permute(2, 0, 1)[None].double(), size=(H, W), mode="bicubic",
+                           align_corners=False)[0].permute(1, 2, 0).numpy().astype(np.float32)
+        ref, grid = proc.process_and_tile(up)                     # already a multiple of 28: rescale + normalise + patch order only
+        assert tuple(grid) == (gh, gw)
+        got = tiles[int(offs[i]): int(offs[i + 1])]
+        worst = max(worst, float(np.abs(got - ref).max()) * float(std) * 255.0)
+    assert worst <= 2e-2, worst
