@@ -1,0 +1,86 @@
+"""A checkpoint DIRECTORY through RecognitionModelLoader (surya_amd/recognition/predictor.py; mirrors the reference's
+surya/recognition/loader.py:25-82): config.json + *.safetensors + the Qwen2 BPE files + special_ocr_tokens. No real checkpoint is
+available offline, so the directory is synthetic (tests/ckpt_util.py; its writer is checked against the reference's own
+save_pretrained in tests/test_oracle_vs_reference.py). CPU: config, token-id layout, tensors; GPU: the loaded model's tokens == the
+oracle's on the same weights, through the predictor's own scheduler."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import ckpt_util as cu
+from surya_amd.synth import make_rec_weights, make_line_crops
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    cfg = cu.tiny_checkpoint_config()
+    sd = make_rec_weights(cfg, 3)
+    return cfg, sd, cu.write_rec_checkpoint(str(tmp_path_factory.mktemp("rec_ckpt")), cfg, sd)
+
+
+def test_loader_reads_config_tokenizer_and_tensors(ckpt):
+    from surya_amd.recognition.predictor import RecognitionModelLoader
+    cfg, sd, path = ckpt
+    ld = RecognitionModelLoader(path)
+    ld._resolve()
+    assert ld._cfg.encoder == cfg.encoder and ld._cfg.decoder == cfg.decoder
+    assert (ld._cfg.bbox_size, ld._cfg.num_register_tokens, ld._cfg.image_embed_encoding_size) == (1025, 4, 1024)
+    assert set(ld._sd) == set(sd) and all(torch.equal(ld._sd[k], sd[k]) for k in sd)
+    tok = ld.tokenizer()
+    # the id layout is defined by the files: BPE ids first, then the tags in the order of special_ocr_tokens["all"], then UTF-16
+    n_tags = len(cu.special_ocr_tokens()["all"])
+    assert tok.qwen_offset == cu.N_BPE and tok.special_token_offset == cu.N_BPE + n_tags and tok.vocab_size == cfg.decoder.vocab_size
+    assert tok.system_tokens["</S>"] == cu.N_BPE and tok.system_tokens["<IMAGE>"] == cu.N_BPE + 2
+    text = 'a<b>x</b><math display="inline">\\frac{1}{2} x^2</math>é\U0001d11e'
+    ids = tok([text], ["ocr_with_boxes"])["input_ids"][0]
+    assert tok.decode(ids) == text
+    math = [i for i in ids if i < tok.qwen_offset]
+    assert 259 in math                                   # "\frac" went through the checkpoint's BPE merges, not byte by byte
+    proc = ld.processor()
+    assert proc.ocr_tokenizer.special_token_offset == tok.special_token_offset
+
+
+def test_padded_and_short_lm_head(tmp_path):
+    """decoder.vocab_size may exceed the tokenizer's id count (padded lm_head: accepted with a warning; ids beyond the tokenizer
+    decode to nothing instead of raising); a head SMALLER than the tokenizer is a layout error."""
+    from surya_amd.recognition.predictor import RecognitionModelLoader
+    cfg = cu.tiny_checkpoint_config(pad_vocab=12)
+    path = cu.write_rec_checkpoint(str(tmp_path / "padded"), cfg, {"x": torch.zeros(1)})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tok = RecognitionModelLoader(path).tokenizer()
+    assert any("padded lm_head" in str(x.message) for x in w) and tok.vocab_size == cfg.decoder.vocab_size - 12
+    small = cu.tiny_checkpoint_config(pad_vocab=-8)
+    path = cu.write_rec_checkpoint(str(tmp_path / "short"), small, {"x": torch.zeros(1)})
+    with pytest.raises(ValueError):
+        RecognitionModelLoader(path).tokenizer()
+
+
+@pytest.mark.gpu
+def test_predictor_from_checkpoint_dir_matches_oracle(hip_lib, ckpt):
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    from surya_amd.settings import settings
+    from test_gpu_predictors import oracle_tokens
+    cfg, sd, path = ckpt
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype_=None, **caps):
+            return super().model("cuda:0", torch.float32, max_slots=4, max_kv_len=256, max_patches=8192, max_prefill_tokens=1024)
+
+    class Pred(RecognitionPredictor):
+        model_loader_cls = Loader
+        batch_size = 4
+
+    settings.RECOGNITION_MAX_TOKENS = 10
+    try:
+        pred = Pred(checkpoint=path)
+        assert pred.model.vocab == cfg.decoder.vocab_size
+        crops = [c.astype(np.float32) for c in make_line_crops(6, seed=9)]
+        crops.sort(key=lambda c: -c.shape[1])
+        prep, ref = oracle_tokens(cfg, sd, pred, crops, 10)
+        toks, boxes, scores = pred.generate(prep, 4)
+        assert [list(t) for t in toks] == ref
+    finally:
+        settings.RECOGNITION_MAX_TOKENS = None

@@ -827,3 +827,57 @@ def test_live_device_path_geometry_against_reference_shapes():
     finally:
         for k in added:
             delattr(cv2_stub, k)
+
+
+def test_live_checkpoint_directory_written_by_the_reference(tmp_path):
+    """A checkpoint directory written by the REFERENCE's own SuryaModel.save_pretrained (+ the tiny Qwen2 BPE files) loads through
+    RecognitionModelLoader with the same configuration, tensors and token-id layout the reference's own loader / tokenizer derive
+    from it (surya/recognition/loader.py:25-82, processor/tokenizer.py:224-260); and tests/ckpt_util.write_rec_checkpoint -- the
+    writer the travelling tests use on the GPU box -- produces a config.json that agrees with the reference's on every key it writes."""
+    import json, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ckpt_util as cu
+    from oracle.make_golden import build_reference_rec
+    from surya_amd.recognition.predictor import RecognitionModelLoader
+    from surya_amd.synth import make_rec_weights
+    ref_shim.install()
+    cfg = cu.tiny_checkpoint_config()
+    sd = make_rec_weights(cfg, 3)
+    ref = build_reference_rec(cfg, sd, "sdpa")
+    special = cu.special_ocr_tokens()
+    ref.config.special_ocr_tokens = special
+    ref.config.tie_word_embeddings = False          # the synthetic weight sets carry an untied lm_head (surya_amd/synth.py)
+    path = str(tmp_path / "from_reference")
+    for m in ref.modules():                         # transformers 5.x wants a dict here; the reference (4.x era) declares a list
+        if isinstance(getattr(m, "_tied_weights_keys", None), (list, tuple)):
+            m._tied_weights_keys = {}
+    ref.save_pretrained(path, safe_serialization=True)
+    cu.write_tokenizer_files(path)
+    # -- our loader on the reference-written directory
+    ld = RecognitionModelLoader(path)
+    ld._resolve()
+    assert ld._cfg.encoder == cfg.encoder and ld._cfg.decoder == cfg.decoder
+    assert (ld._cfg.bbox_size, ld._cfg.num_register_tokens) == (ref.config.bbox_size, ref.config.num_register_tokens)
+    rsd = ref.state_dict()
+    assert set(ld._sd) <= set(rsd) and all(torch.equal(ld._sd[k], rsd[k]) for k in ld._sd)
+    assert {k for k in rsd if k not in ld._sd} <= {"lm_head.weight"}            # only a tied head may be left out of the file
+    # -- token-id layout vs the reference's own tokenizer on the same directory
+    rt = _ref("surya.common.surya.processor.tokenizer")
+    rtok = rt.SuryaOCRTokenizer(special_tokens=special, model_checkpoint=path)
+    tok = ld.tokenizer()
+    assert (tok.qwen_offset, tok.special_token_offset) == (rtok.qwen_offset, rtok.special_token_offset)
+    assert tok.system_tokens == rtok.system_tokens and tok.SPECIAL_TOKEN_MAPPING == dict(rtok.SPECIAL_TOKEN_MAPPING)
+    for text in ['plain text', 'a<b>x</b><math display="inline">\\frac{1}{2} x^2</math>é\U0001d11e', '<i>it</i> &amp; <br>']:
+        ours = tok([text], ["ocr_with_boxes"])["input_ids"][0]
+        theirs = rtok([text], ["ocr_with_boxes"])["input_ids"][0]
+        assert list(ours) == list(theirs), text
+        assert tok.decode(ours) == rtok.decode(theirs, task="ocr_with_boxes")
+    # -- our writer vs the reference's config.json
+    ours_dir = cu.write_rec_checkpoint(str(tmp_path / "ours"), cfg, sd, special)
+    a, b = json.load(open(os.path.join(ours_dir, "config.json"))), json.load(open(os.path.join(path, "config.json")))
+    for k, v in a.items():
+        if isinstance(v, dict) and k != "special_ocr_tokens":
+            for kk, vv in v.items():
+                assert b[k][kk] == vv, (k, kk, b[k].get(kk), vv)
+        else:
+            assert b[k] == v, (k, b.get(k), v)
