@@ -50,6 +50,7 @@ template <typename T>
 struct ConvArgs {
     const T* in; const T* w; T* out; const T* bias; const T* res;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, act;
+    const T* zero = nullptr;        // >= 16 zero bytes on the device: what the direct-to-LDS gather reads outside the image
 };
 
 // CIN64: Cin is a multiple of the K-tile (64 bf16 / 32 fp32 elements), so a K-tile never straddles two filter taps: the
@@ -285,10 +286,35 @@ static inline int launch_conv_cfg(const ConvArgs<T>& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// bf16 convolutions run on gemm.h's direct-to-LDS tiles (CONV gather: per-lane source addresses, zero page outside the image) with
+// its XCD-aware tile order and LDS-staged, coalesced epilogue; round 2's register-staged conv_gemm_kernel below stays for fp32
+// reference mode and for combinations the GEMM epilogues do not cover (r03: 3x3 convs were 0.3-0.5 PF/s on it).
+template <typename T, int EPI>
+static inline int launch_conv_on_gemm(const ConvArgs<T>& a, hipStream_t s) {
+    const long M = (long)a.B * a.Ho * a.Wo;
+    GemmArgs<T, T> g{nullptr, 0, a.w, (long)a.Kpad, a.out, (long)a.Cout, a.bias, a.res, (long)a.Cout, (int)M, a.Cout, a.Kpad};
+    g.conv_in = a.in; g.conv_zero = a.zero;
+    g.cH = a.H; g.cW = a.W; g.cCin = a.Cin; g.cHo = a.Ho; g.cWo = a.Wo; g.cKW = a.KW; g.cStride = a.stride; g.cPad = a.pad;
+    g.cTaps = a.KH * a.KW;
+    if (a.Cout >= 256 && cdivl(M, 256) * cdiv(a.Cout, 256) >= 256) return launch_gemm_cfg<T, T, 256, 256, 4, 2, EPI, false, 2, true>(g, s);
+    if (a.Cout >= 128) return launch_gemm_cfg<T, T, 128, 128, 2, 2, EPI, false, 2, true>(g, s);
+    if (a.Cout >= 64) return launch_gemm_cfg<T, T, 128, 64, 4, 1, EPI, false, 2, true>(g, s);
+    return launch_gemm_cfg<T, T, 128, 32, 4, 1, EPI, false, 2, true>(g, s);
+}
+
 template <typename T>
 static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
     if (a.Cin % Ty<T>::V16 != 0 || a.Kpad % Ty<T>::KE != 0 || a.Cout % 4 != 0) return SA_ERR_SHAPE;
     const long M = (long)a.B * a.Ho * a.Wo;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // (the 32-channel stem convolutions stay on the register-staged kernel: 128x32 tiles measured 5-15 % slower on the gather)
+        if (a.zero && a.Cout >= 64 && a.Cout % 8 == 0 && M < (1L << 31)) {
+            if (a.res && a.act == ACT_NONE) return launch_conv_on_gemm<T, EPI_RESIDUAL>(a, s);
+            if (!a.res && a.act == ACT_HSWISH) return launch_conv_on_gemm<T, EPI_HARDSWISH>(a, s);
+            if (!a.res && a.act == ACT_RELU) return launch_conv_on_gemm<T, EPI_RELU>(a, s);
+            if (!a.res && a.act == ACT_NONE) return launch_conv_on_gemm<T, EPI_BIAS>(a, s);
+        }
+    }
     const bool cin64 = a.Cin % Ty<T>::KE == 0;       // K-tiles aligned with filter taps: scalar tap arithmetic
     if (a.Cout >= 128 && cdivl(M, 128) * cdiv(a.Cout, 128) >= 256)
         return cin64 ? launch_conv_cfg<T, 128, 128, 2, 2, true>(a, s) : launch_conv_cfg<T, 128, 128, 2, 2>(a, s);
@@ -387,21 +413,34 @@ __global__ __launch_bounds__(256) void grouped1x1_kernel(const T* __restrict__ i
 #pragma unroll
         for (int i = 0; i < V; ++i) wr[c + i] = (c < GD) ? t[i] : 0.f;
     }
-    for (int k = 0; k < PPB / 8; ++k) {
-        const long pp = p0 + k * 8 + pl;
-        if (pp >= P) break;
-        const T* xr = in + pp * C + g * GD;
-        float acc = 0.f;
+    // the thread's 8 pixels in two batches of 4: all 16-byte loads of a batch are issued before the first use (the pixel loop with
+    // its `break` made every pixel a separate dependent round trip: 8 per workgroup, 90 us per launch in the r03 profile)
+    constexpr int NCH = 32 / V;                              // 16-byte chunks of a 32-channel group
 #pragma unroll
-        for (int c = 0; c < 32; c += V) {
-            if (c < GD) {
-                float x[V];
-                unpack16(*reinterpret_cast<const uint4*>(xr + c), x, (T*)nullptr);
+    for (int kb = 0; kb < PPB / 8; kb += 4) {
+        uint4 raw[4][NCH];
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc += x[i] * wr[c + i];
-            }
+        for (int k = 0; k < 4; ++k) {
+            const long pp = min(p0 + (kb + k) * 8 + pl, P - 1);
+            const T* xr = in + pp * C + g * GD;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) raw[k][cc] = *reinterpret_cast<const uint4*>(xr + min(cc * V, GD - V));
         }
-        if (o < GD) Ty<T>::st(out + pp * C + g * GD + o, acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long pp = p0 + (kb + k) * 8 + pl;
+            float acc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) {
+                if (cc * V < GD) {
+                    float x[V];
+                    unpack16(raw[k][cc], x, (T*)nullptr);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc += x[i] * wr[cc * V + i];
+                }
+            }
+            if (o < GD && pp < P) Ty<T>::st(out + pp * C + g * GD + o, acc);
+        }
     }
 }
 

@@ -28,6 +28,7 @@ struct DetModel : DetBase {
     std::vector<T*> bufs;
     float* planes = nullptr;             // [max_batch, labels, H/4, W/4] fp32
     float* kvp = nullptr;                // LiteMLA partial kv matrices [max_batch, heads, chunks, 32*33] fp32
+    T* zero_page = nullptr;              // 256 zero bytes: source of the convolution gather outside the image
     char* arena = nullptr;
     int max_batch = 0, H = 0, W = 0, labels = 0, in_cp = 8;
 
@@ -48,7 +49,11 @@ struct DetModel : DetBase {
             if (op.type == SA_DET_LITEMLA)
                 kv_floats = std::max(kv_floats, (size_t)max_batch * (op.cout / op.p0) * cdiv(op.hin * op.win, LITEMLA_CHUNK) * LITEMLA_KV);
         total += kv_floats * sizeof(float) + 256;
+        const size_t zero_off = total;
+        total += 256;
         SA_HIP(hipMalloc((void**)&arena, total));
+        SA_HIP(hipMemset(arena + zero_off, 0, 256));
+        zero_page = reinterpret_cast<T*>(arena + zero_off);
         bufs.resize(n_bufs);
         for (int i = 0; i < n_bufs; ++i) bufs[i] = reinterpret_cast<T*>(arena + offs[i]);
         planes = reinterpret_cast<float*>(arena + planes_off);
@@ -91,7 +96,7 @@ struct DetModel : DetBase {
                         break;
                     }
                     ConvArgs<T> a{bufs[op.in0], WT(op.w_idx), bufs[op.out], WT(op.b_idx), op.res >= 0 ? bufs[op.res] : nullptr,
-                                  B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.k, op.stride, op.p0, op.p1, op.act};
+                                  B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.k, op.stride, op.p0, op.p1, op.act, zero_page};
                     if ((rc = launch_conv<T>(a, s))) return rc;
                     break;
                 }

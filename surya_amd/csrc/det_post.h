@@ -436,12 +436,18 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs p) {
 // --------------------------------------------------------------------------------------------------------- 6. geometry
 // One wave per component. Lanes share the dilated-row sweep and the per-edge rectangle areas; the sequential parts (monotone
 // chain, the first-strictly-smaller tie rule of the calipers) run on lane 0. The component's points / hull stack / edge areas
-// (64 bytes per dilated row) live in LDS for components of up to POST_LDS_ROWS dilated rows -- every text line -- and in a
-// per-workgroup slice of the caller's workspace for taller ones (a page-high blob on a 300-dpi scan: round 2 sized the LDS by
-// the PAGE height and refused pages of 2560 rows and more). BIG selects which of the two a launch handles.
-constexpr int POST_LDS_ROWS = 1024;
-constexpr int POST_BIG_BLOCKS = 8;                                // workgroups (scratch slices) per page of the tall-component launch
+// need 64 bytes per dilated row. Three launches share the components by their row count (each walks the page's component list
+// and skips what is not its own; a class that cannot occur on the page is not launched):
+//   class 0  rows <= POST_SMALL_ROWS   16 KB of LDS per workgroup -- every text line; many workgroups per CU
+//   class 1  rows <= POST_LDS_ROWS     the whole 160 KB LDS -- page-high blobs, vertical rules (one workgroup per CU)
+//   class 2  taller                    a per-workgroup slice of the caller's workspace (pages of 2560 rows and more: round 2
+//                                      sized ONE launch's LDS by the page height and refused those pages; LDS is ~2x faster
+//                                      than the workspace for the lane-0 passes, so it is used wherever it fits)
+constexpr int POST_SMALL_ROWS = 255;
+constexpr int POST_LDS_ROWS = 2555;                               // 64 * rows + 64 (+ the static word) <= 160 KB
+constexpr int POST_BIG_BLOCKS = 8;                                // workgroups (scratch slices) per page of the class-2 launch
 static inline size_t post_scratch_bytes(int rows) { return (size_t)64 * rows + 64; }
+__device__ __forceinline__ int post_class_of(int rows) { return rows <= POST_SMALL_ROWS ? 0 : (rows <= POST_LDS_ROWS ? 1 : 2); }
 
 __device__ __forceinline__ void post_box_of(const PostArgs& p, int b, int ci, int lane, const CompStats& c, const Dil& d, int rows,
                                             Pt* pts, Pt* stack, double* areas, int* m_sh) {
@@ -496,7 +502,7 @@ __device__ __forceinline__ void post_box_of(const PostArgs& p, int b, int ci, in
     }
 }
 
-template <bool BIG>
+template <int CLASS>
 __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p, unsigned char* scratch, size_t scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y, lane = threadIdx.x;
@@ -506,9 +512,9 @@ __global__ __launch_bounds__(64) void post_boxes_kernel(PostArgs p, unsigned cha
         const CompStats c = p.comp[b * p.max_boxes + ci];
         const Dil d = dilation_of(c, p.H);
         const int rows = d.Y1 - d.Y0 + 1;
-        if ((rows > POST_LDS_ROWS) != BIG) continue;                       // wave-uniform: the other launch owns this component
+        if (post_class_of(rows) != CLASS) continue;                        // wave-uniform: another launch owns this component
         __syncthreads();
-        if constexpr (BIG) {
+        if constexpr (CLASS == 2) {
             unsigned char* base = scratch + ((size_t)b * gridDim.x + blockIdx.x) * scratch_stride;
             Pt* pts = reinterpret_cast<Pt*>(base);                         // [2 rows]
             Pt* stack = pts + 2 * rows;                                    // [4 rows + 4]
@@ -595,14 +601,20 @@ static inline int post_run(const float* heat, long page_stride, int B, int H, in
     hipLaunchKernelGGL(post_scatter_kernel, scan, dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_rows_kernel, pix, dim3(256), 0, s, p);
     hipLaunchKernelGGL(post_count_out_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, p);
-    // geometry: 64 bytes of LDS per dilated row (points 2 rows + stack 4 rows + 4 + areas 2 rows doubles) for components of up to
-    // POST_LDS_ROWS rows; a second, small launch takes taller components through workspace scratch (only on pages that can hold one)
-    const size_t lds = post_scratch_bytes(std::min(H, POST_LDS_ROWS));
-    static AttrOnce attr;
-    attr.ensure(post_boxes_kernel<false>, lds);
-    hipLaunchKernelGGL(post_boxes_kernel<false>, dim3(std::min(max_boxes, 256), B), dim3(64), lds, s, p, (unsigned char*)nullptr, (size_t)0);
-    if (H > POST_LDS_ROWS)
-        hipLaunchKernelGGL(post_boxes_kernel<true>, dim3(POST_BIG_BLOCKS, B), dim3(64), 0, s, p, (unsigned char*)(w + L.big), L.big_stride);
+    // geometry: three launches by component height (see post_boxes_kernel)
+    {
+        static AttrOnce a0, a1;
+        const size_t lds0 = post_scratch_bytes(std::min(H, POST_SMALL_ROWS));
+        a0.ensure(post_boxes_kernel<0>, lds0);
+        hipLaunchKernelGGL(post_boxes_kernel<0>, dim3(std::min(max_boxes, 256), B), dim3(64), lds0, s, p, (unsigned char*)nullptr, (size_t)0);
+        if (H > POST_SMALL_ROWS) {
+            const size_t lds1 = post_scratch_bytes(std::min(H, POST_LDS_ROWS));
+            a1.ensure(post_boxes_kernel<1>, lds1);
+            hipLaunchKernelGGL(post_boxes_kernel<1>, dim3(32, B), dim3(64), lds1, s, p, (unsigned char*)nullptr, (size_t)0);
+        }
+        if (H > POST_LDS_ROWS)
+            hipLaunchKernelGGL(post_boxes_kernel<2>, dim3(POST_BIG_BLOCKS, B), dim3(64), 0, s, p, (unsigned char*)(w + L.big), L.big_stride);
+    }
     return (int)hipGetLastError();
 }
 

@@ -55,6 +55,15 @@ struct GemmArgs {
     // four consecutive columns holds two complete rotate_half pairs; rope[m * (D/2) + j] = (cos, sin) of token m, pair j.
     const float2* rope = nullptr;
     int rope_cols = 0, rope_D = 0;
+    // Implicit-GEMM convolution (direct-to-LDS tiles, template parameter CONV): X is not a matrix but an NHWC tensor
+    // conv_in[B][cH][cW][cCin]; row m of the GEMM is output pixel (b, oy, ox), K index k = (ky * cKW + kx) * cCin + ci (the weight
+    // rows are laid out the same way, zero padded to K), and the 16-byte chunk a lane stages comes from input pixel
+    // (oy * cStride - cPad + ky, ox * cStride - cPad + kx) -- or from the 16 zero bytes at conv_zero outside the image / past the
+    // last tap: global_load_lds takes a per-lane source address, so the gather costs address arithmetic only (no im2col buffer,
+    // no staging registers). M = B * cHo * cWo, N = Cout, C / R = the NHWC output / residual.
+    const TI* conv_in = nullptr;
+    const TI* conv_zero = nullptr;
+    int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKW = 0, cStride = 0, cPad = 0, cTaps = 0;
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -77,8 +86,9 @@ template <> struct Mfma<float> {
 };
 
 // BM x BN output tile per workgroup of WM x WN waves.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
+    static_assert(!CONV || (GLDS == 2 && !SPLIT), "the convolution gather exists for the 2-stage direct-to-LDS loop");
     constexpr int NT = 64 * WM * WN;
     constexpr int KE = Ty<TI>::KE;            // elements per 128-byte row
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -230,11 +240,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "glds: whole 8-row groups per wave");
         const unsigned char* xg[XI];
         const unsigned char* wg[WI];
+        [[maybe_unused]] long cbase[XI];                     // CONV: element offset of image b of the lane's row
+        [[maybe_unused]] int ciy[XI], cix[XI], cch[XI];      // CONV: top-left input coordinates of the row's window, the lane's K offset
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int row = (wave * XI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-            xg[i] = reinterpret_cast<const unsigned char*>(p.X + (long)min(m0 + row, p.M - 1) * p.ldx) + c * 16 + (long)kt_begin * 128;
+            if constexpr (CONV) {
+                const int m = min(m0 + row, p.M - 1), hw = p.cHo * p.cWo;
+                const int b = m / hw, r = m - b * hw, oy = r / p.cWo;
+                cbase[i] = (long)b * p.cH * p.cW * p.cCin;
+                ciy[i] = oy * p.cStride - p.cPad;
+                cix[i] = (r - oy * p.cWo) * p.cStride - p.cPad;
+                cch[i] = c * Ty<TI>::V16;
+                xg[i] = nullptr;
+            } else {
+                xg[i] = reinterpret_cast<const unsigned char*>(p.X + (long)min(m0 + row, p.M - 1) * p.ldx) + c * 16 + (long)kt_begin * 128;
+            }
         }
+        // K-tiles aligned with filter taps (Cin a multiple of the K-tile): the tap of a K-tile is a scalar
+        [[maybe_unused]] const bool conv_uniform = CONV && (p.cCin % KE == 0);
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
@@ -252,8 +276,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #define SA_ISSUE(BUFOFF, KT)                                                                                            \
     {                                                                                                                   \
         const long koff_ = (long)(KT) * 128;                                                                            \
-        _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                                \
-            (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                     \
+        if constexpr (CONV) {                                                                                           \
+            const int kb_ = (KT) * KE;                                                                                  \
+            int tap_u_ = 0, ci_u_ = 0;                                                                                  \
+            if (conv_uniform) { tap_u_ = kb_ / p.cCin; ci_u_ = kb_ - tap_u_ * p.cCin; }                                 \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                            \
+                int tap_, ci_;                                                                                          \
+                if (conv_uniform) { tap_ = tap_u_; ci_ = ci_u_ + cch[i]; }                                              \
+                else { const int k0_ = kb_ + cch[i]; tap_ = k0_ / p.cCin; ci_ = k0_ - tap_ * p.cCin; }                  \
+                const int ky_ = tap_ / p.cKW, kx_ = tap_ - ky_ * p.cKW;                                                 \
+                const int iy_ = ciy[i] + ky_, ix_ = cix[i] + kx_;                                                       \
+                const bool ok_ = (tap_ < p.cTaps) & (iy_ >= 0) & (iy_ < p.cH) & (ix_ >= 0) & (ix_ < p.cW);              \
+                const TI* src_ = ok_ ? p.conv_in + cbase[i] + ((long)iy_ * p.cW + ix_) * p.cCin + ci_ : p.conv_zero;    \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0); \
+            }                                                                                                           \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                            \
+                (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                 \
+        }                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
             (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, W_AUX);        \
     }
@@ -589,7 +629,7 @@ inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
 inline int gemm_cfg_id(int BM, int BN) { return (BM >= 128 && BN >= 128) ? 0 : (BM == 256 ? 1 : 2); }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = SPLIT ? cdiv(cdiv(a.N, BN) * a.splitk, 8) * 8 * cdiv(a.M, BM) : cdiv(a.M, BM) * cdiv(a.N, BN);
     a.bn_used = BN;
@@ -607,7 +647,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
     constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
-    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS>;
+    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS, CONV>;
     static AttrOnce attr;           // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
@@ -616,11 +656,12 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, s, aa);
     if (prof) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
-        pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
-        pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
+        pf.cfg_of[pf.n] = CONV ? 3 : gemm_cfg_id(BM, BN);       // bucket 3 = implicit-GEMM convolutions
+        pf.flops_of[pf.n] = CONV ? 2.0 * a.M * a.N * a.cTaps * a.cCin : 2.0 * a.M * a.N * a.K;
         const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : (EPI == EPI_ARGMAX ? 4.0 * cdiv(a.N, BN) : a.N);
-        pf.bytes_of[pf.n] = SPLIT ? ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
-                                  : ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
+        const double xelems = CONV ? (double)a.M / std::max(1, a.cHo * a.cWo) * a.cH * a.cW * a.cCin : (double)a.M * a.K;   // the input tensor once
+        pf.bytes_of[pf.n] = SPLIT ? (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
+                                  : (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
                                         (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
         ++pf.n;
     }

@@ -62,14 +62,46 @@ def split_image(img: Image.Image, height: int, copy: bool = True):
     return parts, heights
 
 
+def det_config_from_reference_json(raw: dict):
+    """Map an EfficientViTConfig config.json (surya/detection/model/config.py:12-52) onto DetConfig."""
+    from ..config import DetConfig
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items() if k in DetConfig.__dataclass_fields__}
+    kw.setdefault("num_labels", raw.get("num_labels", len(raw.get("id2label", {})) or 2))
+    return DetConfig(**{**kw, "name": "checkpoint"})
+
+
 class DetectionModelLoader(ModelLoader):
-    """checkpoint: None / config name (synthetic weights) or {"config": DetConfig, "state_dict": ..., "size": int}."""
+    """checkpoint: None / config name (synthetic weights), {"config": DetConfig, "state_dict": ..., "size": int}, or a directory in
+    the reference's on-disk format (surya/detection/loader.py:23-63): config.json (EfficientViTConfig), *.safetensors (the
+    reference's parameter names) and preprocessor_config.json (SegformerImageProcessor: size, image_mean, image_std)."""
 
     def __init__(self, checkpoint=None):
         super().__init__(checkpoint)
         ck = checkpoint
+        self._mean = self._std = None
         if isinstance(ck, dict):
             self._cfg, self._sd, self._size = ck["config"], ck["state_dict"], int(ck.get("size", 1024))
+        elif isinstance(ck, str) and os.path.isdir(ck):
+            import json
+            from safetensors.torch import load_file
+            with open(os.path.join(ck, "config.json")) as f:
+                self._cfg = det_config_from_reference_json(json.load(f))
+            self._sd = {}
+            for fn in sorted(os.listdir(ck)):
+                if fn.endswith(".safetensors"):
+                    self._sd.update(load_file(os.path.join(ck, fn)))
+            if not self._sd:
+                raise FileNotFoundError(f"{ck}: no *.safetensors file")
+            self._size = 1024
+            pp = os.path.join(ck, "preprocessor_config.json")
+            if os.path.exists(pp):
+                with open(pp) as f:
+                    raw = json.load(f)
+                size = raw.get("size") or {}
+                if size.get("height") != size.get("width"):
+                    raise ValueError(f"{pp}: the detector runs on square processor sizes, got {size}")
+                self._size = int(size.get("height", 1024))
+                self._mean, self._std = raw.get("image_mean"), raw.get("image_std")
         else:
             from ..synth import make_det_weights
             self._cfg = det_config(ck if isinstance(ck, str) else settings.SURYA_AMD_DET_CONFIG)
@@ -90,7 +122,12 @@ class DetectionModelLoader(ModelLoader):
                            broadcast_weights=bw)
 
     def processor(self, device=None, dtype=None) -> SegformerImageProcessor:
-        return SegformerImageProcessor({"height": self._size, "width": self._size})
+        p = SegformerImageProcessor({"height": self._size, "width": self._size})
+        if self._mean is not None:
+            p.image_mean = np.asarray(self._mean, np.float32)
+        if self._std is not None:
+            p.image_std = np.asarray(self._std, np.float32)
+        return p
 
 
 class DetectionPredictor(BasePredictor):

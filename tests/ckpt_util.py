@@ -94,3 +94,22 @@ def write_rec_checkpoint(path: str, cfg: RecConfig, sd: dict, special: dict | No
     save_file({k: v.contiguous() for k, v in sd.items() if torch.is_tensor(v)}, os.path.join(path, "model.safetensors"))
     write_tokenizer_files(path)
     return path
+
+
+def write_det_checkpoint(path: str, cfg, sd: dict, size: int = 256) -> str:
+    """Detector directory as the reference reads it (surya/detection/loader.py:23-63): config.json = EfficientViTConfig.to_dict()
+    keys that define the network, model.safetensors, preprocessor_config.json = SegformerImageProcessor's (size, mean, std)."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump({"model_type": "efficientvit", "num_channels": cfg.num_channels, "widths": list(cfg.widths), "depths": list(cfg.depths),
+                   "strides": list(cfg.strides), "head_dim": cfg.head_dim, "layer_norm_eps": cfg.layer_norm_eps,
+                   "decoder_layer_hidden_size": cfg.decoder_layer_hidden_size, "decoder_hidden_size": cfg.decoder_hidden_size,
+                   # (HF keeps the label count as id2label and omits it at the default of 2 labels -- the detector's own count)
+                   **({} if cfg.num_labels == 2 else {"id2label": {str(i): f"LABEL_{i}" for i in range(cfg.num_labels)}})}, f, indent=1)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    with open(os.path.join(path, "preprocessor_config.json"), "w") as f:
+        json.dump({"do_resize": True, "size": {"height": size, "width": size}, "do_rescale": True, "rescale_factor": 1 / 255,
+                   "do_normalize": True, "image_mean": [0.485, 0.456, 0.406], "image_std": [0.229, 0.224, 0.225],
+                   "image_processor_type": "SegformerImageProcessor"}, f, indent=1)
+    return path

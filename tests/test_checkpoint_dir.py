@@ -84,3 +84,38 @@ def test_predictor_from_checkpoint_dir_matches_oracle(hip_lib, ckpt):
         assert [list(t) for t in toks] == ref
     finally:
         settings.RECOGNITION_MAX_TOKENS = None
+
+
+# ------------------------------------------------------------------------------------------------------------------ detector
+@pytest.fixture(scope="module")
+def det_ckpt(tmp_path_factory):
+    from surya_amd.config import det_config
+    from surya_amd.synth import make_det_weights
+    cfg = det_config("DET-TINY")
+    sd = make_det_weights(cfg, 5)
+    return cfg, sd, cu.write_det_checkpoint(str(tmp_path_factory.mktemp("det_ckpt")), cfg, sd, size=256)
+
+
+def test_det_loader_reads_directory(det_ckpt):
+    import dataclasses
+    from surya_amd.detection.predictor import DetectionModelLoader
+    cfg, sd, path = det_ckpt
+    ld = DetectionModelLoader(path)
+    assert dataclasses.replace(ld._cfg, name=cfg.name) == cfg and ld._size == 256
+    assert set(ld._sd) == set(sd) and all(torch.equal(ld._sd[k], sd[k]) for k in sd)
+    p = ld.processor()
+    assert p.size == {"height": 256, "width": 256} and np.allclose(p.image_mean, [0.485, 0.456, 0.406])
+
+
+@pytest.mark.gpu
+def test_detection_predictor_from_checkpoint_dir(hip_lib, det_ckpt):
+    """The directory-loaded detector yields the same boxes as the dict-loaded one (same weights)."""
+    from PIL import Image
+    from surya_amd.detection.predictor import DetectionPredictor
+    from surya_amd.synth import make_pages
+    cfg, sd, path = det_ckpt
+    pages = [Image.fromarray(p) for p in make_pages(2, 256, seed=13)]
+    a = DetectionPredictor(checkpoint=path, dtype=torch.float32)(pages)
+    b = DetectionPredictor(checkpoint={"config": cfg, "state_dict": sd, "size": 256}, dtype=torch.float32)(pages)
+    assert [[x.polygon for x in r.bboxes] for r in a] == [[x.polygon for x in r.bboxes] for r in b]
+    assert sum(len(r.bboxes) for r in a) > 0

@@ -41,20 +41,24 @@ def test_device_boxes_equal_host_on_synthetic_maps(hip_lib, shape, seeds):
     assert n > 0
 
 
-def test_device_boxes_tall_page_and_tall_component(hip_lib):
-    """A page taller than any LDS sizing by page height allowed (round 2 refused H >= 2560) with a component of ~2000 dilated rows
-    (> POST_LDS_ROWS: the workspace-scratch launch) next to ordinary line-shaped ones (the LDS launch), and a normal page after it
-    through the same HipDetPost (the dynamic-LDS attribute must follow the larger request)."""
+def test_device_boxes_tall_page_and_tall_components(hip_lib):
+    """A page taller than any LDS sizing by page height allowed (round 2 refused H >= 2560) with components of all three height
+    classes of post_boxes_kernel: text-line shaped ones (16 KB LDS launch), a ~1500-row vertical rule (whole-LDS launch) and a
+    ~3000-row one (workspace-scratch launch); then a normal page through the same HipDetPost (the dynamic-LDS attribute must
+    follow the larger request)."""
     from surya_amd.detection.model import HipDetPost
     post = HipDetPost()
     h, w = 3200, 512
     m = synth_map(h, w, 41)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    bar = np.exp(-np.maximum(np.abs(xx - 400) / 9.0, np.abs(yy - 1500) / 1000.0) ** 4) * 0.9      # a vertical rule, ~2000 rows
-    m = np.ascontiguousarray(np.maximum(m, bar.astype(np.float32)))
+    for cx, cy, half in ((400, 1600, 1500.0), (120, 900, 750.0)):
+        bar = np.exp(-np.maximum(np.abs(xx - cx) / 9.0, np.abs(yy - cy) / half) ** 4) * 0.9
+        m = np.maximum(m, bar.astype(np.float32))
+    m = np.ascontiguousarray(m)
     ref_boxes, _ = hm.detect_boxes(m, 0.6, 0.35)
-    assert max(np.ptp(np.asarray(b)[:, 1]) for b in ref_boxes) > 1500          # the tall component is there
-    assert _compare(post, [m]) >= 3
+    spans = sorted(np.ptp(np.asarray(b)[:, 1]) for b in ref_boxes)
+    assert spans[-1] > 2700 and 1200 < spans[-2] < 2500                       # both tall components are there
+    assert _compare(post, [m]) >= 4
     assert _compare(post, [synth_map(1024, 1024, 6)]) > 0
 
 

@@ -881,3 +881,41 @@ def test_live_checkpoint_directory_written_by_the_reference(tmp_path):
                 assert b[k][kk] == vv, (k, kk, b[k].get(kk), vv)
         else:
             assert b[k] == v, (k, b.get(k), v)
+
+
+def test_live_detector_checkpoint_directory_written_by_the_reference(tmp_path):
+    """EfficientViTForSemanticSegmentation.save_pretrained + SegformerImageProcessor.save_pretrained (the reference's own writers,
+    surya/detection/loader.py:23-63 reads them back) -> DetectionModelLoader: same configuration, tensors and processor settings; and
+    tests/ckpt_util.write_det_checkpoint agrees with the reference's files on every key it writes."""
+    import dataclasses, json, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ckpt_util as cu
+    ref_shim.install()
+    from surya.detection.model.config import EfficientViTConfig
+    from surya.detection.model.encoderdecoder import EfficientViTForSemanticSegmentation
+    from surya.detection.processor import SegformerImageProcessor
+    from surya_amd.config import det_config
+    from surya_amd.detection.predictor import DetectionModelLoader
+    from surya_amd.synth import make_det_weights
+    c = det_config("DET-TINY")
+    sd = make_det_weights(c, 5)
+    rc = EfficientViTConfig(widths=c.widths, depths=c.depths, head_dim=c.head_dim, decoder_layer_hidden_size=c.decoder_layer_hidden_size,
+                            decoder_hidden_size=c.decoder_hidden_size, num_labels=c.num_labels)
+    m = EfficientViTForSemanticSegmentation(rc).eval()
+    m.load_state_dict(sd, strict=True)
+    path = str(tmp_path / "det_from_reference")
+    m.save_pretrained(path, safe_serialization=True)
+    SegformerImageProcessor(size={"height": 256, "width": 256}).save_pretrained(path)
+    ld = DetectionModelLoader(path)
+    assert dataclasses.replace(ld._cfg, name=c.name) == c and ld._size == 256
+    rsd = m.state_dict()
+    assert set(ld._sd) == set(rsd) and all(torch.equal(ld._sd[k], rsd[k]) for k in rsd)
+    p = ld.processor()
+    import numpy as np
+    rp = SegformerImageProcessor.from_pretrained(path)
+    assert p.size == dict(rp.size) and np.allclose(p.image_mean, rp.image_mean) and np.allclose(p.image_std, rp.image_std)
+    ours = cu.write_det_checkpoint(str(tmp_path / "det_ours"), c, sd, size=256)
+    for fn in ("config.json", "preprocessor_config.json"):
+        a, b = json.load(open(os.path.join(ours, fn))), json.load(open(os.path.join(path, fn)))
+        for k, v in a.items():
+            assert k in b and (b[k] == v or (isinstance(v, float) and abs(b[k] - v) < 1e-12)), (fn, k, b.get(k), v)
