@@ -156,6 +156,7 @@ struct Tuning {
     int split_min_kt = 4;    // at least this many 128-byte K-tiles per slice
     int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
     int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
+    int bigtile_min_k = 0;   // ... only when K >= this (short-K GEMMs are prologue / epilogue bound: two 128x128 workgroups per CU overlap those)
     int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)
 };
 inline Tuning& tuning() { static Tuning t; return t; }

@@ -712,7 +712,7 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         // measured throughput ratio of the two kernels on full rounds ~1.17 (r01 microbench)
         const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
         const double cost256 = (double)cdivl(t256, 256) * 256 * 4 / 1.17, cost128 = (double)cdivl(big, 512) * 512;
-        if (bigtile && t256 >= 256 && cost256 <= cost128) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
+        if (bigtile && a.K >= tuning().bigtile_min_k && t256 >= 256 && cost256 <= cost128) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
     }
     if (big >= 256) {
         if (glds == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);

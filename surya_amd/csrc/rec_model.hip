@@ -1233,7 +1233,7 @@ int surya_set_tuning(const char* key, int value) {
     Tuning& t = tuning();
     struct { const char* k; int* v; } tab[] = {
         {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
-        {"bigtile", &t.bigtile}, {"glds", &t.glds}};
+        {"bigtile", &t.bigtile}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) { *e.v = value; return SA_OK; }
     return SA_ERR_ARG;

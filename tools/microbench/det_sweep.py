@@ -30,9 +30,9 @@ def run(n=8):
     return e0.elapsed_time(e1) / n
 
 
-variants = [dict(), dict(bigtile=0), dict(glds=3), dict(bigtile=0, glds=3)] + [dict(**{k: int(v)}) for k, v in
+variants = [dict(), dict(bigtile=0), dict(bigtile_min_k=320), dict(bigtile_min_k=576), dict(bigtile_min_k=1100), dict(bigtile_min_k=2100)] + [dict(**{k: int(v)}) for k, v in
                                                                                  (a.split("=") for a in sys.argv[1:])]
-base = dict(bigtile=1, glds=2)
+base = dict(bigtile=1, glds=2, bigtile_min_k=0)
 for v in variants:
     for k, val in {**base, **v}.items():
         L.check(lib.surya_set_tuning(k.encode(), C.c_int(val)), k)
