@@ -307,6 +307,55 @@ int surya_det_boxes(const float* heat, long page_stride, int batch, int height, 
                     int max_boxes, float* boxes, float* conf, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Layout model family: Donut-Swin window-attention encoder + ADETR decoder with cross- and self-attention.
+ * Replaces DonutSwinLayoutModel.forward (surya/layout/model/encoder.py:36-80, surya/common/donut/encoder.py) and
+ * SuryaLayoutDecoder.forward (surya/layout/model/decoder.py:96-131, surya/common/adetr/decoder.py) as
+ * LayoutPredictor.batch_layout_detection calls them (surya/layout/__init__.py:95-131): one `encode` per image batch, then one
+ * `decode_step` per box until every image emitted its end token (the per-step host round trip is the reference's own).
+ * Window 8 (64 tokens), head dim 32 in the encoder; image sides a multiple of 4 * 8 * 2^(stages-1).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct surya_layout_config {
+    int32_t img_h, img_w, patch, embed_dim, n_stages;
+    int32_t depths[8], heads[8], kv_heads[8];
+    int32_t window;
+    float enc_eps;                    /* layer_norm_eps of the Swin blocks */
+    int32_t encoder_length;           /* rows of the learned position_embeddings */
+    int32_t dec_layers, dec_hidden, dec_inter, dec_heads, dec_kv_heads;
+    int32_t vocab, label_count, bbox_size;
+    float rms_eps, ln_eps;
+    int32_t max_batch, max_boxes, dtype;
+} surya_layout_config;
+
+/* Weight table (device pointers, compute dtype unless noted; Linear weights [out, in]):
+ *   globals SA_LW_*; PATCH_W is [embed_dim][64] = the Conv2d weight flattened (c, ky, kx) and zero padded; DEC_INVFREQ fp32 [hd / 2];
+ *   DEC_ZERO_BIAS = zeros [(heads + 2 kv_heads) * hd] (the ADETR attention has no qkv bias; the fused decode-attention kernel takes one);
+ *   EMB_TABLES = 15 tables in the order w, h, cx, cy, xskew, yskew, x1, y1, x2, y2, x3, y3, x4, y4 ([vocab][hidden]), label ([label_count][hidden]);
+ *   per stage SA_LS_* (SINCOS = the stage's 2-D sin-cos table [tokens][dim] built as the reference builds it; MERGE_* of the last stage
+ *   are ignored), then per block SA_LB_* (QKV fused q | k | v rows; RELBIAS fp32 [heads][64][64] = relative_position_bias_table gathered
+ *   through relative_position_index, rounded to the compute dtype first); then per decoder layer SA_LD_* (CKV_W = cross k | v rows fused,
+ *   QKV_W = self q | k | v fused, GU_W = gate / up rows interleaved g0, u0, g1, u1 ...). */
+enum { SA_LW_PATCH_W = 0, SA_LW_PATCH_B, SA_LW_EMB_LN_W, SA_LW_EMB_LN_B, SA_LW_POS_EMB, SA_LW_DEC_FNORM, SA_LW_DEC_LN_W, SA_LW_DEC_LN_B,
+       SA_LW_DEC_LM_W, SA_LW_DEC_BB_W, SA_LW_DEC_BB_B, SA_LW_DEC_INVFREQ, SA_LW_DEC_ZERO_BIAS, SA_LW_EMB_TABLES, SA_LW_GLOBALS = SA_LW_EMB_TABLES + 15 };
+enum { SA_LS_SINCOS = 0, SA_LS_MERGE_NORM_W, SA_LS_MERGE_NORM_B, SA_LS_MERGE_RED_W, SA_LS_COUNT };
+enum { SA_LB_LN1_W = 0, SA_LB_LN1_B, SA_LB_QKV_W, SA_LB_QKV_B, SA_LB_RELBIAS, SA_LB_PROJ_W, SA_LB_PROJ_B, SA_LB_LN2_W, SA_LB_LN2_B, SA_LB_FC1_W,
+       SA_LB_FC1_B, SA_LB_FC2_W, SA_LB_FC2_B, SA_LB_COUNT };
+enum { SA_LD_CNORM = 0, SA_LD_CQ_W, SA_LD_CKV_W, SA_LD_CO_W, SA_LD_CO_B, SA_LD_TNORM, SA_LD_QKV_W, SA_LD_TO_W, SA_LD_TO_B, SA_LD_MNORM, SA_LD_GU_W,
+       SA_LD_DOWN_W, SA_LD_COUNT };
+
+typedef struct surya_layout surya_layout;
+int surya_layout_create(const surya_layout_config* cfg, const void* const* weights, int n_weights, surya_layout** out);
+int surya_layout_destroy(surya_layout* h);
+/* pixel_values: device fp32 [batch, 3, img_h, img_w] (rescaled + normalised by the processor). Runs the encoder, keeps its output
+ * inside the handle and projects every decoder layer's cross-attention keys / values; resets the self-attention caches. Enqueue only. */
+int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, void* stream);
+/* One decoder token per image at cache position `position` (0 = the start token): boxes host int32 [batch][7] = (cx, cy, w, h, xskew,
+ * yskew, label) as the reference feeds them back; class_logits host fp32 [batch][label_count], bbox host fp32 [batch][6] (after the
+ * sigmoid). Synchronises the stream (the reference moves both to the host after every step as well). */
+int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream);
+/* Test hook: encoder output [batch * tokens, hidden] of the last encode (device, compute dtype). */
+int surya_layout_encoder_states(surya_layout* h, void* out, int batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): when enabled every GEMM launch is bracketed by hipEvents on its own
  * stream. surya_prof_read syncs the device and returns, per bucket (0: 128x128 GEMM, 1: tall 256-row GEMM tiles, 2: smaller GEMM tiles,
  * 3: implicit-GEMM convolutions),

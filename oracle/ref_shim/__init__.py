@@ -78,3 +78,47 @@ def import_recognition():
     finally:
         builtins.__import__ = orig
     return sr
+
+
+def import_submodule(modname: str):
+    """Import ONE reference submodule without running its package's __init__ (several of those import names that transformers 5.x
+    dropped, or cv2 / pypdfium2 users): the parent packages are registered as bare namespaces pointing at the reference tree."""
+    import importlib
+    import types
+    install()
+    importlib.import_module("surya")
+    parts = modname.split(".")
+    for i in range(2, len(parts)):
+        pkg = ".".join(parts[:i])
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, *pkg.split("."))]
+            sys.modules[pkg] = m
+    return importlib.import_module(modname)
+
+
+def install_layout():
+    """What the layout / table-rec model family needs on top of install(): names transformers 5.x removed from pytorch_utils (only
+    used by head pruning, never at inference)."""
+    install()
+    import transformers.pytorch_utils as pu
+    if not hasattr(pu, "find_pruneable_heads_and_indices"):
+        def _no_pruning(*a, **k):
+            raise NotImplementedError("head pruning is not available under the shim")
+        pu.find_pruneable_heads_and_indices = _no_pruning
+    from transformers.modeling_utils import PreTrainedModel
+    if not hasattr(PreTrainedModel, "get_head_mask"):                 # removed in 5.x; the encoder calls it with head_mask=None
+        PreTrainedModel.get_head_mask = lambda self, head_mask, num_hidden_layers, *a, **k: [None] * num_hidden_layers
+    return True
+
+
+def import_layout_modules():
+    """(config, encoder, decoder) modules of the reference's layout model with the transformers-5.x incompatibilities patched:
+    SuryaADETRDecoderPreTrainedModel.tie_weights takes no arguments there, transformers now passes one."""
+    install_layout()
+    cfgm = import_submodule("surya.layout.model.config")
+    encm = import_submodule("surya.layout.model.encoder")
+    adetr = import_submodule("surya.common.adetr.decoder")
+    adetr.SuryaADETRDecoderPreTrainedModel.tie_weights = lambda self, *a, **k: None
+    decm = import_submodule("surya.layout.model.decoder")
+    return cfgm, encm, decm

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsurya_amd.so")
-SOURCES = ["rec_model.hip", "det_model.hip"]
+SOURCES = ["rec_model.hip", "det_model.hip", "layout_model.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 
 

@@ -33,7 +33,8 @@
 
 namespace sa {
 
-enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6, EPI_ROPE = 7 };
+enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6, EPI_ROPE = 7,
+               EPI_GEGLU = 8 /* gelu_tanh(gate) * up, rows interleaved like SWIGLU (ADETR decoder MLP, adetr/decoder.py:331-344) */ };
 
 template <typename TI, typename TO>
 struct GemmArgs {
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     // loop-`continue` conditions: hipcc then branches around every load and waits vmcnt(0) behind each -- 32 dependent L2 round
     // trips for the bias of a 256x256 tile and 16 for its residual (r03 ISA), ~15-20 us of a ~50 us tile at K = 1280.
     __syncthreads();
-    constexpr int OW = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;         // output columns of this tile
+    constexpr bool GLU = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT;     // gated epilogues halve the output width
+    constexpr int OW = GLU ? BN / 2 : BN;                                    // output columns of this tile
     using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
     constexpr int ROWB = OW * (int)sizeof(TS), CPR = ROWB / 16;              // bytes and 16-byte chunks per tile row
     constexpr int XM = CPR >= 8 ? 7 : CPR - 1;                               // chunk XOR mask (conflict-free b128 writes)
@@ -517,11 +519,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                         v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
                     }
                 }
-                if constexpr (EPI == EPI_SWIGLU && !SPLIT) {
+                if constexpr (GLU) {
                     // weight rows interleaved (gate_j, up_j): columns ncol..+3 = g0,u0,g1,u1 -> outputs ncol/2, ncol/2+1
                     const int boff = (ncol >> 1) * (int)sizeof(TS);
                     TS* dst = reinterpret_cast<TS*>(smem + row * ROWB + ((((boff >> 4) ^ (row & XM)) << 4) | (boff & 15)));
-                    store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                    if constexpr (EPI == EPI_GEGLU) {
+                        // the reference rounds gate and up to the storage dtype, applies gelu there, then multiplies (two Linear outputs)
+                        const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
+                        store2(dst, g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
+                    } else {
+                        store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                    }
                 } else {
                     const int boff = ncol * (int)sizeof(TS);
                     TS* dst = reinterpret_cast<TS*>(smem + row * ROWB + ((((boff >> 4) ^ (row & XM)) << 4) | (boff & 15)));
@@ -571,8 +579,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         return;
     }
     constexpr int EPC = 16 / (int)sizeof(TS);                                // elements per 16-byte chunk
-    const int n_out = (EPI == EPI_SWIGLU && !SPLIT) ? p.N / 2 : p.N;
-    const int n0_out = (EPI == EPI_SWIGLU && !SPLIT) ? n0 / 2 : n0;
+    const int n_out = GLU ? p.N / 2 : p.N;
+    const int n0_out = GLU ? n0 / 2 : n0;
     constexpr int ITERS = (BM * CPR + NT - 1) / NT;                          // 16-byte chunks per thread
     [[maybe_unused]] u32x4 res[ITERS];
     if constexpr (EPI == EPI_RESIDUAL && !SPLIT) {                           // the whole tile's residual in one batch of loads
@@ -643,7 +651,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
             tiles = cdiv(tm * tn, 8 * GRP) * 8 * GRP;
         }
     }
-    constexpr size_t out_w = (EPI == EPI_SWIGLU && !SPLIT) ? BN / 2 : BN;
+    constexpr size_t out_w = ((EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT) ? BN / 2 : BN;
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
     constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
@@ -658,7 +666,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
         pf.cfg_of[pf.n] = CONV ? 3 : gemm_cfg_id(BM, BN);       // bucket 3 = implicit-GEMM convolutions
         pf.flops_of[pf.n] = CONV ? 2.0 * a.M * a.N * a.cTaps * a.cCin : 2.0 * a.M * a.N * a.K;
-        const double outn = (EPI == EPI_SWIGLU) ? a.N / 2 : (EPI == EPI_ARGMAX ? 4.0 * cdiv(a.N, BN) : a.N);
+        const double outn = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : (EPI == EPI_ARGMAX ? 4.0 * cdiv(a.N, BN) : a.N);
         const double xelems = CONV ? (double)a.M / std::max(1, a.cHo * a.cWo) * a.cH * a.cW * a.cCin : (double)a.M * a.K;   // the input tensor once
         pf.bytes_of[pf.n] = SPLIT ? (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
                                   : (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
@@ -675,7 +683,7 @@ template <typename TI, typename TO, int EPI>
 static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return SA_OK;
     {   // rows are stored in 16-byte chunks: output width (N, or N/2 after SwiGLU) must be a multiple of 16 bytes of TO
-        const int n_out = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
+        const int n_out = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : a.N;
         if (a.K % Ty<TI>::KE != 0 || a.N % 4 != 0 || n_out % (16 / (int)sizeof(TO)) != 0 || a.ldc % (16 / (int)sizeof(TO)) != 0)
             return SA_ERR_SHAPE;
     }

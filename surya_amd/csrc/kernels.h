@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, l
 // i with i + D/2; fp32 math. The rotation itself happens in the qkv GEMM's epilogue (EPI_ROPE, gemm.h); this kernel builds its
 // (cos, sin) table tab[p * D/2 + i] once per encoder pass (the first version ran a separate in-place kernel per layer:
 // 8 x 165 us per recognition step).
-__global__ void rope_vision_table_kernel(const int* __restrict__ pos_hw, const float* __restrict__ inv_freq, float2* __restrict__ tab,
+static __global__ void rope_vision_table_kernel(const int* __restrict__ pos_hw, const float* __restrict__ inv_freq, float2* __restrict__ tab,
                                          int P, int D) {
     const int half = D / 2, quarter = D / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,381 @@
+// Layout model family on MI355X: Donut-Swin window-attention encoder + ADETR decoder with cross- and
+// self-attention, behind surya_layout_* of include/surya_amd.h. Replaces DonutSwinLayoutModel.forward
+// (surya/layout/model/encoder.py:36-80, surya/common/donut/encoder.py) and SuryaLayoutDecoder.forward
+// (surya/layout/model/decoder.py:96-131, surya/common/adetr/decoder.py) as LayoutPredictor calls them
+// (surya/layout/__init__.py:95-131).
+//
+// Design notes (vs the PyTorch path):
+//   * window partition, cyclic shift and their inverses are ONE permutation table per (stage, shift): LayerNorm writes its rows
+//     straight into window order, the projection output is added back through the same table -- no roll / view / permute passes;
+//   * the shift mask is computed from the window's position (only the last window row / column is cut), the relative position
+//     bias is gathered once at load time into [head][64][64];
+//   * cross-attention K / V of the encoder states are projected once per batch in `encode` (the reference caches them at the
+//     first decoder call); the decode step's self-attention reuses the recogniser's fused split-K-combine + RoPE + KV-append +
+//     attention kernel (decode_attn.h) on a [layer][image][kv_head][max_boxes][d] cache;
+//   * every dense layer runs on gemm.h's MFMA tiles (patch embedding = GEMM over patch rows, merge reduction, GeGLU MLP).
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/surya_amd.h"
+#include "gemm.h"
+#include "kernels.h"
+#include "decode_attn.h"
+#include "layout_kernels.h"
+
+namespace sa {
+
+struct LayoutBase {
+    virtual ~LayoutBase() {}
+    virtual int encode(const float* pixels, int B, hipStream_t s) = 0;
+    virtual int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) = 0;
+    virtual int encoder_states(void* out, int B, hipStream_t s) = 0;
+};
+
+static size_t lalign(size_t v) { return (v + 255) & ~(size_t)255; }
+
+__global__ void fill_int_kernel(int* p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+template <typename T>
+struct LayoutModel : LayoutBase {
+    surya_layout_config c;
+    std::vector<const void*> w;
+    std::vector<int> stage_base;                 // weight-table index of each stage's first entry
+    int dec_base = 0;
+    char* arena = nullptr;
+    // encoder workspaces
+    T *patch_rows, *x, *hbuf, *qkv, *att, *mlp;
+    std::vector<int*> perm;                      // [stage * 2 + (shift > 0)] device permutation tables (token -> window-order row)
+    // decoder
+    T *ckv;                                      // [layer][B][Lk][2 * kvd]
+    T *kcache, *vcache;                          // [layer][B][nkv][Tmax][hd]
+    T *dx, *dh, *dq, *dattn, *dres, *dmlp;
+    float* part;
+    float2* rope_cs;
+    int *boxes_dev, *slots_dev, *len_dev;
+    float *cls_dev, *box_dev;
+    const T** tabs_dev = nullptr;                // 15 embedding table pointers
+    char* pinned = nullptr;
+    int Lk = 0, enc_rows_final = 0, batch_encoded = 0;
+
+    const T* W(int i) const { return reinterpret_cast<const T*>(w[i]); }
+    int gh() const { return c.img_h / c.patch; }
+    int gw() const { return c.img_w / c.patch; }
+    int kvd() const { return c.dec_kv_heads * (c.dec_hidden / c.dec_heads); }
+    int hd() const { return c.dec_hidden / c.dec_heads; }
+
+    int init(const surya_layout_config& cfg, const void* const* weights, int n) {
+        c = cfg;
+        w.assign(weights, weights + n);
+        int idx = SA_LW_GLOBALS;
+        for (int s = 0; s < c.n_stages; ++s) { stage_base.push_back(idx); idx += SA_LS_COUNT + c.depths[s] * SA_LB_COUNT; }
+        dec_base = idx;
+        if (n != dec_base + c.dec_layers * SA_LD_COUNT) return SA_ERR_ARG;
+        const size_t B = c.max_batch, rows0 = B * gh() * gw(), E = c.embed_dim;
+        int fh = gh(), fw = gw();
+        for (int s = 1; s < c.n_stages; ++s) { fh /= 2; fw /= 2; }
+        Lk = fh * fw;
+        if (Lk > c.encoder_length) return SA_ERR_SHAPE;
+        const size_t He = E << (c.n_stages - 1), Hd = c.dec_hidden, I = c.dec_inter, qd = Hd, kv = kvd();
+        const size_t qkv_d = qd + 2 * kv;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = lalign(off + bytes); return o; };
+        const size_t o_patch = take(rows0 * 64 * sizeof(T)), o_x = take(rows0 * E * sizeof(T)), o_h = take(rows0 * E * sizeof(T));
+        const size_t o_qkv = take(rows0 * 3 * E * sizeof(T)), o_att = take(rows0 * E * sizeof(T)), o_mlp = take(rows0 * 4 * E * sizeof(T));
+        const size_t o_ckv = take((size_t)c.dec_layers * B * Lk * 2 * kv * sizeof(T));
+        const size_t kv_elems = (size_t)c.dec_layers * B * c.dec_kv_heads * c.max_boxes * hd();
+        const size_t o_k = take(kv_elems * sizeof(T)), o_v = take(kv_elems * sizeof(T));
+        const size_t o_dx = take(B * Hd * sizeof(T)), o_dh = take(B * Hd * sizeof(T)), o_dq = take(B * qd * sizeof(T));
+        const size_t o_da = take(B * qd * sizeof(T)), o_dr = take(B * Hd * sizeof(T)), o_dm = take(B * I * sizeof(T));
+        const size_t o_part = take((size_t)8 * B * std::max(qkv_d, Hd) * sizeof(float));
+        const size_t o_rope = take((size_t)c.max_boxes * (hd() / 2) * sizeof(float2));
+        const size_t o_boxes = take(B * 7 * sizeof(int)), o_slots = take(B * sizeof(int)), o_len = take(B * sizeof(int));
+        const size_t o_cls = take(B * c.label_count * sizeof(float)), o_box = take(B * 6 * sizeof(float));
+        const size_t o_tabs = take(15 * sizeof(void*));
+        // permutation tables: two per stage
+        std::vector<size_t> o_perm;
+        {
+            int h = gh(), wd = gw();
+            for (int s = 0; s < c.n_stages; ++s) {
+                o_perm.push_back(take((size_t)h * wd * sizeof(int)));
+                o_perm.push_back(take((size_t)h * wd * sizeof(int)));
+                h /= 2; wd /= 2;
+            }
+        }
+        SA_HIP(hipMalloc((void**)&arena, off));
+        char* b = arena;
+        patch_rows = (T*)(b + o_patch); x = (T*)(b + o_x); hbuf = (T*)(b + o_h); qkv = (T*)(b + o_qkv); att = (T*)(b + o_att); mlp = (T*)(b + o_mlp);
+        ckv = (T*)(b + o_ckv); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
+        dx = (T*)(b + o_dx); dh = (T*)(b + o_dh); dq = (T*)(b + o_dq); dattn = (T*)(b + o_da); dres = (T*)(b + o_dr); dmlp = (T*)(b + o_dm);
+        part = (float*)(b + o_part); rope_cs = (float2*)(b + o_rope);
+        boxes_dev = (int*)(b + o_boxes); slots_dev = (int*)(b + o_slots); len_dev = (int*)(b + o_len);
+        cls_dev = (float*)(b + o_cls); box_dev = (float*)(b + o_box); tabs_dev = (const T**)(b + o_tabs);
+        {   // window-order row of every token, per stage and shift (window_partition after torch.roll(-shift), donut/encoder.py:624-636)
+            int h = gh(), wd = gw();
+            for (int s = 0; s < c.n_stages; ++s) {
+                const int ws = c.window;
+                if (h % 2 && s + 1 < c.n_stages) return SA_ERR_SHAPE;
+                const bool part_ok = std::min(h, wd) > ws;                 // else one window = the whole map, no shift (:551-559)
+                const int wse = part_ok ? ws : std::min(h, wd);
+                if (wse != ws || h % ws || wd % ws) return SA_ERR_UNSUPPORTED;     // padded / sub-window resolutions are not built
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int shift = (sh && part_ok) ? ws / 2 : 0;
+                    std::vector<int> p((size_t)h * wd);
+                    for (int y = 0; y < h; ++y)
+                        for (int xx = 0; xx < wd; ++xx) {
+                            const int ys = ((y - shift) % h + h) % h, xs = ((xx - shift) % wd + wd) % wd;
+                            p[(size_t)y * wd + xx] = ((ys / ws) * (wd / ws) + xs / ws) * ws * ws + (ys % ws) * ws + xs % ws;
+                        }
+                    int* d = (int*)(b + o_perm[2 * s + sh]);
+                    SA_HIP(hipMemcpy(d, p.data(), p.size() * sizeof(int), hipMemcpyHostToDevice));
+                    perm.push_back(d);
+                }
+                h /= 2; wd /= 2;
+            }
+        }
+        {
+            std::vector<int> ident(B);
+            for (size_t i = 0; i < B; ++i) ident[i] = (int)i;
+            SA_HIP(hipMemcpy(slots_dev, ident.data(), B * sizeof(int), hipMemcpyHostToDevice));
+            const void* tabs[15];
+            for (int i = 0; i < 15; ++i) tabs[i] = w[SA_LW_EMB_TABLES + i];
+            SA_HIP(hipMemcpy((void*)tabs_dev, tabs, sizeof(tabs), hipMemcpyHostToDevice));
+            const int half = hd() / 2, nn = c.max_boxes * half;
+            hipLaunchKernelGGL(rope_table_kernel<T>, dim3(cdiv(nn, 256)), dim3(256), 0, 0, reinterpret_cast<const float*>(w[SA_LW_DEC_INVFREQ]),
+                               rope_cs, c.max_boxes, half);
+            SA_HIP(hipGetLastError());
+        }
+        SA_HIP(hipHostMalloc((void**)&pinned, B * (7 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
+        SA_HIP(hipDeviceSynchronize());
+        return SA_OK;
+    }
+    ~LayoutModel() override {
+        if (arena) (void)hipFree(arena);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+
+    template <int EPI>
+    int gemm(const T* X, long ldx, const T* Wt, long ldw, T* C, long ldc, const T* bias, const T* R, long ldr, int M, int N, int K,
+             hipStream_t s) {
+        GemmArgs<T, T> a{X, ldx, Wt, ldw, C, ldc, bias, R, ldr, M, N, K};
+        return launch_gemm<T, T, EPI>(a, s);
+    }
+    int layernorm(const T* in, int wi, int bi, T* out, const int* pm, long rows, int rpi, int C, float eps, hipStream_t s) {
+        hipLaunchKernelGGL(lay::layernorm_kernel<T>, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, s, in, W(wi), W(bi), out, pm, rows, rpi, C, eps);
+        return (int)hipGetLastError();
+    }
+
+    int encode(const float* pixels, int B, hipStream_t s) override {
+        if (B <= 0 || B > c.max_batch) return SA_ERR_ARG;
+        int rc;
+        int h = gh(), wd = gw(), dim = c.embed_dim;
+        long rows = (long)B * h * wd;
+        {
+            const long total = rows * 64;
+            hipLaunchKernelGGL(lay::patchify_kernel<T>, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, pixels, patch_rows, B, 3, c.img_h,
+                               c.img_w, c.patch, 64);
+            if ((rc = gemm<EPI_BIAS>(patch_rows, 64, W(SA_LW_PATCH_W), 64, hbuf, dim, W(SA_LW_PATCH_B), nullptr, 0, (int)rows, dim, 64, s))) return rc;
+            if ((rc = layernorm(hbuf, SA_LW_EMB_LN_W, SA_LW_EMB_LN_B, x, nullptr, rows, h * wd, dim, 1e-5f, s))) return rc;
+        }
+        for (int st = 0; st < c.n_stages; ++st) {
+            const int sb = stage_base[st], nh = c.heads[st], nkv = c.kv_heads[st], ws = c.window;
+            if (dim / nh != 32) return SA_ERR_UNSUPPORTED;
+            const int rpi = h * wd;
+            {
+                const long n4 = rows * (dim / 4);
+                hipLaunchKernelGGL(lay::add_rows_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, W(sb + SA_LS_SINCOS), rows, rpi, dim);
+            }
+            const int qkv_n = (nh + 2 * nkv) * 32;
+            for (int bi = 0; bi < c.depths[st]; ++bi) {
+                const int wb = sb + SA_LS_COUNT + bi * SA_LB_COUNT;
+                const bool shifted = (bi % 2 == 1) && std::min(h, wd) > ws;
+                const int* pm = perm[2 * st + (shifted ? 1 : 0)];
+                if ((rc = layernorm(x, wb + SA_LB_LN1_W, wb + SA_LB_LN1_B, hbuf, pm, rows, rpi, dim, c.enc_eps, s))) return rc;
+                if ((rc = gemm<EPI_BIAS>(hbuf, dim, W(wb + SA_LB_QKV_W), dim, qkv, qkv_n, W(wb + SA_LB_QKV_B), nullptr, 0, (int)rows, qkv_n, dim, s)))
+                    return rc;
+                const int nwx = wd / ws, nwy = h / ws;
+                hipLaunchKernelGGL(lay::swin_window_attn_kernel<T>, dim3((unsigned)(rows / 64), nh), dim3(256), 0, s, qkv,
+                                   reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
+                if ((rc = gemm<EPI_BIAS>(att, dim, W(wb + SA_LB_PROJ_W), dim, hbuf, dim, W(wb + SA_LB_PROJ_B), nullptr, 0, (int)rows, dim, dim, s)))
+                    return rc;
+                {
+                    const long n4 = rows * (dim / 4);
+                    hipLaunchKernelGGL(lay::gather_add_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, hbuf, pm, rows, rpi, dim);
+                }
+                if ((rc = layernorm(x, wb + SA_LB_LN2_W, wb + SA_LB_LN2_B, hbuf, nullptr, rows, rpi, dim, c.enc_eps, s))) return rc;
+                if ((rc = gemm<EPI_GELU>(hbuf, dim, W(wb + SA_LB_FC1_W), dim, mlp, 4 * dim, W(wb + SA_LB_FC1_B), nullptr, 0, (int)rows, 4 * dim, dim, s)))
+                    return rc;
+                if ((rc = gemm<EPI_RESIDUAL>(mlp, 4 * dim, W(wb + SA_LB_FC2_W), 4 * dim, x, dim, W(wb + SA_LB_FC2_B), x, dim, (int)rows, dim, 4 * dim,
+                                             s))) return rc;
+            }
+            if (st + 1 < c.n_stages) {
+                const long orows = rows / 4;
+                hipLaunchKernelGGL(lay::merge_ln_kernel<T>, dim3((unsigned)cdivl(orows, 4)), dim3(256), 0, s, x, W(sb + SA_LS_MERGE_NORM_W),
+                                   W(sb + SA_LS_MERGE_NORM_B), mlp, B, h, wd, dim, 1e-5f);
+                if ((rc = gemm<EPI_BIAS>(mlp, 4 * dim, W(sb + SA_LS_MERGE_RED_W), 4 * dim, x, 2 * dim, nullptr, nullptr, 0, (int)orows, 2 * dim,
+                                         4 * dim, s))) return rc;
+                rows = orows; h /= 2; wd /= 2; dim *= 2;
+            }
+        }
+        {
+            const long n4 = rows * (dim / 4);
+            hipLaunchKernelGGL(lay::add_rows_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, W(SA_LW_POS_EMB), rows, h * wd, dim);
+        }
+        enc_rows_final = (int)rows;
+        batch_encoded = B;
+        // cross-attention keys / values of every decoder layer (adetr/decoder.py:167-173: projected once, then cached)
+        const int kv2 = 2 * kvd();
+        for (int l = 0; l < c.dec_layers; ++l) {
+            const int lb = dec_base + l * SA_LD_COUNT;
+            T* dst = ckv + (size_t)l * c.max_batch * Lk * kv2;
+            if ((rc = gemm<EPI_BIAS>(x, dim, W(lb + SA_LD_CKV_W), dim, dst, kv2, nullptr, nullptr, 0, (int)rows, kv2, dim, s))) return rc;
+        }
+        return (int)hipGetLastError();
+    }
+
+    int encoder_states(void* out, int B, hipStream_t s) override {
+        if (B != batch_encoded) return SA_ERR_STATE;
+        const size_t He = (size_t)c.embed_dim << (c.n_stages - 1);
+        SA_HIP(hipMemcpyAsync(out, x, (size_t)enc_rows_final * He * sizeof(T), hipMemcpyDeviceToDevice, s));
+        return SA_OK;
+    }
+
+    int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) override {
+        if (B != batch_encoded) return SA_ERR_STATE;
+        if (pos < 0 || pos >= c.max_boxes) return SA_ERR_ARG;
+        const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
+        const int qkv_d = Hd + 2 * kv, He = c.embed_dim << (c.n_stages - 1);
+        int rc;
+        int* hb = reinterpret_cast<int*>(pinned);
+        memcpy(hb, boxes, (size_t)B * 7 * sizeof(int));
+        SA_HIP(hipMemcpyAsync(boxes_dev, hb, (size_t)B * 7 * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, len_dev, pos, B);
+        hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.bbox_size, c.vocab, c.label_count);
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t layer_kv = (size_t)c.max_batch * nkv * c.max_boxes * d;
+        for (int l = 0; l < c.dec_layers; ++l) {
+            const int lb = dec_base + l * SA_LD_COUNT;
+            // cross attention (double residual flow, adetr/decoder.py:430-457): cross = o(attn(norm(x))) + x
+            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dx, W(lb + SA_LD_CNORM), dh, B, Hd, c.rms_eps);
+            if ((rc = gemm<EPI_BIAS>(dh, Hd, W(lb + SA_LD_CQ_W), Hd, dq, Hd, nullptr, nullptr, 0, B, Hd, Hd, s))) return rc;
+            {
+                const T* kvp = ckv + (size_t)l * c.max_batch * Lk * 2 * kv;
+                const size_t lds = (size_t)(nq / nkv) * Lk * 4 + (size_t)(nq / nkv) * d * 4;
+                dim3 grid(B, nkv);
+                if (d == 64) hipLaunchKernelGGL((lay::cross_attn_decode_kernel<T, 64>), grid, dim3(256), lds, s, dq, kvp, dattn, nq, nkv, Lk, scale);
+                else if (d == 32) hipLaunchKernelGGL((lay::cross_attn_decode_kernel<T, 32>), grid, dim3(256), lds, s, dq, kvp, dattn, nq, nkv, Lk, scale);
+                else return SA_ERR_UNSUPPORTED;
+            }
+            if ((rc = gemm<EPI_RESIDUAL>(dattn, Hd, W(lb + SA_LD_CO_W), Hd, dres, Hd, W(lb + SA_LD_CO_B), dx, Hd, B, Hd, Hd, s))) return rc;
+            // self attention on norm(cross); residual = o(attn) + RAW layer input
+            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dres, W(lb + SA_LD_TNORM), dh, B, Hd, c.rms_eps);
+            {
+                GemmArgs<T, T> a{dh, Hd, W(lb + SA_LD_QKV_W), Hd, nullptr, 0, nullptr, nullptr, 0, B, qkv_d, Hd, 1, part};
+                if ((rc = launch_gemm_splitk<T>(a, s))) return rc;
+                const int S = a.splitk, G = nq / nkv;
+                dim3 grid(B, nkv), block(256);
+                T* kc = kcache + (size_t)l * layer_kv;
+                T* vc = vcache + (size_t)l * layer_kv;
+#define SA_LAY_DEC(KERN, LDS, ...)                                                                                                  \
+    {                                                                                                                               \
+        auto kern = KERN;                                                                                                           \
+        static AttrOnce attr;                                                                                                       \
+        attr.ensure(kern, LDS);                                                                                                     \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, part, S, W(SA_LW_DEC_ZERO_BIAS), dattn, kc, vc, slots_dev, len_dev, rope_cs, nq, \
+                           nkv, c.max_boxes, scale, ##__VA_ARGS__);                                                                \
+    }
+                bool done = false;
+                if constexpr (std::is_same<T, bf16_t>::value) {
+                    done = true;
+                    if (d == 64 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<64, 8>), (decode_attn_flash_lds<64, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                    else if (d == 32 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<32, 8>), (decode_attn_flash_lds<32, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                    else done = false;
+                }
+                if (!done) {
+                    if (d == 64 && G <= 8) SA_LAY_DEC((decode_attn_mfma_kernel<T, 64, 8>), (decode_attn_mfma_lds<T, 64, 8>()))
+                    else if (d == 32 && G <= 8) SA_LAY_DEC((decode_attn_mfma_kernel<T, 32, 8>), (decode_attn_mfma_lds<T, 32, 8>()))
+                    else return SA_ERR_UNSUPPORTED;
+                }
+#undef SA_LAY_DEC
+            }
+            if ((rc = gemm<EPI_RESIDUAL>(dattn, Hd, W(lb + SA_LD_TO_W), Hd, dres, Hd, W(lb + SA_LD_TO_B), dx, Hd, B, Hd, Hd, s))) return rc;
+            // MLP: x = down(gelu_tanh(gate(n)) * up(n)) + residual
+            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dres, W(lb + SA_LD_MNORM), dh, B, Hd, c.rms_eps);
+            if ((rc = gemm<EPI_GEGLU>(dh, Hd, W(lb + SA_LD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, B, 2 * I, Hd, s))) return rc;
+            if ((rc = gemm<EPI_RESIDUAL>(dmlp, I, W(lb + SA_LD_DOWN_W), I, dx, Hd, nullptr, dres, Hd, B, Hd, I, s))) return rc;
+        }
+        hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
+                           W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd, c.label_count,
+                           c.rms_eps, c.ln_eps);
+        if ((rc = (int)hipGetLastError())) return rc;
+        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * 7 * sizeof(int));
+        float* hbx = hc + (size_t)c.max_batch * c.label_count;
+        SA_HIP(hipMemcpyAsync(hc, cls_dev, (size_t)B * c.label_count * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(hbx, box_dev, (size_t)B * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipStreamSynchronize(s));
+        memcpy(cls, hc, (size_t)B * c.label_count * sizeof(float));
+        memcpy(box, hbx, (size_t)B * 6 * sizeof(float));
+        return SA_OK;
+    }
+};
+
+}  // namespace sa
+
+using namespace sa;
+struct surya_layout { std::unique_ptr<LayoutBase> impl; };
+
+extern "C" {
+
+int surya_layout_create(const surya_layout_config* cfg, const void* const* weights, int n_weights, surya_layout** out) {
+    if (!cfg || !weights || !out) return SA_ERR_ARG;
+    if (cfg->n_stages < 1 || cfg->n_stages > 8 || cfg->patch * cfg->patch * 3 > 64 || cfg->embed_dim % 64 || cfg->window != 8) return SA_ERR_UNSUPPORTED;
+    if (cfg->img_h % cfg->patch || cfg->img_w % cfg->patch || cfg->dec_hidden % 64 || cfg->dec_inter % 64 || cfg->dec_heads % cfg->dec_kv_heads)
+        return SA_ERR_SHAPE;
+    if (cfg->max_batch <= 0 || cfg->max_boxes <= 0 || cfg->label_count <= 0) return SA_ERR_ARG;
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) return SA_ERR_ARG;
+    auto* h = new surya_layout();
+    int rc;
+    if (cfg->dtype == SA_DTYPE_F32) {
+        auto m = std::make_unique<LayoutModel<float>>();
+        rc = m->init(*cfg, weights, n_weights);
+        h->impl = std::move(m);
+    } else if (cfg->dtype == SA_DTYPE_BF16) {
+        auto m = std::make_unique<LayoutModel<bf16_t>>();
+        rc = m->init(*cfg, weights, n_weights);
+        h->impl = std::move(m);
+    } else {
+        rc = SA_ERR_UNSUPPORTED;
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return SA_OK;
+}
+
+int surya_layout_destroy(surya_layout* h) {
+    if (!h) return SA_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    delete h;
+    return SA_OK;
+}
+
+int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, void* stream) {
+    if (!h || !pixel_values) return SA_ERR_ARG;
+    return h->impl->encode(pixel_values, batch, (hipStream_t)stream);
+}
+
+int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream) {
+    if (!h || !boxes || !class_logits || !bbox) return SA_ERR_ARG;
+    return h->impl->decode_step(boxes, batch, position, class_logits, bbox, (hipStream_t)stream);
+}
+
+int surya_layout_encoder_states(surya_layout* h, void* out, int batch, void* stream) {
+    if (!h || !out) return SA_ERR_ARG;
+    return h->impl->encoder_states(out, batch, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""HipLayoutModel: the layout model (Donut-Swin encoder + ADETR decoder) behind libsurya_amd.so's surya_layout_* entry points.
+
+Python here is plumbing only (weight re-layout at load, device memory via torch, ctypes marshalling); all arithmetic runs in the
+HIP library. There is no fallback: constructing this without the built library or without a GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .config import LayoutConfig
+
+(LW_PATCH_W, LW_PATCH_B, LW_EMB_LN_W, LW_EMB_LN_B, LW_POS_EMB, LW_DEC_FNORM, LW_DEC_LN_W, LW_DEC_LN_B, LW_DEC_LM_W, LW_DEC_BB_W, LW_DEC_BB_B,
+ LW_DEC_INVFREQ, LW_DEC_ZERO_BIAS, LW_EMB_TABLES) = range(14)
+LW_GLOBALS = LW_EMB_TABLES + 15
+LS_COUNT, LB_COUNT, LD_COUNT = 4, 13, 12
+EMB_ORDER = ("w", "h", "cx", "cy", "xskew", "yskew", "x1", "y1", "x2", "y2", "x3", "y3", "x4", "y4", "label")
+
+
+class LayoutConfigC(C.Structure):
+    _fields_ = [("img_h", C.c_int32), ("img_w", C.c_int32), ("patch", C.c_int32), ("embed_dim", C.c_int32), ("n_stages", C.c_int32),
+                ("depths", C.c_int32 * 8), ("heads", C.c_int32 * 8), ("kv_heads", C.c_int32 * 8), ("window", C.c_int32),
+                ("enc_eps", C.c_float), ("encoder_length", C.c_int32), ("dec_layers", C.c_int32), ("dec_hidden", C.c_int32),
+                ("dec_inter", C.c_int32), ("dec_heads", C.c_int32), ("dec_kv_heads", C.c_int32), ("vocab", C.c_int32),
+                ("label_count", C.c_int32), ("bbox_size", C.c_int32), ("rms_eps", C.c_float), ("ln_eps", C.c_float),
+                ("max_batch", C.c_int32), ("max_boxes", C.c_int32), ("dtype", C.c_int32)]
+
+
+def _relative_position_index(ws: int) -> torch.Tensor:
+    """surya/common/donut/encoder.py:348-359."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _sincos_2d(width: int, height: int, dim: int, temperature: float = 10000.0) -> torch.Tensor:
+    """DonutSwinStage.build_2d_sincos_position_embedding (donut/encoder.py:735-757), with the reference's (w, h) meshgrid order."""
+    gw, gh = torch.meshgrid(torch.arange(int(width), dtype=torch.float32), torch.arange(int(height), dtype=torch.float32), indexing="ij")
+    pos_dim = dim // 4
+    omega = 1.0 / (temperature ** (torch.arange(pos_dim, dtype=torch.float32) / pos_dim))
+    ow, oh = gw.flatten()[..., None] @ omega[None], gh.flatten()[..., None] @ omega[None]
+    return torch.cat([ow.sin(), ow.cos(), oh.sin(), oh.cos()], dim=1)
+
+
+def _interleave(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    out = g.new_zeros((2 * g.shape[0],) + tuple(g.shape[1:]))
+    out[0::2] = g
+    out[1::2] = u
+    return out
+
+
+def repack_layout_weights(cfg: LayoutConfig, sd, dtype: torch.dtype, device) -> List[torch.Tensor]:
+    """Reference state dict (`encoder.*` = DonutSwinLayoutModel, `decoder.*` = SuryaLayoutDecoder) -> the table of
+    include/surya_amd.h (SA_LW_* / SA_LS_* / SA_LB_* / SA_LD_*)."""
+    e, d = cfg.encoder, cfg.decoder
+    out: List[torch.Tensor] = []
+
+    def put(t, dt=None):
+        out.append(t.to(device=device, dtype=dt or dtype).contiguous())
+
+    f = lambda k: sd[k].float()
+    E = e.embed_dim
+    pw = f("encoder.embeddings.patch_embeddings.projection.weight").reshape(E, -1)
+    pwp = torch.zeros((E, 64))
+    pwp[:, : pw.shape[1]] = pw
+    put(pwp); put(f("encoder.embeddings.patch_embeddings.projection.bias"))
+    put(f("encoder.embeddings.norm.weight")); put(f("encoder.embeddings.norm.bias"))
+    put(f("encoder.position_embeddings")[0])
+    put(f("decoder.model.final_norm.weight")); put(f("decoder.pre_output_norm.weight")); put(f("decoder.pre_output_norm.bias"))
+    put(f("decoder.lm_head.weight")); put(f("decoder.bbox_head.weight")); put(f("decoder.bbox_head.bias"))
+    hd = d.head_dim
+    put(1.0 / (d.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd)), torch.float32)
+    put(torch.zeros((d.num_attention_heads + 2 * d.num_key_value_heads) * hd))
+    for nm in EMB_ORDER:
+        put(f(f"decoder.model.embed_tokens.{nm}_embed.weight"))
+    assert len(out) == LW_GLOBALS
+    gh, gw = e.grid
+    ws = e.window_size
+    rel_idx = _relative_position_index(ws).view(-1)
+    for si, depth in enumerate(e.depths):
+        dim = E * 2 ** si
+        res = (gh // 2 ** si, gw // 2 ** si)
+        sincos = _sincos_2d(res[1], res[0], dim) if e.use_positional_embeddings else torch.zeros((res[0] * res[1], dim))
+        put(sincos)
+        if si < len(e.depths) - 1:
+            p = f"encoder.encoder.layers.{si}.downsample."
+            put(f(p + "norm.weight")); put(f(p + "norm.bias")); put(f(p + "reduction.weight"))
+        else:
+            put(torch.zeros(4)); put(torch.zeros(4)); put(torch.zeros(4))
+        nh = e.num_heads[si]
+        for bi in range(depth):
+            p = f"encoder.encoder.layers.{si}.blocks.{bi}."
+            put(f(p + "layernorm_before.weight")); put(f(p + "layernorm_before.bias"))
+            put(torch.cat([f(p + "attention.self.query.weight"), f(p + "attention.self.key.weight"), f(p + "attention.self.value.weight")], 0))
+            put(torch.cat([f(p + "attention.self.query.bias"), f(p + "attention.self.key.bias"), f(p + "attention.self.value.bias")], 0))
+            # the reference adds the bias in the model dtype: round it there before it is widened to fp32 for the kernel
+            bias = f(p + "attention.self.relative_position_bias_table")[rel_idx].view(ws * ws, ws * ws, nh).permute(2, 0, 1)
+            put(bias.to(dtype).float(), torch.float32)
+            put(f(p + "attention.output.dense.weight")); put(f(p + "attention.output.dense.bias"))
+            put(f(p + "layernorm_after.weight")); put(f(p + "layernorm_after.bias"))
+            put(f(p + "intermediate.dense.weight")); put(f(p + "intermediate.dense.bias"))
+            put(f(p + "output.dense.weight")); put(f(p + "output.dense.bias"))
+    for li in range(d.num_hidden_layers):
+        p = f"decoder.model.layers.{li}."
+        put(f(p + "cross_pre_norm.weight"))
+        put(f(p + "cross_attn_block.q_proj.weight"))
+        put(torch.cat([f(p + "cross_attn_block.k_proj.weight"), f(p + "cross_attn_block.v_proj.weight")], 0))
+        put(f(p + "cross_attn_block.o_proj.weight")); put(f(p + "cross_attn_block.o_proj.bias"))
+        put(f(p + "temporal_pre_norm.weight"))
+        put(torch.cat([f(p + "temporal_block.q_proj.weight"), f(p + "temporal_block.k_proj.weight"), f(p + "temporal_block.v_proj.weight")], 0))
+        put(f(p + "temporal_block.o_proj.weight")); put(f(p + "temporal_block.o_proj.bias"))
+        put(f(p + "channel_pre_norm.weight"))
+        put(_interleave(f(p + "mlp_block.gate_proj.weight"), f(p + "mlp_block.up_proj.weight")))
+        put(f(p + "mlp_block.down_proj.weight"))
+    return out
+
+
+class HipLayoutModel:
+    def __init__(self, cfg: LayoutConfig, state_dict, *, dtype: torch.dtype = torch.bfloat16, device="cuda:0", max_batch: int = 32,
+                 max_boxes: int = 100):
+        if not torch.cuda.is_available():
+            raise L.SuryaAmdError("HipLayoutModel needs a GPU (MI355X); there is no CPU fallback")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be float32 (reference mode) or bfloat16")
+        self.lib = L.lib()
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.max_batch, self.max_boxes = max_batch, max_boxes
+        torch.cuda.set_device(self.device)
+        self.weights = repack_layout_weights(cfg, state_dict, dtype, self.device)
+        e, d = cfg.encoder, cfg.decoder
+        c = LayoutConfigC(img_h=e.image_size[0], img_w=e.image_size[1], patch=e.patch_size, embed_dim=e.embed_dim, n_stages=len(e.depths),
+                          window=e.window_size, enc_eps=e.layer_norm_eps, encoder_length=e.encoder_length, dec_layers=d.num_hidden_layers,
+                          dec_hidden=d.hidden_size, dec_inter=d.intermediate_size, dec_heads=d.num_attention_heads,
+                          dec_kv_heads=d.num_key_value_heads, vocab=d.vocab_size, label_count=d.label_count, bbox_size=d.bbox_size,
+                          rms_eps=d.rms_norm_eps, ln_eps=d.layer_norm_eps, max_batch=max_batch, max_boxes=max_boxes,
+                          dtype=L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16)
+        for i, (dep, nh, nkv) in enumerate(zip(e.depths, e.num_heads, e.num_kv_heads)):
+            c.depths[i], c.heads[i], c.kv_heads[i] = dep, nh, nkv
+        self.c = c
+        table = (C.c_void_p * len(self.weights))(*[t.data_ptr() for t in self.weights])
+        self.handle = C.c_void_p()
+        L.check(self.lib.surya_layout_create(C.byref(c), table, len(self.weights), C.byref(self.handle)), "surya_layout_create")
+        self._cls = np.zeros((max_batch, d.label_count), np.float32)
+        self._box = np.zeros((max_batch, 6), np.float32)
+        self.batch = 0
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.surya_layout_destroy(h)
+            self.handle = None
+
+    @property
+    def config(self):
+        return self.cfg
+
+    def eval(self):
+        return self
+
+    def to(self, device_dtype=None):
+        return self
+
+    @property
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def encode(self, pixel_values: torch.Tensor):
+        """pixel_values: cuda fp32 [B, 3, H, W]; keeps the encoder states and the cross-attention K / V inside the handle."""
+        assert pixel_values.is_cuda and pixel_values.dtype == torch.float32 and pixel_values.is_contiguous()
+        B = pixel_values.shape[0]
+        assert tuple(pixel_values.shape[1:]) == (3,) + tuple(self.cfg.encoder.image_size) and B <= self.max_batch
+        L.check(self.lib.surya_layout_encode(self.handle, L.ptr(pixel_values), C.c_int(B), self._stream), "surya_layout_encode")
+        self.batch = B
+
+    def decode_step(self, boxes: np.ndarray, position: int):
+        """boxes: int32 [B, 7]; returns (class_logits [B, label_count], bbox [B, 6]) numpy copies."""
+        b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, 7)
+        L.check(self.lib.surya_layout_decode_step(self.handle, L.np_ptr(b), C.c_int(self.batch), C.c_int(position),
+                                                  L.np_ptr(self._cls, C.c_float), L.np_ptr(self._box, C.c_float), self._stream),
+                "surya_layout_decode_step")
+        return self._cls[: self.batch].copy(), self._box[: self.batch].copy()
+
+    def encoder_states(self) -> torch.Tensor:
+        e = self.cfg.encoder
+        n = (e.grid[0] >> (len(e.depths) - 1)) * (e.grid[1] >> (len(e.depths) - 1))
+        out = torch.empty((self.batch, n, e.hidden_size), dtype=self.dtype, device=self.device)
+        L.check(self.lib.surya_layout_encoder_states(self.handle, L.ptr(out), C.c_int(self.batch), self._stream), "surya_layout_encoder_states")
+        return out

@@ -333,3 +333,76 @@ def text_like_map(h: int, w: int, n_lines: int, seed: int = 0) -> np.ndarray:
             x = cx + half_len + rng.uniform(12, 40)
             done += 1
     return np.ascontiguousarray(np.clip(m, 0.001, 0.999).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------- layout model
+def make_layout_weights(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """fp32 CPU state dict with the reference's parameter names: `encoder.*` = DonutSwinLayoutModel (surya/layout/model/encoder.py,
+    surya/common/donut/encoder.py), `decoder.*` = SuryaLayoutDecoder (surya/layout/model/decoder.py, surya/common/adetr/decoder.py).
+    Gains are chosen so activations stay O(1) through the stacks and the class logits are spread (a random tied-scale head would
+    emit one label forever)."""
+    g = torch.Generator().manual_seed(seed)
+    e, d = cfg.encoder, cfg.decoder
+    sd: Dict[str, torch.Tensor] = {}
+    E = e.embed_dim
+    sd["encoder.embeddings.patch_embeddings.projection.weight"] = _normal(g, (E, e.num_channels, e.patch_size, e.patch_size),
+                                                                            1.0 / math.sqrt(e.num_channels * e.patch_size ** 2))
+    sd["encoder.embeddings.patch_embeddings.projection.bias"] = _normal(g, (E,), 0.02)
+    sd["encoder.embeddings.norm.weight"] = 1.0 + _normal(g, (E,), 0.05)
+    sd["encoder.embeddings.norm.bias"] = _normal(g, (E,), 0.05)
+    ws = e.window_size
+    for si, depth in enumerate(e.depths):
+        dim, nh, nkv = E * 2 ** si, e.num_heads[si], e.num_kv_heads[si]
+        hd = dim // nh
+        for bi in range(depth):
+            p = f"encoder.encoder.layers.{si}.blocks.{bi}."
+            sd[p + "layernorm_before.weight"] = 1.0 + _normal(g, (dim,), 0.05)
+            sd[p + "layernorm_before.bias"] = _normal(g, (dim,), 0.05)
+            sd[p + "attention.self.relative_position_bias_table"] = _normal(g, ((2 * ws - 1) ** 2, nh), 0.5)
+            sd[p + "attention.self.query.weight"] = _normal(g, (dim, dim), 1.2 / math.sqrt(dim))
+            sd[p + "attention.self.query.bias"] = _normal(g, (dim,), 0.05)
+            sd[p + "attention.self.key.weight"] = _normal(g, (nkv * hd, dim), 1.2 / math.sqrt(dim))
+            sd[p + "attention.self.key.bias"] = _normal(g, (nkv * hd,), 0.05)
+            sd[p + "attention.self.value.weight"] = _normal(g, (nkv * hd, dim), 1.0 / math.sqrt(dim))
+            sd[p + "attention.self.value.bias"] = _normal(g, (nkv * hd,), 0.05)
+            sd[p + "attention.output.dense.weight"] = _normal(g, (dim, dim), 0.5 / math.sqrt(dim))
+            sd[p + "attention.output.dense.bias"] = _normal(g, (dim,), 0.02)
+            sd[p + "layernorm_after.weight"] = 1.0 + _normal(g, (dim,), 0.05)
+            sd[p + "layernorm_after.bias"] = _normal(g, (dim,), 0.05)
+            inter = int(e.mlp_ratio * dim)
+            sd[p + "intermediate.dense.weight"] = _normal(g, (inter, dim), 1.0 / math.sqrt(dim))
+            sd[p + "intermediate.dense.bias"] = _normal(g, (inter,), 0.05)
+            sd[p + "output.dense.weight"] = _normal(g, (dim, inter), 0.5 / math.sqrt(inter))
+            sd[p + "output.dense.bias"] = _normal(g, (dim,), 0.02)
+        if si < len(e.depths) - 1:
+            p = f"encoder.encoder.layers.{si}.downsample."
+            sd[p + "reduction.weight"] = _normal(g, (2 * dim, 4 * dim), 1.0 / math.sqrt(4 * dim))
+            sd[p + "norm.weight"] = 1.0 + _normal(g, (4 * dim,), 0.05)
+            sd[p + "norm.bias"] = _normal(g, (4 * dim,), 0.05)
+    sd["encoder.position_embeddings"] = _normal(g, (1, e.encoder_length, e.hidden_size), 0.3)
+    H, I, qd, kvd = d.hidden_size, d.intermediate_size, d.num_attention_heads * d.head_dim, d.num_key_value_heads * d.head_dim
+    for nm in ("w", "h", "cx", "cy", "xskew", "yskew", "x1", "y1", "x2", "y2", "x3", "y3", "x4", "y4"):
+        sd[f"decoder.model.embed_tokens.{nm}_embed.weight"] = _normal(g, (d.vocab_size, H), 0.3)
+    sd["decoder.model.embed_tokens.label_embed.weight"] = _normal(g, (d.label_count, H), 0.5)
+    for li in range(d.num_hidden_layers):
+        p = f"decoder.model.layers.{li}."
+        for nm in ("cross_pre_norm", "temporal_pre_norm", "channel_pre_norm"):
+            sd[p + nm + ".weight"] = _normal(g, (H,), 0.1)                      # the norm multiplies by (1 + weight)
+        for blk, kin in (("temporal_block", H), ("cross_attn_block", d.encoder_hidden_size)):
+            sd[p + blk + ".q_proj.weight"] = _normal(g, (qd, H), 1.2 / math.sqrt(H))
+            sd[p + blk + ".k_proj.weight"] = _normal(g, (kvd, kin), 1.2 / math.sqrt(kin))
+            sd[p + blk + ".v_proj.weight"] = _normal(g, (kvd, kin), 1.0 / math.sqrt(kin))
+            sd[p + blk + ".o_proj.weight"] = _normal(g, (H, qd), 0.7 / math.sqrt(qd))
+            sd[p + blk + ".o_proj.bias"] = _normal(g, (H,), 0.02)
+        sd[p + "mlp_block.gate_proj.weight"] = _normal(g, (I, H), 1.0 / math.sqrt(H))
+        sd[p + "mlp_block.up_proj.weight"] = _normal(g, (I, H), 1.0 / math.sqrt(H))
+        sd[p + "mlp_block.down_proj.weight"] = _normal(g, (H, I), 0.7 / math.sqrt(I))
+    sd["decoder.model.final_norm.weight"] = _normal(g, (H,), 0.1)
+    sd["decoder.pre_output_norm.weight"] = 1.0 + _normal(g, (H,), 0.05)
+    sd["decoder.pre_output_norm.bias"] = _normal(g, (H,), 0.05)
+    sd["decoder.lm_head.weight"] = _normal(g, (d.label_count, H), 1.5 / math.sqrt(H))
+    # nothing ends a page early by itself: keep </S> / <PAD> / pause unlikely so a fixed number of boxes is decoded in tests
+    sd["decoder.lm_head.weight"][: d.special_token_count] *= 0.05
+    sd["decoder.bbox_head.weight"] = _normal(g, (6, H), 1.0 / math.sqrt(H))
+    sd["decoder.bbox_head.bias"] = _normal(g, (6,), 0.1)
+    return sd

@@ -211,3 +211,32 @@ def test_host_assembly_and_tokenizer_match_reference_vectors():
         assert ours._tokenize_ocr(e["text"]) == e["ids"], e["text"]
     for d in t["decode"]:
         assert ours._decode_ocr(d["ids"]) == d["text"], d["ids"]
+
+
+# ------------------------------------------------------------------------------------------ layout model family
+@pytest.mark.parametrize("name,fixture", [("LAYOUT-TINY", "layout_tiny.pt"), ("LAYOUT-SMALL", "layout_small.pt"), ("LAYOUT-DEFAULT", "layout_default.pt")])
+def test_layout_oracle_matches_reference(name, fixture):
+    """oracle/layout_oracle.py (Donut-Swin encoder + ADETR decoder with cross / self attention) against fixtures recorded from the
+    reference's own DonutSwinLayoutModel / SuryaLayoutDecoder (oracle/make_golden_layout.py): encoder output, and -- teacher-forced on
+    the recorded fed-back tokens -- class logits and sigmoid box outputs of every decode step; the argmax classes are bit-exact."""
+    from oracle import layout_oracle as lo
+    from oracle.make_golden_layout import layout_pixels
+    from surya_amd.layout.config import layout_config
+    from surya_amd.synth import make_layout_weights
+    g = torch.load(os.path.join(GOLD, fixture))
+    cfg = layout_config(name)
+    d = cfg.decoder
+    sd = make_layout_weights(cfg, 0)
+    x = layout_pixels(cfg, g["batch"], g["seed"])
+    with torch.inference_mode():
+        enc = lo.encoder_forward(sd, cfg.encoder, x)
+        assert (enc[:, ::g["enc_stride"]] - g["encoder_out"]).abs().max().item() <= 1e-4 * g["encoder_absmax"]
+        st = lo.LayoutDecoderState(d.num_hidden_layers)
+        boxes = torch.tensor([[[d.bos_token_id] * 7]] * g["batch"], dtype=torch.long)
+        for step in range(g["steps"]):
+            box, cls = lo.decoder_forward(sd, d, boxes, enc, step, st)
+            ref_c, ref_b = g["class_logits"][step], g["bbox_logits"][step]
+            assert (cls[:, -1] - ref_c).abs().max().item() <= 1e-4 * max(1.0, ref_c.abs().max().item()), step
+            assert (box[:, -1] - ref_b).abs().max().item() <= 1e-5, step
+            assert torch.equal(cls[:, -1].argmax(-1), ref_c.argmax(-1))
+            boxes = g["fed_tokens"][step].unsqueeze(1)
