@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--texify-crops", type=int, default=128)
     ap.add_argument("--texify-tokens", type=int, default=256, help="decode horizon of the texify leg (the task's own default is 768)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
+    ap.add_argument("--no-layout", action="store_true", help="skip the layout-model leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
@@ -593,6 +594,74 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def bench_layout(args, local_rank):
+    """Layout model family (not a BASELINE.json config): LAYOUT-DEFAULT (Donut-Swin 128-d x [2, 2, 16, 2], ADETR
+    decoder 8 x 1024) with synthetic weights, 32 pages at the processor size 768^2, bf16. Random weights never emit </S>, so every
+    page decodes LAYOUT_MAX_BOXES = 100 boxes: pages/s = 32 / (encode + 100 decode steps incl. the per-step host round trip the
+    reference's loop has as well). Parity: teacher-forced bf16 class logits vs the fixture recorded from the REAL reference modules
+    (tests/golden/layout_default.pt); CPU: the oracle (bit-identical to the reference modules) on 2 pages, encoder + 4 steps."""
+    from oracle import layout_oracle as lo
+    from surya_amd.layout.config import layout_config
+    from surya_amd.layout.model import HipLayoutModel
+    from surya_amd.synth import make_layout_weights
+    cfg = layout_config("LAYOUT-DEFAULT")
+    d = cfg.decoder
+    sd = make_layout_weights(cfg, 0)
+    B, steps = 32, 100
+    m = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=f"cuda:{local_rank}", max_batch=B, max_boxes=steps + 4)
+    px = torch.randn(B, 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(5)).to(f"cuda:{local_rank}").contiguous()
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.encode(px)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        boxes = np.full((B, 7), d.bos_token_id, np.int32)
+        for k in range(steps):
+            cls, box = m.decode_step(boxes, k)
+            boxes = np.concatenate([box * d.bbox_size, cls.argmax(-1)[:, None].astype(np.float32)], -1).astype(np.int64).astype(np.int32)
+        return t1 - t0, time.perf_counter() - t1
+
+    run()
+    t_enc, t_dec = min(run() for _ in range(3))
+    out = {"metric": "layout pages/s (encode + 100 greedy boxes per page)", "pages_per_s": round(B / (t_enc + t_dec), 1), "pages": B,
+           "encode_ms": round(t_enc * 1e3, 2), "decode_step_us": round(t_dec / steps * 1e6, 1), "boxes_per_page": steps, "dtype": "bf16",
+           "config": {"workload": f"{B} synthetic pages at the processor size 768x768, LAYOUT-DEFAULT synthetic weights, pixel_values in HBM"}}
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "layout_default.pt"))
+    m2 = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=f"cuda:{local_rank}", max_batch=g["batch"], max_boxes=16)
+    m2.encode(torch.randn(g["batch"], 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(g["seed"])).to(f"cuda:{local_rank}").contiguous())
+    boxes = np.full((g["batch"], 7), d.bos_token_id, np.int32)
+    worst, agree, total = 0.0, 0, 0
+    for k in range(g["steps"]):
+        cls, _ = m2.decode_step(boxes, k)
+        ref = g["class_logits"][k].numpy()
+        worst = max(worst, float(np.abs(cls - ref).max() / max(1.0, np.abs(ref).max())))
+        agree += int((cls.argmax(-1) == ref.argmax(-1)).sum()); total += ref.shape[0]
+        boxes = g["fed_tokens"][k].numpy().astype(np.int32)
+    out["parity"] = {"bf16_worst_class_logit_err_rel": round(worst, 4), "bf16_argmax_equal": f"{agree}/{total}",
+                     "note": "teacher-forced on the reference's fed-back tokens; fp32 mode is bit-exact on the classes (tests/test_gpu_layout.py)"}
+    del m, m2
+    torch.cuda.empty_cache()
+    if not args.no_cpu_baseline:
+        x2 = px[:2].float().cpu()
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            enc = lo.encoder_forward(sd, cfg.encoder, x2)
+            t_e = time.perf_counter() - t0
+            st = lo.LayoutDecoderState(d.num_hidden_layers)
+            bx = torch.tensor([[[d.bos_token_id] * 7]] * 2, dtype=torch.long)
+            t0 = time.perf_counter()
+            for k in range(4):
+                bo, co = lo.decoder_forward(sd, d, bx, enc, k, st)
+                bx = torch.cat([(bo[:, -1] * d.bbox_size).unsqueeze(1), co[:, -1].argmax(-1)[:, None, None].float()], -1).to(torch.long)
+            t_s = (time.perf_counter() - t0) / 4
+        out["cpu_baseline"] = {"value": round(2 / (t_e + steps * t_s), 3), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"2 of the same pages: encoder {t_e:.2f}s + 4 decode steps at {t_s * 1e3:.1f} ms, extrapolated to {steps} boxes; "
+                                         "fp32 oracle, bit-identical to the reference modules"}
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -751,7 +820,7 @@ def main():
                    "parallelism": (f"dp{world}: {args.lines * world} width-sorted lines dealt round-robin, one all_gather of the outputs per step, "
                                    f"weights broadcast from rank 0 ({args.dist_backend})" if world > 1 else "1 GPU"),
                    "rank_ms_per_step": rank_ms},
-        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None,
+        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None, "layout": None,
     }
     emit_lock = threading.Lock()
     emitted = [False]
@@ -796,6 +865,8 @@ def main():
         out["detection"] = leg("detection", lambda: bench_det(args, local_rank, world, rank, barrier))
     if not args.no_e2e:
         out["e2e"] = leg("e2e", lambda: bench_e2e(args, pred, local_rank, world, rank, barrier))
+    if rank == 0 and world == 1 and not args.no_layout:
+        out["layout"] = leg("layout", lambda: bench_layout(args, local_rank))
     if rank == 0 and world == 1 and not args.no_texify:
         del pred
         torch.cuda.empty_cache()

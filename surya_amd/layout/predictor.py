@@ -1,0 +1,175 @@
+"""LayoutPredictor: drop-in for surya.layout.LayoutPredictor (surya/layout/__init__.py:18-225) on the HIP layout model.
+
+Same call signature, batching by slice count, greedy box loop with the reference's stop and re-labelling rules, same LayoutResult
+schema. The model calls are `HipLayoutModel.encode` (once per batch) and `.decode_step` (once per emitted box; the reference
+synchronises with the host after every step as well). There is no CPU fallback for the model."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..common import imageops
+from ..common.predictor import BasePredictor, ModelLoader
+from ..detection.heatmap import clean_boxes
+from ..settings import settings
+from .config import ID_TO_LABEL, LayoutConfig, layout_config
+from .model import HipLayoutModel
+from .schema import LayoutBox, LayoutResult
+from .slicer import ImageSlicer
+
+LAYOUT_SLICE_MIN = {"height": 1500, "width": 1500}        # surya/settings.py:101-105
+LAYOUT_SLICE_SIZE = {"height": 1200, "width": 1200}
+LAYOUT_MAX_BOXES = 100                                     # surya/settings.py:108
+
+
+def prediction_to_polygon(pred, img_size, bbox_scaler, skew_scaler, skew_min=0.001):
+    """surya/layout/util.py:4-40 on a length-7 float vector (cx, cy, w, h, xskew, yskew, label)."""
+    w_scale, h_scale = img_size[0] / bbox_scaler, img_size[1] / bbox_scaler
+    cx, cy, width, height = (float(pred[i]) for i in range(4))
+    x1, y1, x2, y2 = cx - width / 2, cy - height / 2, cx + width / 2, cy + height / 2
+    skew_x = float(np.floor((float(pred[4]) - skew_scaler) / 2))
+    skew_y = float(np.floor((float(pred[5]) - skew_scaler) / 2))
+    if abs(skew_x) < skew_min:
+        skew_x = 0.0
+    if abs(skew_y) < skew_min:
+        skew_y = 0.0
+    pts = [x1 - skew_x, y1 - skew_y, x2 - skew_x, y1 + skew_y, x2 + skew_x, y2 + skew_y, x1 + skew_x, y2 - skew_y]
+    return [[pts[2 * i] * w_scale, pts[2 * i + 1] * h_scale] for i in range(4)]
+
+
+class LayoutImageProcessor:
+    """SuryaEncoderImageProcessor (surya/common/donut/processor.py:24-126) for the layout model: every slice is resized straight to
+    max_size (no aspect preservation) with cv2 interpolation flag 2 -- the reference passes PIL's BILINEAR constant to cv2.resize,
+    which reads it as INTER_CUBIC --, rescaled by 1/255 in fp64 and normalised with mean = std = 0.5. cv2 is absent from the image:
+    the cubic resample is common/imageops' restatement rounded to uint8 (cv2 returns uint8 for uint8 input)."""
+    image_mean = np.array((0.5, 0.5, 0.5), np.float32)
+    image_std = np.array((0.5, 0.5, 0.5), np.float32)
+
+    def __init__(self, max_size):
+        self.max_size = max_size
+
+    def __call__(self, images: List[Image.Image]):
+        out = []
+        W, H = self.max_size["width"], self.max_size["height"]
+        for img in images:
+            a = np.asarray(img, dtype=np.uint8)
+            assert a.ndim == 3 and a.shape[2] == 3
+            r = imageops.resize(a.astype(np.float32), W, H, "cubic") if a.shape[:2] != (H, W) else a.astype(np.float32)
+            r = np.clip(np.rint(r), 0, 255).astype(np.float32).transpose(2, 0, 1)
+            r = (r.astype(np.float64) * (1 / 255)).astype(np.float32)
+            out.append(((r - self.image_mean[:, None, None]) / self.image_std[:, None, None]).astype(np.float32))
+        return {"pixel_values": out}
+
+
+class LayoutModelLoader(ModelLoader):
+    """checkpoint: None / config name (synthetic weights) or {"config": LayoutConfig, "state_dict": {...}}."""
+
+    def __init__(self, checkpoint=None):
+        super().__init__(checkpoint)
+        ck = checkpoint
+        if isinstance(ck, dict):
+            self._cfg, self._sd = ck["config"], ck["state_dict"]
+        else:
+            from ..synth import make_layout_weights
+            self._cfg = layout_config(ck if isinstance(ck, str) else "LAYOUT-DEFAULT")
+            self._sd = make_layout_weights(self._cfg, 0)
+
+    def model(self, device=None, dtype=None, max_batch=None) -> HipLayoutModel:
+        if device is None or device == "cuda":
+            device = "cuda:0"
+        return HipLayoutModel(self._cfg, self._sd, dtype=dtype or torch.bfloat16, device=device,
+                              max_batch=max_batch or LayoutPredictor.default_batch_sizes["cuda"], max_boxes=LAYOUT_MAX_BOXES)
+
+    def processor(self, device=None, dtype=None) -> LayoutImageProcessor:
+        h, w = self._cfg.encoder.image_size
+        return LayoutImageProcessor({"height": h, "width": w})
+
+
+class LayoutPredictor(BasePredictor):
+    model_loader_cls = LayoutModelLoader
+    batch_size = None
+    default_batch_sizes = {"cpu": 4, "mps": 4, "cuda": 32, "xla": 16}
+
+    def __call__(self, images: List[Image.Image], batch_size: Optional[int] = None, top_k: int = 5) -> List[LayoutResult]:
+        return self.batch_layout_detection(images, top_k=top_k, batch_size=batch_size)
+
+    def batch_layout_detection(self, images: List[Image.Image], batch_size: Optional[int] = None, top_k: int = 5) -> List[LayoutResult]:
+        assert all(isinstance(image, Image.Image) for image in images)
+        if batch_size is None:
+            batch_size = self.get_batch_size()
+        batch_size = min(batch_size, self.model.max_batch)
+        slicer = ImageSlicer(LAYOUT_SLICE_MIN, LAYOUT_SLICE_SIZE)
+        counts = [slicer.slice_count(image) for image in images]
+        batches, start, end = [], 0, 1                                   # the reference's batching by slice count (:53-66)
+        while end < len(counts):
+            if sum(counts[start:end]) >= batch_size or sum(counts[start:end + 1]) > batch_size:
+                batches.append((start, end))
+                start = end
+            end += 1
+        if start < len(counts):
+            batches.append((start, len(counts)))
+        dcfg = self.model.config.decoder
+        results: List[LayoutResult] = []
+        for start, end in batches:
+            batch_images = [image.convert("RGB") for image in images[start:end]]
+            batch_images, tile_positions = slicer.slice(batch_images)
+            orig_sizes = [image.size for image in batch_images]
+            batch_results = []
+            for s0 in range(0, len(batch_images), self.model.max_batch):     # a page's slices may exceed the model's batch
+                chunk = batch_images[s0:s0 + self.model.max_batch]
+                batch_results.extend(self._detect_chunk(chunk, orig_sizes[s0:s0 + self.model.max_batch], dcfg, top_k))
+            assert len(batch_results) == len(tile_positions)
+            results.extend(slicer.join(batch_results, tile_positions))
+        assert len(results) == len(images)
+        return results
+
+    def _detect_chunk(self, chunk, orig_sizes, dcfg, top_k) -> List[LayoutResult]:
+        n = len(chunk)
+        px = torch.from_numpy(np.stack(self.processor(chunk)["pixel_values"]))
+        self.model.encode(px.pin_memory().to(self.model.device, non_blocking=True).contiguous())
+        assert dcfg.pause_token_count == 0, "pause tokens in the decoder prompt are not built"
+        boxes = np.full((n, 7), dcfg.bos_token_id, np.int32)
+        preds = [[] for _ in range(n)]
+        all_done = np.zeros(n, bool)
+        sp = dcfg.special_token_count
+        for position in range(LAYOUT_MAX_BOXES):
+            cls, box = self.model.decode_step(boxes, position)
+            class_preds = cls.argmax(-1)
+            box_preds = box * dcfg.bbox_size
+            all_done |= (class_preds == dcfg.eos_token_id) | (class_preds == dcfg.pad_token_id)
+            if all_done.all():
+                break
+            nxt = np.concatenate([box_preds, class_preds[:, None].astype(np.float32)], -1)      # float tokens, truncated below (:131)
+            for j in range(n):
+                if all_done[j]:
+                    continue
+                p = nxt[j].copy()
+                poly = prediction_to_polygon(p, orig_sizes[j], dcfg.bbox_size, dcfg.skew_scaler)
+                label = int(p[6]) - sp
+                logits = torch.from_numpy(cls[j].copy())
+                text_label = ID_TO_LABEL.get(label)
+                w, h = orig_sizes[j]
+                if (text_label in ("PageHeader", "PageFooter") and poly[0][1] < h * .8 and poly[2][1] > h * .2 and poly[0][0] < w * .8
+                        and poly[2][0] > w * .2):
+                    # page headers / footers in the middle of a page take their next-best label (:158-169)
+                    logits[int(p[6])] = 0
+                    new = int(logits.argmax(-1))
+                    label = new - sp
+                    p[6] = new
+                    nxt[j, 6] = new
+                probs, idx = torch.topk(torch.softmax(logits, dim=-1), k=top_k, dim=-1)
+                preds[j].append({"token": p, "polygon": poly, "label": label, "top_k_probs": probs, "top_k_indices": idx})
+            boxes = nxt.astype(np.int64).astype(np.int32)
+        out = []
+        for j in range(n):
+            lb = []
+            keep = [p for p in preds[j] if p["token"][6] > sp]                # special tokens (pause ...) carry no box (:187)
+            for z, p in enumerate(keep):
+                top_k_dict = {ID_TO_LABEL.get(int(l)): float(pr) for l, pr in zip(p["top_k_indices"] - sp, p["top_k_probs"]) if l > 0}
+                name = ID_TO_LABEL[int(p["label"])]
+                lb.append(LayoutBox(polygon=p["polygon"], label=name, position=z, top_k=top_k_dict, confidence=top_k_dict[name]))
+            out.append(LayoutResult(bboxes=clean_boxes(lb), image_bbox=[0, 0, orig_sizes[j][0], orig_sizes[j][1]]))
+        return out

@@ -74,3 +74,46 @@ def test_layout_free_running_tokens_fp32(hip_lib, name, fixture):
         for b, k in zip(*np.nonzero(~same)):
             assert k < 6 and abs(raw[b, k] - round(raw[b, k])) < 2e-2 and abs(int(nxt[b, k]) - int(ref[b, k])) == 1, (step, b, k, raw[b, k])
         boxes = ref.astype(np.int32)
+
+
+def test_layout_predictor_call_and_schema(hip_lib):
+    """LayoutPredictor end to end on synthetic pages (LAYOUT-SMALL, fp32): signature / schema of surya.layout.LayoutPredictor, one
+    result per page with boxes inside the page, a large page sliced and re-joined, and the model-facing part of the loop equal to the
+    oracle's greedy loop on the processor's own pixel_values."""
+    from PIL import Image
+    from oracle import layout_oracle as lo
+    from surya_amd.layout.predictor import LayoutPredictor, LayoutModelLoader
+    from surya_amd.layout.schema import LayoutResult
+    from surya_amd.synth import make_pages
+    cfg = layout_config("LAYOUT-SMALL")
+    sd = make_layout_weights(cfg, 0)
+
+    class Loader(LayoutModelLoader):
+        def model(self, device=None, dtype=None, max_batch=None):
+            return super().model("cuda:0", torch.float32, max_batch=4)
+
+    class Pred(LayoutPredictor):
+        model_loader_cls = Loader
+        batch_size = 4
+
+    pred = Pred(checkpoint={"config": cfg, "state_dict": sd})
+    pages = [Image.fromarray(p) for p in make_pages(3, 512, seed=3)]
+    pages.append(Image.fromarray(np.vstack(make_pages(2, 1024, seed=5))[:1800]))          # 1024 x 1800: two slices of 1200 / 600 rows
+    out = pred(pages, top_k=3)
+    assert len(out) == 4 and all(isinstance(r, LayoutResult) for r in out)
+    assert out[3].sliced and out[3].image_bbox == [0, 0, 1024, 1800] and not out[0].sliced
+    for r, p in zip(out, pages):
+        for b in r.bboxes:
+            assert b.label in set(__import__("surya_amd.layout.config", fromlist=["ID_TO_LABEL"]).ID_TO_LABEL.values())
+            assert len(b.polygon) == 4 and 0 <= b.confidence <= 1 and len(b.top_k) <= 3
+    assert sum(len(r.bboxes) for r in out) > 0
+    # the tokens the loop fed back == the oracle's on the same pixel_values (first page batch, 6 steps)
+    px = torch.from_numpy(np.stack(pred.processor(pages[:3])["pixel_values"]))
+    _, steps = lo.generate(sd, cfg, px, 6)
+    pred.model.encode(px.cuda().contiguous())
+    boxes = np.full((3, 7), cfg.decoder.bos_token_id, np.int32)
+    for k, st in enumerate(steps):
+        cls, box = pred.model.decode_step(boxes, k)
+        assert np.array_equal(cls.argmax(-1), st["class_preds"].numpy())
+        nxt = torch.cat([st["box_preds"], st["class_preds"][:, None].float()], -1).to(torch.long).numpy()
+        boxes = nxt.astype(np.int32)

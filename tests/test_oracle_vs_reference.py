@@ -919,3 +919,74 @@ def test_live_detector_checkpoint_directory_written_by_the_reference(tmp_path):
         a, b = json.load(open(os.path.join(ours, fn))), json.load(open(os.path.join(path, fn)))
         for k, v in a.items():
             assert k in b and (b[k] == v or (isinstance(v, float) and abs(b[k] - v) < 1e-12)), (fn, k, b.get(k), v)
+
+
+def test_live_layout_host_logic_against_reference():
+    """SURVEY 8(f) rank 4, host side: the reference's own ImageSlicer (surya/layout/slicer.py), prediction_to_polygon
+    (surya/layout/util.py) and SuryaEncoderImageProcessor (surya/common/donut/processor.py; cv2.resize stood in by our INTER_CUBIC
+    restatement rounded to uint8) against surya_amd.layout's restatements: identical slices / positions / counts, polygons, merged
+    LayoutResults and pixel_values."""
+    import numpy as np
+    from PIL import Image
+    ref_shim.install_layout()
+    import cv2 as cv2_stub
+    from surya_amd.common import imageops
+    from surya_amd.layout import predictor as lp, slicer as ls
+    from surya_amd.layout.schema import LayoutBox as OB, LayoutResult as OR
+
+    def resize(img, size, interpolation=None):
+        assert interpolation == 2                      # PIL's BILINEAR constant, read by cv2 as INTER_CUBIC
+        out = imageops.resize(img.astype(np.float32), size[0], size[1], "cubic")
+        return np.clip(np.rint(out), 0, 255).astype(img.dtype)
+
+    added = dict(INTER_LANCZOS4=4, INTER_CUBIC=2, resize=resize)
+    for k, v in added.items():
+        setattr(cv2_stub, k, v)
+    try:
+        rs = ref_shim.import_submodule("surya.layout.slicer")
+        ru = ref_shim.import_submodule("surya.layout.util")
+        rsch = ref_shim.import_submodule("surya.layout.schema")
+        rproc = ref_shim.import_submodule("surya.common.donut.processor")
+        rng = np.random.default_rng(4)
+        mins, sizes = {"height": 1500, "width": 1500}, {"height": 1200, "width": 1200}
+        a, b = ls.ImageSlicer(mins, sizes), rs.ImageSlicer(mins, sizes)
+        imgs = [Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in ((800, 600), (1600, 900), (1000, 5200), (1501, 1501))]
+        assert [a.slice_count(i) for i in imgs] == [b.slice_count(i) for i in imgs]
+        (sa_, pa), (sb_, pb) = a.slice(imgs), b.slice(imgs)
+        assert pa == pb and [s.size for s in sa_] == [s.size for s in sb_]
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(sa_, sb_))
+        # prediction_to_polygon on random tokens
+        for _ in range(300):
+            tok = torch.tensor(rng.integers(0, 1025, size=7).astype(np.float32))
+            size = (int(rng.integers(50, 3000)), int(rng.integers(50, 3000)))
+            assert lp.prediction_to_polygon(tok.numpy(), size, 1024, 512) == ru.prediction_to_polygon(tok, size, 1024, 512)
+        # merging per-slice results: same boxes on both sides
+        labels = ["Text", "Picture", "Figure", "Table", "SectionHeader"]
+
+        def results(BoxCls, ResCls):
+            r = np.random.default_rng(7)
+            out = []
+            for size in ((1300, 900), (1300, 900), (1300, 400)):
+                bx = []
+                for z in range(6):
+                    x0, y0 = r.uniform(0, size[0] - 200), r.uniform(-30, size[1] - 100)
+                    w, h = r.uniform(40, 400), r.uniform(20, 200)
+                    bx.append(BoxCls(polygon=[[x0, y0], [x0 + w, y0], [x0 + w, y0 + h], [x0, y0 + h]], label=labels[int(r.integers(0, 5))],
+                                     position=z, top_k={"Text": 0.5}, confidence=0.5))
+                out.append(ResCls(bboxes=bx, image_bbox=[0, 0, size[0], size[1]]))
+            return out
+
+        pos = [(0, 0, 0), (0, 0, 1), (0, 0, 2)]
+        ja, jb = a.join(results(OB, OR), pos), b.join(results(rsch.LayoutBox, rsch.LayoutResult), pos)
+        assert len(ja) == len(jb) == 1 and ja[0].image_bbox == jb[0].image_bbox and ja[0].sliced == jb[0].sliced
+        assert [(x.polygon, x.label, x.position) for x in ja[0].bboxes] == [(y.polygon, y.label, y.position) for y in jb[0].bboxes]
+        # image processor
+        ours = lp.LayoutImageProcessor({"height": 768, "width": 768})
+        theirs = rproc.SuryaEncoderImageProcessor(max_size={"height": 768, "width": 768})
+        page = [imgs[0], imgs[1].crop((0, 0, 900, 768))]
+        pa_, pb_ = ours(page)["pixel_values"], theirs(page)["pixel_values"]
+        for x, y in zip(pa_, pb_):
+            assert x.shape == (3, 768, 768) and np.array_equal(x, np.asarray(y))
+    finally:
+        for k in added:
+            delattr(cv2_stub, k)
