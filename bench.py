@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--texify-tokens", type=int, default=256, help="decode horizon of the texify leg (the task's own default is 768)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
     ap.add_argument("--no-layout", action="store_true", help="skip the layout-model leg (SURVEY 8(f) rank 4)")
+    ap.add_argument("--layout-only", action="store_true", help="profiling aid: run only the layout leg and print its object")
+    ap.add_argument("--texify-only", action="store_true", help="profiling aid: run only the texify leg and print its object")
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
@@ -684,6 +686,9 @@ def main():
     if args.det_only:
         print(json.dumps(bench_det(args, local_rank, world, rank, lambda: None)), flush=True)
         return
+    if args.layout_only:
+        print(json.dumps(bench_layout(args, local_rank)), flush=True)
+        return
     os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
     if args.steps_per_sync:
         os.environ["RECOGNITION_STEPS_PER_SYNC"] = str(args.steps_per_sync)
@@ -710,6 +715,9 @@ def main():
             return super().model(f"cuda:{local_rank}", dtype, max_slots=args.batch, max_kv_len=64 + args.max_tokens + 32,
                                  max_patches=65536, max_prefill_tokens=args.batch * 72)
 
+    if args.texify_only:
+        print(json.dumps(bench_texify(args, cfg, sd, local_rank)), flush=True)
+        return
     RecognitionPredictor.model_loader_cls = Loader
     pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
     # The workload is ONE list of args.lines x world crops (seed 1234), widest first -- the predictor's own ordering -- dealt round-robin

@@ -169,6 +169,113 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const T* __restri
     store4(op + 4, o[4], o[5], o[6], o[7]);
 }
 
+// bf16 windows on the matrix cores. One workgroup (2 waves x 32 queries) per (window, head); the tile plan of attn_mfma.h with the
+// whole window as its single 64-key chunk:
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16(K fragment, Q fragment): a lane owns ONE query (lane & 31) and 16 of each 32 keys, so
+//                 bias / mask / softmax are per-lane work plus one exchange with lane ^ 32;
+//   O^T = V^T P^T the lane's exp() values are its P fragment, the V^T fragment comes from two ds_read_b64_tr_b16 per 16-key step.
+// The scalar kernel above spent 23.8 ms per stage-1 layer of 32 pages in LDS reads (profiles/r03_f_layout_kernel_stats_before.md); it
+// stays as the fp32 reference-mode path.
+__global__ __launch_bounds__(128) void swin_window_attn_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
+                                                                    bf16_t* __restrict__ out, int nh, int nkv, int nwx, int nwy, int shift,
+                                                                    int ws) {
+    constexpr int N = 64, D = 32, PK = D + 8;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    __shared__ __attribute__((aligned(16))) bf16_t ks[N * PK];
+    __shared__ __attribute__((aligned(16))) bf16_t vs[N * PK];
+    const long win = blockIdx.x;
+    const int head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, h = lane >> 5, qi = wave * 32 + ql;
+    const int row_w = (nh + 2 * nkv) * D, kvh = head % nkv;
+    const bf16_t* base = qkv + win * N * row_w;
+    u32x4 kreg[2], vreg[2], qf[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * 128, r = c >> 2, cc = c & 3;
+        kreg[it] = *reinterpret_cast<const u32x4*>(base + (long)r * row_w + (nh + kvh) * D + cc * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(base + (long)r * row_w + (nh + nkv + kvh) * D + cc * 8);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const u32x4*>(base + (long)qi * row_w + head * D + h * 8 + kk * 16);
+    // relative position bias of this lane's query row: register 4g + r of key block kb = key kb * 32 + g * 8 + h * 4 + r
+    const float* brow = bias + ((long)head * N + qi) * N + h * 4;
+    f32x4 b4[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b4[kb][g] = *reinterpret_cast<const f32x4*>(brow + kb * 32 + g * 8);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * 128, r = c >> 2, cc = c & 3;
+        *reinterpret_cast<u32x4*>(ks + r * PK + cc * 8) = kreg[it];
+        *reinterpret_cast<u32x4*>(vs + r * PK + cc * 8) = vreg[it];
+    }
+    __syncthreads();
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+        const bf16_t* kp = ks + (kb * 32 + ql) * PK + h * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(kp + kk * 16);
+            sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sacc[kb], 0, 0, 0);
+        }
+    }
+    const int wimg = (int)(win % ((long)nwx * nwy));
+    const bool last_y = shift > 0 && (wimg / nwx) == nwy - 1, last_x = shift > 0 && (wimg % nwx) == nwx - 1;
+    auto region = [&](int n) { return (last_y && (n / ws) >= ws - shift ? 2 : 0) + (last_x && (n % ws) >= ws - shift ? 1 : 0); };
+    const int ri = region(qi);
+    const float scale = 0.17677669529663687f;                       // 32 ** -0.5
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kb * 32 + g * 8 + h * 4 + r;
+                const float sv = sacc[kb][4 * g + r] * scale + b4[kb][g][r] + (region(j) != ri ? -100.0f : 0.f);    // scores stay fp32
+                sacc[kb][4 * g + r] = sv;
+                m = fmaxf(m, sv);
+            }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = exp2f((sacc[kb][r] - m) * 1.44269504088896340736f);
+            sacc[kb][r] = pv;
+            l += pv;
+        }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int tr_off = ((lane & 15) >> 2) * PK + ((lane >> 4) & 1) * 16 + (lane & 3) * 4 + h * 4 * PK;
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kb = t >> 1, o8 = (t & 1) * 8;
+        u32x4 pf;                                                    // probabilities rounded to bf16 as softmax(...).to(bf16) does
+        pf[0] = pack2(sacc[kb][o8 + 0] * inv, sacc[kb][o8 + 1] * inv);
+        pf[1] = pack2(sacc[kb][o8 + 2] * inv, sacc[kb][o8 + 3] * inv);
+        pf[2] = pack2(sacc[kb][o8 + 4] * inv, sacc[kb][o8 + 5] * inv);
+        pf[3] = pack2(sacc[kb][o8 + 6] * inv, sacc[kb][o8 + 7] * inv);
+        const bf16_t* vp = vs + t * 16 * PK + tr_off;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * PK));
+        const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), oacc, 0, 0, 0);
+    }
+    bf16_t* op = out + (win * N + qi) * (long)(nh * D) + head * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store4(op + g * 8 + h * 4, oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Patch merging (DonutSwinPatchMerging, donut/encoder.py:289-319): the four neighbours (0,0), (1,0), (0,1), (1,1) of a 2x2 block
 // concatenated to 4C channels, LayerNorm(4C, eps 1e-5); the reduction Linear(4C -> 2C) is a GEMM on the rows written here.
@@ -330,6 +437,191 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
     }
 }
 
+// The same cross attention spread over the chip: one workgroup per (image, kv head, key range), NS ranges per (image, kv head).
+// cross_attn_decode_kernel above runs B * nkv = 128 workgroups whose P V phase keeps 64 threads busy for Lk serial steps (88 us
+// per layer at Lk = 576); here
+//   * the query row is the sum of the q projection's split-K slabs (qpart [S][M][nq * D] fp32, rounded to T like the unsplit
+//     GEMM's output), so that projection needs no reduce launch;
+//   * scores: 4 lanes per key (coalesced 2 D-byte row reads), quad-reduced; softmax statistics per range;
+//   * P V: the 256 threads are (key slice, head, 4 output dims), slices summed through LDS;
+//   * the range's (max, sum, un-normalised output) goes to `scratch`; cross_attn_merge_kernel merges the NS ranges.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void cross_attn_split_kernel(const float* __restrict__ qpart, int S, int M, const T* __restrict__ kv,
+                                                               float* __restrict__ scratch, int nq, int nkv, int Lk, int chunk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int G = nq / nkv;
+    float* sc = reinterpret_cast<float*>(smem_raw);                 // [G][chunk] scores -> exp()
+    float* qsh = sc + G * chunk;                                    // [G][D]
+    float* osh = qsh + G * D;                                       // [256][4] P V partials
+    __shared__ float red[2][8][4];                                   // [max | sum][head g][wave]
+    const int b = blockIdx.x, kvh = blockIdx.y, sp = blockIdx.z, NS = gridDim.z, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int row_w = 2 * nkv * D, Hq = nq * D;
+    const int j0 = sp * chunk, nk = min(chunk, Lk - j0);
+    const T* kb = kv + ((long)b * Lk + j0) * row_w + kvh * D;
+    const T* vb = kb + nkv * D;
+    for (int i = tid; i < G * D; i += 256) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += qpart[((long)s * M + b) * Hq + kvh * G * D + i];
+        qsh[i] = Ty<T>::rnd(a);
+    }
+    __syncthreads();
+    {
+        constexpr int DQ = D / 4;                                   // dims per lane of a key's quad
+        const int quarter = tid & 3;
+        for (int jb = 0; jb < nk; jb += 64) {
+            const int j = jb + (tid >> 2), jc = min(j, nk - 1);
+            float kr[DQ];
+#pragma unroll
+            for (int c = 0; c < DQ; c += 4) load4(kb + (long)jc * row_w + quarter * DQ + c, *reinterpret_cast<float(*)[4]>(&kr[c]));
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < DQ; ++c) d += qsh[g * D + quarter * DQ + c] * kr[c];
+                d = quad_sum(d);
+                if (quarter == 0 && j < nk) sc[g * chunk + j] = d * scale;
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        float m = -INFINITY;
+        for (int j = tid; j < nk; j += 256) m = fmaxf(m, sc[g * chunk + j]);
+        m = wave_max(m);
+        if (lane == 0) red[0][g][wave] = m;
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        const float m = fmaxf(fmaxf(red[0][g][0], red[0][g][1]), fmaxf(red[0][g][2], red[0][g][3]));
+        float l = 0.f;
+        for (int j = tid; j < nk; j += 256) { const float e = expf(sc[g * chunk + j] - m); sc[g * chunk + j] = e; l += e; }
+        l = wave_sum(l);
+        if (lane == 0) red[1][g][wave] = l;
+    }
+    __syncthreads();
+    const int combos = G * (D / 4), nslice = 256 / combos;          // combos <= 128 (G <= 8, D <= 64)
+    {
+        const int combo = tid % combos, slice = tid / combos;
+        const int g = combo / (D / 4), c = (combo % (D / 4)) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (slice < nslice) {
+            int j = slice;
+            for (; j + 3 * nslice < nk; j += 4 * nslice) {           // four V rows in flight
+                float v0[4], v1[4], v2[4], v3[4];
+                load4(vb + (long)j * row_w + c, v0);
+                load4(vb + (long)(j + nslice) * row_w + c, v1);
+                load4(vb + (long)(j + 2 * nslice) * row_w + c, v2);
+                load4(vb + (long)(j + 3 * nslice) * row_w + c, v3);
+                const float p0 = sc[g * chunk + j], p1 = sc[g * chunk + j + nslice], p2 = sc[g * chunk + j + 2 * nslice],
+                            p3 = sc[g * chunk + j + 3 * nslice];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += p0 * v0[i] + p1 * v1[i] + p2 * v2[i] + p3 * v3[i];
+            }
+            for (; j < nk; j += nslice) {
+                float v0[4];
+                load4(vb + (long)j * row_w + c, v0);
+                const float p0 = sc[g * chunk + j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += p0 * v0[i];
+            }
+        }
+        *reinterpret_cast<float4*>(osh + tid * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // range record per head: [m, l, o[D]]
+    const int REC = D + 2;
+    if (tid < combos) {
+        const int g = tid / (D / 4), c = (tid % (D / 4)) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < nslice; ++sl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += osh[(sl * combos + tid) * 4 + i];
+        float* rec = scratch + (((long)b * nq + kvh * G + g) * NS + sp) * REC;
+        *reinterpret_cast<float2*>(rec + 2 + c) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(rec + 4 + c) = make_float2(o[2], o[3]);
+        if (c == 0) {
+            rec[0] = fmaxf(fmaxf(red[0][g][0], red[0][g][1]), fmaxf(red[0][g][2], red[0][g][3]));
+            rec[1] = red[1][g][0] + red[1][g][1] + red[1][g][2] + red[1][g][3];
+        }
+    }
+}
+
+// Merge of the NS key ranges of cross_attn_split_kernel: one thread per (image, head, 4 output dims). (A ticket counter that let
+// the last range's workgroup merge in place cost more than this launch: its device-scope fences write back and invalidate the
+// XCD's L2 once per wave, 65 us per layer against 88 for the unsplit kernel.)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void cross_attn_merge_kernel(const float* __restrict__ scratch, T* __restrict__ out, int rows, int NS) {
+    constexpr int REC = D + 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (D / 4)) return;
+    const int r = i / (D / 4), c = (i % (D / 4)) * 4;              // r = image * nq + head
+    const float* rec = scratch + (long)r * NS * REC;
+    float mm = -INFINITY;
+    for (int s2 = 0; s2 < NS; ++s2) mm = fmaxf(mm, rec[s2 * REC]);
+    float l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < NS; ++s2) {
+        const float f = expf(rec[s2 * REC] - mm);
+        l += f * rec[s2 * REC + 1];
+        const float2 a = *reinterpret_cast<const float2*>(rec + s2 * REC + 2 + c), b = *reinterpret_cast<const float2*>(rec + s2 * REC + 4 + c);
+        o[0] += f * a.x; o[1] += f * a.y; o[2] += f * b.x; o[3] += f * b.y;
+    }
+    const float inv = 1.0f / l;
+    store4(out + (long)r * D + c, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+}
+
+// Launch-boundary reduce of a split-K projection of the ADETR decoder, fused with bias, the residual add and the NEXT
+// SuryaADETRDecoderRMSNorm (adetr_rmsnorm_kernel's arithmetic):
+//   x_out <- T(res + T(bias + sum_s part[s]))          (Linear output rounded, then the residual add, as the unsplit epilogue does)
+//   y     <- clamp(x_out * rsqrt(max(mean(x_out^2), eps)) * (1 + w))        (skipped when w == nullptr)
+// One workgroup per row, blockDim = H / 4 rounded up to whole waves: every thread owns one 4-element chunk.
+template <typename T>
+__global__ __launch_bounds__(1024) void splitk_residual_adetr_norm_kernel(const float* __restrict__ part, int S, int M, const T* __restrict__ res,
+                                                                          const T* __restrict__ bias, T* __restrict__ x_out,
+                                                                          const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[16];
+    const int c = tid * 4;
+    const bool on_row = c < H;
+    const int cc = on_row ? c : 0;
+    float r4[4], g[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+    load4(res + (long)row * H + cc, r4);
+    if (w) load4(w + cc, g);
+    if (bias) load4(bias + cc, b4);
+    f32x4 p4[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) p4[s] = *reinterpret_cast<const f32x4*>(part + ((long)min(s, S - 1) * M + row) * H + cc);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float on = (s < S) ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += on * p4[s][i];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = Ty<T>::rnd(r4[i] + Ty<T>::rnd(v[i] + b4[i]));
+        ss += on_row ? v[i] * v[i] : 0.f;
+    }
+    if (on_row) store4(x_out + (long)row * H + c, v[0], v[1], v[2], v[3]);
+    if (!w) return;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    const float rstd = rsqrtf(fmaxf(tot / (float)H, eps));
+    const float lim = sizeof(T) == 2 ? 3.3895313892515355e38f : 3.4028234663852886e38f;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float t = v[i] * rstd * (1.0f + g[i]);
+        t = fminf(fmaxf(t, -lim), lim);
+        o[i] = (t != t) ? 0.f : t;
+    }
+    if (on_row) store4(y + (long)row * H + c, o[0], o[1], o[2], o[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Output heads of SuryaLayoutDecoder.forward (layout/model/decoder.py:119-131): final ADETR RMSNorm -> LayerNorm -> class logits
 // (label_count rows, no bias) and sigmoid(bbox_head). One workgroup per image; every intermediate is rounded to the storage dtype
@@ -373,7 +665,11 @@ __global__ __launch_bounds__(256) void layout_heads_kernel(const T* __restrict__
     for (int o = wave; o < label_count + 6; o += 4) {               // one wave per output neuron
         const T* wr = o < label_count ? lm_w + (long)o * Hd : bb_w + (long)(o - label_count) * Hd;
         float d = 0.f;
-        for (int c = lane; c < Hd; c += 64) d += h[c] * Ty<T>::ld(wr + c);
+        for (int c = lane * 4; c < Hd; c += 256) {                  // Hd % 4 == 0 (checked by the host)
+            float wv[4];
+            load4(wr + c, wv);
+            d += h[c] * wv[0] + h[c + 1] * wv[1] + h[c + 2] * wv[2] + h[c + 3] * wv[3];
+        }
         d = wave_sum(d);
         if (lane == 0) {
             if (o < label_count) cls[(long)b * label_count + o] = Ty<T>::rnd(d);

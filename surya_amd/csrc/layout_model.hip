@@ -55,6 +55,8 @@ struct LayoutModel : LayoutBase {
     T *kcache, *vcache;                          // [layer][B][nkv][Tmax][hd]
     T *dx, *dh, *dq, *dattn, *dres, *dmlp;
     float* part;
+    float* cross_scratch;                        // [B][nq][ranges][hd + 2] partial cross-attention records
+    int cross_ranges = 1, cross_chunk = 0;
     float2* rope_cs;
     int *boxes_dev, *slots_dev, *len_dev;
     float *cls_dev, *box_dev;
@@ -93,6 +95,9 @@ struct LayoutModel : LayoutBase {
         const size_t o_da = take(B * qd * sizeof(T)), o_dr = take(B * Hd * sizeof(T)), o_dm = take(B * I * sizeof(T));
         const size_t o_part = take((size_t)8 * B * std::max(qkv_d, Hd) * sizeof(float));
         const size_t o_rope = take((size_t)c.max_boxes * (hd() / 2) * sizeof(float2));
+        cross_chunk = (Lk + std::max(1, std::min(8, Lk / 128)) - 1) / std::max(1, std::min(8, Lk / 128));     // >= 128 keys per range
+        cross_ranges = (Lk + cross_chunk - 1) / cross_chunk;
+        const size_t o_cscr = take(B * c.dec_heads * cross_ranges * (hd() + 2) * sizeof(float));
         const size_t o_boxes = take(B * 7 * sizeof(int)), o_slots = take(B * sizeof(int)), o_len = take(B * sizeof(int));
         const size_t o_cls = take(B * c.label_count * sizeof(float)), o_box = take(B * 6 * sizeof(float));
         const size_t o_tabs = take(15 * sizeof(void*));
@@ -112,6 +117,7 @@ struct LayoutModel : LayoutBase {
         ckv = (T*)(b + o_ckv); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
         dx = (T*)(b + o_dx); dh = (T*)(b + o_dh); dq = (T*)(b + o_dq); dattn = (T*)(b + o_da); dres = (T*)(b + o_dr); dmlp = (T*)(b + o_dm);
         part = (float*)(b + o_part); rope_cs = (float2*)(b + o_rope);
+        cross_scratch = (float*)(b + o_cscr);
         boxes_dev = (int*)(b + o_boxes); slots_dev = (int*)(b + o_slots); len_dev = (int*)(b + o_len);
         cls_dev = (float*)(b + o_cls); box_dev = (float*)(b + o_box); tabs_dev = (const T**)(b + o_tabs);
         {   // window-order row of every token, per stage and shift (window_partition after torch.roll(-shift), donut/encoder.py:624-636)
@@ -198,8 +204,12 @@ struct LayoutModel : LayoutBase {
                 if ((rc = gemm<EPI_BIAS>(hbuf, dim, W(wb + SA_LB_QKV_W), dim, qkv, qkv_n, W(wb + SA_LB_QKV_B), nullptr, 0, (int)rows, qkv_n, dim, s)))
                     return rc;
                 const int nwx = wd / ws, nwy = h / ws;
-                hipLaunchKernelGGL(lay::swin_window_attn_kernel<T>, dim3((unsigned)(rows / 64), nh), dim3(256), 0, s, qkv,
-                                   reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
+                if constexpr (std::is_same<T, bf16_t>::value)
+                    hipLaunchKernelGGL(lay::swin_window_attn_mfma_kernel, dim3((unsigned)(rows / 64), nh), dim3(128), 0, s, qkv,
+                                       reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
+                else
+                    hipLaunchKernelGGL(lay::swin_window_attn_kernel<T>, dim3((unsigned)(rows / 64), nh), dim3(256), 0, s, qkv,
+                                       reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
                 if ((rc = gemm<EPI_BIAS>(att, dim, W(wb + SA_LB_PROJ_W), dim, hbuf, dim, W(wb + SA_LB_PROJ_B), nullptr, 0, (int)rows, dim, dim, s)))
                     return rc;
                 {
@@ -257,22 +267,48 @@ struct LayoutModel : LayoutBase {
         hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.bbox_size, c.vocab, c.label_count);
         const float scale = 1.0f / sqrtf((float)d);
         const size_t layer_kv = (size_t)c.max_batch * nkv * c.max_boxes * d;
+        // Every M = B projection runs split-K (64 x 64 tiles over ~128-256 workgroups instead of 32) and hands its slabs to the
+        // consumer: the cross-attention kernel sums the q slabs itself, the decode-attention kernel the qkv slabs, and
+        // splitk_residual_adetr_norm_kernel folds reduce + bias + residual + the NEXT norm into one launch (r03: 1476 -> 680 us
+        // per step of 32 pages, profiles/r03_g_layout_kernel_stats.md; the unsplit 64 x 32 launches ran 14 us each on 32 workgroups).
+        auto splitk = [&](const T* A, int lda, const T* Wt, int N, int K, int& S) -> int {
+            GemmArgs<T, T> a{A, lda, Wt, K, nullptr, 0, nullptr, nullptr, 0, B, N, K, 1, part};
+            const int r = launch_gemm_splitk<T>(a, s);
+            S = a.splitk;
+            return r;
+        };
+        auto reduce_norm = [&](int S, const T* res, const T* bias, T* xo, const T* nw) {
+            const int threads = std::min(1024, ((Hd / 4 + 63) / 64) * 64);
+            hipLaunchKernelGGL(lay::splitk_residual_adetr_norm_kernel<T>, dim3(B), dim3(threads), 0, s, part, S, B, res, bias, xo, nw, dh, Hd,
+                               c.rms_eps);
+        };
+        if (Hd % 4 || Hd > 4096) return SA_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dx, W(dec_base + SA_LD_CNORM), dh, B, Hd, c.rms_eps);
         for (int l = 0; l < c.dec_layers; ++l) {
             const int lb = dec_base + l * SA_LD_COUNT;
-            // cross attention (double residual flow, adetr/decoder.py:430-457): cross = o(attn(norm(x))) + x
-            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dx, W(lb + SA_LD_CNORM), dh, B, Hd, c.rms_eps);
-            if ((rc = gemm<EPI_BIAS>(dh, Hd, W(lb + SA_LD_CQ_W), Hd, dq, Hd, nullptr, nullptr, 0, B, Hd, Hd, s))) return rc;
+            int S = 1;
+            // cross attention (double residual flow, adetr/decoder.py:430-457): cross = o(attn(norm(x))) + x; dh = norm(x) on entry
+            if ((rc = splitk(dh, Hd, W(lb + SA_LD_CQ_W), Hd, Hd, S))) return rc;
             {
                 const T* kvp = ckv + (size_t)l * c.max_batch * Lk * 2 * kv;
-                const size_t lds = (size_t)(nq / nkv) * Lk * 4 + (size_t)(nq / nkv) * d * 4;
-                dim3 grid(B, nkv);
-                if (d == 64) hipLaunchKernelGGL((lay::cross_attn_decode_kernel<T, 64>), grid, dim3(256), lds, s, dq, kvp, dattn, nq, nkv, Lk, scale);
-                else if (d == 32) hipLaunchKernelGGL((lay::cross_attn_decode_kernel<T, 32>), grid, dim3(256), lds, s, dq, kvp, dattn, nq, nkv, Lk, scale);
-                else return SA_ERR_UNSUPPORTED;
+                const int G = nq / nkv;
+                const size_t lds = ((size_t)G * cross_chunk + (size_t)G * d + 1024) * sizeof(float);
+                dim3 grid(B, nkv, cross_ranges);
+                if (G > 8 || G * (d / 4) > 256) return SA_ERR_UNSUPPORTED;
+                const int mblocks = cdiv(B * nq * (d / 4), 256);
+                if (d == 64) {
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, nq, nkv, Lk,
+                                       cross_chunk, scale);
+                    hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 64>), dim3(mblocks), dim3(256), 0, s, cross_scratch, dattn, B * nq, cross_ranges);
+                } else if (d == 32) {
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 32>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, nq, nkv, Lk,
+                                       cross_chunk, scale);
+                    hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 32>), dim3(mblocks), dim3(256), 0, s, cross_scratch, dattn, B * nq, cross_ranges);
+                } else return SA_ERR_UNSUPPORTED;
             }
-            if ((rc = gemm<EPI_RESIDUAL>(dattn, Hd, W(lb + SA_LD_CO_W), Hd, dres, Hd, W(lb + SA_LD_CO_B), dx, Hd, B, Hd, Hd, s))) return rc;
+            if ((rc = splitk(dattn, Hd, W(lb + SA_LD_CO_W), Hd, Hd, S))) return rc;
+            reduce_norm(S, dx, W(lb + SA_LD_CO_B), dres, W(lb + SA_LD_TNORM));              // dres = cross, dh = temporal_pre_norm(cross)
             // self attention on norm(cross); residual = o(attn) + RAW layer input
-            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dres, W(lb + SA_LD_TNORM), dh, B, Hd, c.rms_eps);
             {
                 GemmArgs<T, T> a{dh, Hd, W(lb + SA_LD_QKV_W), Hd, nullptr, 0, nullptr, nullptr, 0, B, qkv_d, Hd, 1, part};
                 if ((rc = launch_gemm_splitk<T>(a, s))) return rc;
@@ -302,11 +338,12 @@ struct LayoutModel : LayoutBase {
                 }
 #undef SA_LAY_DEC
             }
-            if ((rc = gemm<EPI_RESIDUAL>(dattn, Hd, W(lb + SA_LD_TO_W), Hd, dres, Hd, W(lb + SA_LD_TO_B), dx, Hd, B, Hd, Hd, s))) return rc;
-            // MLP: x = down(gelu_tanh(gate(n)) * up(n)) + residual
-            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dres, W(lb + SA_LD_MNORM), dh, B, Hd, c.rms_eps);
+            if ((rc = splitk(dattn, Hd, W(lb + SA_LD_TO_W), Hd, Hd, S))) return rc;
+            reduce_norm(S, dx, W(lb + SA_LD_TO_B), dres, W(lb + SA_LD_MNORM));              // dres = residual, dh = channel_pre_norm(residual)
+            // MLP: x = down(gelu_tanh(gate(n)) * up(n)) + residual; dh <- the next layer's cross_pre_norm(x)
             if ((rc = gemm<EPI_GEGLU>(dh, Hd, W(lb + SA_LD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, B, 2 * I, Hd, s))) return rc;
-            if ((rc = gemm<EPI_RESIDUAL>(dmlp, I, W(lb + SA_LD_DOWN_W), I, dx, Hd, nullptr, dres, Hd, B, Hd, I, s))) return rc;
+            if ((rc = splitk(dmlp, I, W(lb + SA_LD_DOWN_W), Hd, I, S))) return rc;
+            reduce_norm(S, dres, nullptr, dx, l + 1 < c.dec_layers ? W(lb + SA_LD_COUNT + SA_LD_CNORM) : nullptr);
         }
         hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
                            W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd, c.label_count,
