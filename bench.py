@@ -564,20 +564,28 @@ def bench_texify(args, cfg, sd, local_rank):
     # the fp8 weight path configs[4] names: decode steps on MXFP8 weights + activations (csrc/gemm_mx.h), prefill in bf16
     pred.model.set_decode_fp8(True)
     fp8, toks_f = timed()
+    # ... and the same with the decode steps reading an FP8 KV cache as well (csrc/decode_attn_kv8.h)
+    pred.model.set_kv_fp8(True)
+    fp8kv, toks_k = timed()
     pred.model.set_decode_fp8(False)
-    same = sum(int(a == b) for x, y in zip(toks_b, toks_f) for a, b in zip(x, y))
-    fp8["tokens_equal_to_bf16_run"] = round(same / max(1, min(bf16["tokens"], fp8["tokens"])), 4)
-    fp8["speedup_vs_bf16"] = round(bf16["ms"] / fp8["ms"], 3)
+    kv_only, _ = timed()                                   # bf16 weights, fp8 KV: what the cache format alone buys
+    pred.model.set_kv_fp8(False)
+    for o, tk in ((fp8, toks_f), (fp8kv, toks_k)):
+        same = sum(int(a == b) for x, y in zip(toks_b, tk) for a, b in zip(x, y))
+        o["tokens_equal_to_bf16_run"] = round(same / max(1, min(bf16["tokens"], o["tokens"])), 4)
+        o["speedup_vs_bf16"] = round(bf16["ms"] / o["ms"], 3)
+    kv_only["speedup_vs_bf16"] = round(bf16["ms"] / kv_only["ms"], 3)
     settings.RECOGNITION_MAX_TOKENS = args.max_tokens
     del pred
     torch.cuda.empty_cache()
     out = {"metric": "LaTeX-OCR crops/s and tokens/s (task block_without_boxes)", "crops": n}
     out.update(bf16)
-    out.update({"dtype": "bf16", "fp8_decode": fp8,
+    out.update({"dtype": "bf16", "fp8_decode": fp8, "fp8_decode_fp8_kv": fp8kv, "bf16_decode_fp8_kv": kv_only,
                 "config": {"workload": f"{n} synthetic 384x384 crops, batch {n}, max_tokens={T}, prompt 202 tokens (196 image tokens), "
                                        f"{args.config} synthetic weights; fp8_decode = the same run with the decode steps on MXFP8 "
-                                       "weights and activations (v_mfma_scale_f32_32x32x64_f8f6f4), prefill bf16; on random weights "
-                                       "the two token streams part at the first near-tie (tokens_equal_to_bf16_run)"}})
+                                       "weights and activations (v_mfma_scale_f32_32x32x64_f8f6f4), prefill bf16; fp8_decode_fp8_kv adds "
+                                       "the e4m3 KV cache (one power-of-two scale per token and kv head); on random weights the token "
+                                       "streams part at the first near-tie (tokens_equal_to_bf16_run)"}})
     return out
 
 

@@ -194,6 +194,16 @@ enum { SA_MX_LM_W = 0, SA_MX_LM_S, SA_MX_GLOBALS };      /* after the per-layer 
 #define SA_MX_TOTAL(dec_layers) ((dec_layers) * SA_MX_COUNT + SA_MX_GLOBALS)
 int surya_rec_set_mx_weights(surya_rec* h, const void* const* table, int n);
 
+/* FP8 (OCP e4m3) KV cache for the decode steps -- the second half of configs[4]'s fp8 path: at the texify horizon (KV 202 -> 970)
+ * the decode-attention kernel is the largest of the step and moves its rows at HBM speed, so the lever is the bytes. Format "KV8":
+ * per (slot, kv head, token) one power-of-two scale (the smallest with absmax / scale <= 448) + round-to-nearest-even e4m3
+ * elements; K rows [slot][kv_head][max_kv_len][head_dim] bytes, V transposed per 128-token tile [slot][kv_head][T8 / 128][head_dim][128] bytes, scales fp32
+ * [slot][kv_head][T8], T8 = max_kv_len rounded up to 128; the arrays live inside the handle. Prefill still attends over the bf16
+ * cache and quantises the prompt's rows; decode steps read and append fp8 only (decode_attn_kv8.h). bf16 models, head_dim in
+ * {32, 64, 128}. No reference counterpart (surya/recognition/__init__.py:379-395 offers HQQ 8-bit only): the format is pinned by
+ * oracle/mx_oracle.py::kv8_quantize and tests/test_gpu_kv8.py. Call while no line is in flight. */
+int surya_rec_set_kv_fp8(surya_rec* h, int on);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Op-level entry points (unit tests of the kernels through the same library; row-major, compute dtype).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -222,6 +232,15 @@ int surya_op_attn(int dtype, int head_dim, const void* q, const void* k, const v
 int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_slabs, const void* qkv_bias, void* out, void* kcache,
                          void* vcache, const int32_t* active_slots, const int32_t* row_len, const float* rope_cs, int rows, int heads,
                          int kv_heads, int max_kv_len, float scale, void* stream);
+/* The KV8 kernels by themselves (tests): surya_op_kv8_quant_rows quantises rows (tok_slot[i], tok_pos[i]) of bf16 caches
+ * [slot][kv_head][max_kv_len][head_dim] into the KV8 arrays (layout above); surya_op_decode_attn_kv8 = surya_op_decode_attn on those
+ * arrays (bf16 model path only), appending the new token's quantised k / v. All pointers device; enqueue only. */
+int surya_op_kv8_quant_rows(int head_dim, const void* kcache, const void* vcache, const int32_t* tok_slot, const int32_t* tok_pos, int n_tokens,
+                            void* k8, void* v8t, float* kscale, float* vscale, int kv_heads, int max_kv_len, void* stream);
+int surya_op_decode_attn_kv8(int head_dim, const float* qkv_part, int n_slabs, const void* qkv_bias, void* out, void* k8, void* v8t,
+                             float* kscale, float* vscale, const int32_t* active_slots, const int32_t* row_len, const float* rope_cs, int rows,
+                             int heads, int kv_heads, int max_kv_len, float scale, void* stream);
+
 /* MXFP8 ops (csrc/gemm_mx.h). quantize: fp32 rows [rows][K], K % 128 == 0 -> e4m3 [rows][K] + e8m0 scales K-tile-major
  * [K / 128][rows][4], with the rule every producer kernel uses (block scale = smallest power of two that keeps absmax <=
  * 448, round to nearest even). gemm_mx: C[M,N] fp32 = X W^T from MXFP8 operands (scales K-tile-major with M resp. N rows),

@@ -74,3 +74,19 @@ def fake_quant(x: torch.Tensor) -> torch.Tensor:
     """Quantise-dequantise along the last dimension (what an MXFP8 GEMM operand carries)."""
     q, s = quantize(x.detach().float().cpu().numpy())
     return torch.from_numpy(dequantize(q, s)).to(x.dtype)
+
+
+# ---- "KV8": the fp8 KV cache of the decode steps (csrc/decode_attn_kv8.h, include/surya_amd.h surya_rec_set_kv_fp8) -----------------
+# One MX-style block per (token, kv head) that spans the whole head dim: a power-of-two scale (block_exponent above, stored as the
+# fp32 value 2^e) and round-to-nearest-even e4m3 elements. No reference counterpart (see the header comment): this IS the definition.
+
+def kv8_quantize(x: np.ndarray):
+    """[..., D] rows -> (uint8 codes [..., D], float32 scales [...])."""
+    x = x.astype(np.float32)
+    e = block_exponent(np.abs(x).max(-1))
+    q = e4m3_encode(np.ldexp(x.astype(np.float64), -e[..., None]))
+    return q, np.ldexp(np.float32(1.0), e).astype(np.float32)
+
+
+def kv8_dequantize(q: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    return (e4m3_decode(q).astype(np.float64) * scale.astype(np.float64)[..., None]).astype(np.float32)

@@ -30,6 +30,9 @@ ATTN_IMPL = "eager"
 # of the decoder projections and lm_head (oracle/mx_oracle.py; weights from their bf16 rounding, as the product does). There is
 # no reference counterpart -- this pins the product's fp8 arithmetic to the published MX format, not to surya.
 MX_DECODE = False
+# Emulate the FP8 KV cache of the decode steps (csrc/decode_attn_kv8.h): every cached K / V row (one per token and kv head) passes
+# through mx_oracle.kv8_quantize / kv8_dequantize before the decode steps' attention; prefill attends over unquantised rows.
+KV8_DECODE = False
 _MX_W = {}
 
 
@@ -236,7 +239,7 @@ class OracleKV:
 
 
 def decoder_forward(sd: SD, d: DecoderConfig, x: torch.Tensor, attention_mask, position_ids, cache: OracleKV,
-                    taps: Optional[dict] = None, mx: bool = False) -> torch.Tensor:
+                    taps: Optional[dict] = None, mx: bool = False, kv8: bool = False) -> torch.Tensor:
     """SuryaDecoderModel.forward (decoder/__init__.py:417-490) with the eager attention of :101-128."""
     B, S, H = x.shape
     nq, nkv, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
@@ -254,6 +257,10 @@ def decoder_forward(sd: SD, d: DecoderConfig, x: torch.Tensor, attention_mask, p
         q = q * cos + rotate_half(q) * sin                                # apply_rotary_pos_emb :60-84
         k = k * cos + rotate_half(k) * sin
         k, v = cache.update(li, k, v)
+        if kv8:
+            from oracle import mx_oracle as _mo
+            k = torch.from_numpy(_mo.kv8_dequantize(*_mo.kv8_quantize(k.float().numpy()))).to(k.dtype)
+            v = torch.from_numpy(_mo.kv8_dequantize(*_mo.kv8_quantize(v.float().numpy()))).to(v.dtype)
         g = nq // nkv
         kk = k[:, :, None].expand(B, nkv, g, -1, hd).reshape(B, nq, -1, hd)   # repeat_kv :87-98
         vv = v[:, :, None].expand(B, nkv, g, -1, hd).reshape(B, nq, -1, hd)
@@ -311,7 +318,7 @@ class OracleRecModel:
     @torch.inference_mode()
     def decode(self, input_ids, attention_mask, position_ids):
         x = self.sd["embedder.token_embed.weight"][input_ids]
-        h = decoder_forward(self.sd, self.cfg.decoder, x, attention_mask, position_ids, self.cache, mx=MX_DECODE)
+        h = decoder_forward(self.sd, self.cfg.decoder, x, attention_mask, position_ids, self.cache, mx=MX_DECODE, kv8=KV8_DECODE)
         return self.heads(h[:, -1:, :], mx=MX_DECODE)
 
 

@@ -22,6 +22,7 @@
 #include "gemm_mx.h"
 #include "kernels.h"
 #include "decode_attn.h"
+#include "decode_attn_kv8.h"
 #include "attn_mfma.h"
 #include "rec_prep.h"
 
@@ -156,6 +157,7 @@ struct RecBase {
     virtual int copy_last_logits(float*, int, int*, hipStream_t) = 0;
     virtual int set_next_tokens(const int32_t*, const int32_t*, int, hipStream_t) = 0;
     virtual int set_mx_weights(const void* const*, int) = 0;
+    virtual int set_kv_fp8(int) = 0;
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -202,6 +204,13 @@ struct RecModel : RecBase {
     // activation buffers, written by the kernels that produce the bf16 ones.
     std::vector<const uint8_t*> mxw;
     char* mx_arena = nullptr;
+    // FP8 KV cache of the decode steps (surya_rec_set_kv_fp8; decode_attn_kv8.h). Prefill keeps writing (and attending over) the
+    // bf16 cache and quantises the prompt rows into these arrays; the decode steps read and append only here.
+    char* kv8_arena = nullptr;
+    uint8_t *k8c = nullptr, *v8tc = nullptr;     // [layer][slot][kvh][Tmax][D], [layer][slot][kvh][D][Tmax8]
+    float *ksc8 = nullptr, *vsc8 = nullptr;      // [layer][slot][kvh][Tmax8]
+    bool kv8 = false;
+    int tmax8() const { return (c.max_kv_len + 127) & ~127; }
     uint8_t *dh8 = nullptr, *sdh = nullptr, *dattn8 = nullptr, *sattn = nullptr, *dmlp8 = nullptr, *smlp = nullptr, *dlast8 = nullptr,
             *slast = nullptr;
     bool mx() const { return !mxw.empty(); }
@@ -308,6 +317,7 @@ struct RecModel : RecBase {
     }
     ~RecModel() override {
         if (mx_arena) (void)hipFree(mx_arena);
+        if (kv8_arena) (void)hipFree(kv8_arena);
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         if (gstream) (void)hipStreamDestroy(gstream);
         if (gev_in) (void)hipEventDestroy(gev_in);
@@ -511,6 +521,20 @@ struct RecModel : RecBase {
                 return rc;
             hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(M), dim3(256), 0, s, dqkv, d_tok_slot, d_tok_pos, rope_cs, kc, vc,
                                nq, nkv, d, c.max_kv_len);
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (kv8) {
+                    const size_t l8 = (size_t)c.max_slots * nkv, T8 = tmax8();
+                    uint8_t* k8l = k8c + l * l8 * c.max_kv_len * d;
+                    uint8_t* v8l = v8tc + l * l8 * d * T8;
+                    float* ksl = ksc8 + l * l8 * T8;
+                    float* vsl = vsc8 + l * l8 * T8;
+                    dim3 qg(cdiv(M * nkv, 4));
+                    if (d == 128) hipLaunchKernelGGL(kv8_quant_rows_kernel<128>, qg, dim3(256), 0, s, kc, vc, d_tok_slot, d_tok_pos, M, k8l, v8l, ksl, vsl, nkv, c.max_kv_len, (int)T8);
+                    else if (d == 64) hipLaunchKernelGGL(kv8_quant_rows_kernel<64>, qg, dim3(256), 0, s, kc, vc, d_tok_slot, d_tok_pos, M, k8l, v8l, ksl, vsl, nkv, c.max_kv_len, (int)T8);
+                    else if (d == 32) hipLaunchKernelGGL(kv8_quant_rows_kernel<32>, qg, dim3(256), 0, s, kc, vc, d_tok_slot, d_tok_pos, M, k8l, v8l, ksl, vsl, nkv, c.max_kv_len, (int)T8);
+                    else return SA_ERR_UNSUPPORTED;
+                }
+            }
             if ((rc = attention(d, dqkv, kc, vc, dattn, *sg, n_tiles, nq, qkv_d, d, d, (long)c.max_kv_len * d, (long)nq * d, d,
                                 nq / nkv, 1, scale, s))) return rc;
             if ((rc = gemm<EPI_RESIDUAL>(dattn, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, dx, Hd, nullptr, dx, Hd, M, Hd, nq * d,
@@ -545,6 +569,29 @@ struct RecModel : RecBase {
         int rc = launch_gemm_mx_splitk(a, s);
         *S = a.splitk;
         return rc;
+    }
+
+    // FP8 KV cache for the decode steps (bf16 model only). Takes effect for lines prefilled AFTER the call: switch while no line
+    // is in flight.
+    int set_kv_fp8(int on) override {
+        if constexpr (!std::is_same<T, bf16_t>::value) return on ? SA_ERR_UNSUPPORTED : SA_OK;
+        if (!on) { kv8 = false; return SA_OK; }
+        const int d = c.dec_head_dim;
+        if (d != 128 && d != 64 && d != 32) return SA_ERR_UNSUPPORTED;
+        if (c.dec_heads / c.dec_kv_heads > 8) return SA_ERR_UNSUPPORTED;
+        if (!kv8_arena) {
+            const size_t rows = (size_t)c.dec_layers * c.max_slots * c.dec_kv_heads, T8 = tmax8();
+            size_t off = 0;
+            auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+            const size_t o_k = take(rows * c.max_kv_len * d), o_v = take(rows * d * T8), o_ks = take(rows * T8 * 4), o_vs = take(rows * T8 * 4);
+            SA_HIP(hipMalloc((void**)&kv8_arena, off));
+            SA_HIP(hipMemset(kv8_arena, 0, off));           // finite bytes and scales everywhere: masked key columns multiply P = 0
+            SA_HIP(hipDeviceSynchronize());
+            k8c = (uint8_t*)(kv8_arena + o_k); v8tc = (uint8_t*)(kv8_arena + o_v);
+            ksc8 = (float*)(kv8_arena + o_ks); vsc8 = (float*)(kv8_arena + o_vs);
+        }
+        kv8 = true;
+        return SA_OK;
     }
 
     // MXFP8 weight table of the decode steps: per layer SA_MX_COUNT pointers, then SA_MX_LM_W, SA_MX_LM_S. bf16 model only.
@@ -628,13 +675,39 @@ struct RecModel : RecBase {
 #define SA_DEC_MFMA(DD, GG) SA_DEC_LAUNCH((decode_attn_mfma_kernel<T, DD, GG>), (decode_attn_mfma_lds<T, DD, GG>()))
 #define SA_DEC_FLASH(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), at8, sat, c.max_slots)
         bool launched = false;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (kv8) {                                       // FP8 KV cache (decode_attn_kv8.h)
+                const size_t l8 = (size_t)c.max_slots * nkv, T8 = tmax8();
+                uint8_t* k8l = k8c + l * l8 * c.max_kv_len * d;
+                uint8_t* v8l = v8tc + l * l8 * d * T8;
+                float* ksl = ksc8 + l * l8 * T8;
+                float* vsl = vsc8 + l * l8 * T8;
+#define SA_DEC_KV8(DD, GG)                                                                                                       \
+    {                                                                                                                           \
+        auto kern = decode_attn_kv8_kernel<DD, GG>;                                                                             \
+        static AttrOnce attr;                                                                                                   \
+        attr.ensure(kern, decode_attn_kv8_lds<DD, GG>());                                                                       \
+        hipLaunchKernelGGL(kern, grid, block, (decode_attn_kv8_lds<DD, GG>()), s, h.part, S, WD(l, SA_RD_QKV_B), at, k8l, v8l, ksl, \
+                           vsl, act, rl, rope_cs, nq, nkv, c.max_kv_len, (int)T8, scale, at8, sat, c.max_slots);                \
+    }
+                launched = true;
+                if (d == 128 && G <= 5) SA_DEC_KV8(128, 5)
+                else if (d == 128 && G <= 8) SA_DEC_KV8(128, 8)
+                else if (d == 64 && G <= 8) SA_DEC_KV8(64, 8)
+                else if (d == 32 && G <= 8) SA_DEC_KV8(32, 8)
+                else return SA_ERR_UNSUPPORTED;
+#undef SA_DEC_KV8
+            }
+        }
         if constexpr (std::is_same<T, bf16_t>::value) {      // bf16: per-wave flash kernel (decode_attn.h, third version)
+          if (!launched) {
             launched = true;
             if (d == 128 && G <= 5) SA_DEC_FLASH(128, 5)
             else if (d == 128 && G <= 8) SA_DEC_FLASH(128, 8)
             else if (d == 64 && G <= 8) SA_DEC_FLASH(64, 8)
             else if (d == 32 && G <= 8) SA_DEC_FLASH(32, 8)
             else launched = false;
+          }
         }
         if (!launched) {                                     // fp32 reference mode (and head shapes the flash kernel lacks)
             if (d == 128 && G <= 5) SA_DEC_MFMA(128, 5)
@@ -1048,6 +1121,11 @@ int surya_rec_set_mx_weights(surya_rec* h, const void* const* table, int n) {
     return h->impl->set_mx_weights(table, n);
 }
 
+int surya_rec_set_kv_fp8(surya_rec* h, int on) {
+    if (!h) return SA_ERR_ARG;
+    return h->impl->set_kv_fp8(on);
+}
+
 int surya_op_gemm(int dtype, int out_f32, int epi, const void* X, long ldx, const void* W, long ldw, void* C, long ldc,
                   const void* bias, const void* R, long ldr, int M, int N, int K, void* stream) {
     if (!X || !W || !C) return SA_ERR_ARG;
@@ -1167,6 +1245,50 @@ int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_s
 #undef SA_OPD_FLASH
 #undef SA_OPD_MFMA
 #undef SA_OPD
+    return (int)hipGetLastError();
+}
+
+int surya_op_kv8_quant_rows(int head_dim, const void* kcache, const void* vcache, const int32_t* tok_slot, const int32_t* tok_pos, int n_tokens,
+                            void* k8, void* v8t, float* kscale, float* vscale, int kv_heads, int max_kv_len, void* stream) {
+    if (!kcache || !vcache || !tok_slot || !tok_pos || !k8 || !v8t || !kscale || !vscale || n_tokens <= 0 || kv_heads <= 0) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int T8 = (max_kv_len + 127) & ~127;
+    dim3 qg(cdiv(n_tokens * kv_heads, 4));
+#define SA_Q8(DD)                                                                                                                  \
+    hipLaunchKernelGGL(kv8_quant_rows_kernel<DD>, qg, dim3(256), 0, s, (const bf16_t*)kcache, (const bf16_t*)vcache, tok_slot, tok_pos, \
+                       n_tokens, (uint8_t*)k8, (uint8_t*)v8t, kscale, vscale, kv_heads, max_kv_len, T8)
+    if (head_dim == 128) SA_Q8(128);
+    else if (head_dim == 64) SA_Q8(64);
+    else if (head_dim == 32) SA_Q8(32);
+    else return SA_ERR_UNSUPPORTED;
+#undef SA_Q8
+    return (int)hipGetLastError();
+}
+
+int surya_op_decode_attn_kv8(int head_dim, const float* qkv_part, int n_slabs, const void* qkv_bias, void* out, void* k8, void* v8t,
+                             float* kscale, float* vscale, const int32_t* active_slots, const int32_t* row_len, const float* rope_cs, int rows,
+                             int heads, int kv_heads, int max_kv_len, float scale, void* stream) {
+    if (!qkv_part || !qkv_bias || !out || !k8 || !v8t || !kscale || !vscale || !active_slots || !row_len || !rope_cs) return SA_ERR_ARG;
+    if (rows <= 0 || n_slabs < 1 || n_slabs > 8 || kv_heads <= 0 || heads % kv_heads) return SA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = heads / kv_heads, d = head_dim, T8 = (max_kv_len + 127) & ~127;
+    dim3 grid(rows, kv_heads), block(256);
+    const float2* cs = reinterpret_cast<const float2*>(rope_cs);
+#define SA_OPD8(DD, GG)                                                                                                          \
+    {                                                                                                                           \
+        auto kern = decode_attn_kv8_kernel<DD, GG>;                                                                             \
+        static AttrOnce attr;                                                                                                   \
+        attr.ensure(kern, decode_attn_kv8_lds<DD, GG>());                                                                       \
+        hipLaunchKernelGGL(kern, grid, block, (decode_attn_kv8_lds<DD, GG>()), s, qkv_part, n_slabs, (const bf16_t*)qkv_bias,   \
+                           (bf16_t*)out, (uint8_t*)k8, (uint8_t*)v8t, kscale, vscale, active_slots, row_len, cs, heads, kv_heads, \
+                           max_kv_len, T8, scale, (uint8_t*)nullptr, (uint8_t*)nullptr, 0);                                     \
+    }
+    if (d == 128 && G <= 5) SA_OPD8(128, 5)
+    else if (d == 128 && G <= 8) SA_OPD8(128, 8)
+    else if (d == 64 && G <= 8) SA_OPD8(64, 8)
+    else if (d == 32 && G <= 8) SA_OPD8(32, 8)
+    else return SA_ERR_UNSUPPORTED;
+#undef SA_OPD8
     return (int)hipGetLastError();
 }
 

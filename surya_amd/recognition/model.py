@@ -72,6 +72,10 @@ class HipRecModel:
             decode_fp8 = settings.RECOGNITION_DECODE_FP8
         if decode_fp8:
             self.set_decode_fp8(True)
+        self.kv_fp8 = False
+        from ..settings import settings as _settings
+        if _settings.RECOGNITION_KV_FP8:
+            self.set_kv_fp8(True)
 
     def set_decode_fp8(self, on: bool):
         """Decode steps on MXFP8 weights and activations (surya_rec_set_mx_weights; bf16 models only). The e4m3 / e8m0 twins
@@ -89,6 +93,15 @@ class HipRecModel:
             L.check(self.lib.surya_rec_set_mx_weights(self.handle, None, C.c_int(0)), "surya_rec_set_mx_weights")
         torch.cuda.synchronize(self.device)
         self.decode_fp8 = bool(on)
+
+    def set_kv_fp8(self, on: bool):
+        """Decode steps on an FP8 (e4m3 + one power-of-two scale per token and kv head) KV cache (surya_rec_set_kv_fp8,
+        csrc/decode_attn_kv8.h; bf16 models only). Prefill still attends over the bf16 cache; lines prefilled after the call decode
+        from the fp8 arrays. Switch while no line is in flight."""
+        if on and self.dtype != torch.bfloat16:
+            raise ValueError("the fp8 KV cache exists for bfloat16 models only")
+        L.check(self.lib.surya_rec_set_kv_fp8(self.handle, C.c_int(1 if on else 0)), "surya_rec_set_kv_fp8")
+        self.kv_fp8 = bool(on)
 
     def __del__(self):
         h = getattr(self, "handle", None)

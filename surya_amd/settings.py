@@ -52,6 +52,8 @@ class Settings:
         # decode steps on MXFP8 weights + activations (csrc/gemm_mx.h; BASELINE.json configs[4]). Off by default: the
         # reference computes in the checkpoint dtype, and fp8 changes which token wins a near-tie
         self.RECOGNITION_DECODE_FP8: bool = _env("RECOGNITION_DECODE_FP8", bool, False)
+        # decode steps on an fp8 KV cache (csrc/decode_attn_kv8.h): pays at long horizons (texify); off by default for the same reason
+        self.RECOGNITION_KV_FP8: bool = _env("RECOGNITION_KV_FP8", bool, False)
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
         # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the

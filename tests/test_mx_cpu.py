@@ -74,3 +74,26 @@ def test_mx_weight_table_layout():
     assert torch.equal(mx.tile_major_scales(s_rows), t[5])
     back = mx.dequantize_mx(t[4], s_rows)
     assert (back - src).abs().max() <= src.abs().max() * 2.0 ** -4
+
+
+def test_kv8_row_format_properties():
+    """The fp8 KV cache row format (oracle/mx_oracle.py::kv8_quantize; csrc/decode_attn_kv8.h): power-of-two scale, nothing
+    saturates, error <= 1/16 of the row's absmax per element, dequantised rows are fixed points in value and exact in bf16."""
+    import torch
+    from oracle import mx_oracle as mo
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((7, 3, 128)) * np.exp2(rng.integers(-8, 9, (7, 3, 1)))).astype(np.float32)
+    x[0, 0] = 0.0                                            # an all-zero row
+    x[1, 1, 5] = 448.0 * 4                                   # a row whose absmax sits exactly on the format maximum after scaling
+    q, s = mo.kv8_quantize(x)
+    assert q.dtype == np.uint8 and s.shape == x.shape[:-1]
+    assert (np.log2(s[s > 0]) % 1 == 0).all()
+    d = mo.kv8_dequantize(q, s)
+    assert np.isfinite(d).all() and (d[0, 0] == 0).all()
+    amax = np.abs(x).max(-1, keepdims=True)
+    assert (np.abs(d - x) <= amax / 16 + 1e-30).all()
+    assert np.array_equal(mo.kv8_dequantize(*mo.kv8_quantize(d)), d)
+    assert np.array_equal(torch.from_numpy(d).bfloat16().float().numpy(), d)
+    # torch's own e4m3 cast agrees with the table-based encoder on scaled rows
+    scaled = torch.from_numpy(x / s[..., None].clip(min=1e-38))
+    assert np.array_equal(scaled.to(torch.float8_e4m3fn).view(torch.uint8).numpy() & 0x7F, q & 0x7F)
