@@ -343,18 +343,29 @@ typedef struct surya_layout_config {
     int32_t vocab, label_count, bbox_size;
     float rms_eps, ln_eps;
     int32_t max_batch, max_boxes, dtype;
+    /* Model family on the same encoder / decoder stack:
+     *   SA_FAMILY_LAYOUT (0): surya/layout -- 7-number tokens, BboxEmbedding (15 tables of dec_hidden), double residual flow
+     *     (layout/model/config.py:221), heads = lm_head [label_count] + sigmoid(bbox_head + bias);
+     *   SA_FAMILY_TABLE (1): surya/table_rec -- 10-number tokens (bbox 6, category, merges, colspan, is_header), LabelEmbedding =
+     *     concat(14 box tables of box_embed, category + merge + colspan tables of dec_hidden - box_embed)
+     *     (table_rec/model/decoder.py:12-73), the plain residual flow (adetr/decoder.py:395-417), heads = the four non-bbox
+     *     box_property_heads stacked [category | merges | colspan | is_header] (label_count rows in all, no bias) + sigmoid(bbox head). */
+    int32_t family, box_embed, category_count, merge_count;
 } surya_layout_config;
+enum { SA_FAMILY_LAYOUT = 0, SA_FAMILY_TABLE = 1 };
 
 /* Weight table (device pointers, compute dtype unless noted; Linear weights [out, in]):
  *   globals SA_LW_*; PATCH_W is [embed_dim][64] = the Conv2d weight flattened (c, ky, kx) and zero padded; DEC_INVFREQ fp32 [hd / 2];
  *   DEC_ZERO_BIAS = zeros [(heads + 2 kv_heads) * hd] (the ADETR attention has no qkv bias; the fused decode-attention kernel takes one);
- *   EMB_TABLES = 15 tables in the order w, h, cx, cy, xskew, yskew, x1, y1, x2, y2, x3, y3, x4, y4 ([vocab][hidden]), label ([label_count][hidden]);
+ *   EMB_TABLES = 17 slots: w, h, cx, cy, xskew, yskew, x1, y1, x2, y2, x3, y3, x4, y4 ([vocab][hidden], table family [vocab][box_embed]), then
+ *     layout: label ([label_count][hidden]) + 2 unused; table: category ([category_count][P]), merge ([merge_count][P]), colspan ([vocab][P]),
+ *     P = dec_hidden - box_embed;
  *   per stage SA_LS_* (SINCOS = the stage's 2-D sin-cos table [tokens][dim] built as the reference builds it; MERGE_* of the last stage
  *   are ignored), then per block SA_LB_* (QKV fused q | k | v rows; RELBIAS fp32 [heads][64][64] = relative_position_bias_table gathered
  *   through relative_position_index, rounded to the compute dtype first); then per decoder layer SA_LD_* (CKV_W = cross k | v rows fused,
  *   QKV_W = self q | k | v fused, GU_W = gate / up rows interleaved g0, u0, g1, u1 ...). */
 enum { SA_LW_PATCH_W = 0, SA_LW_PATCH_B, SA_LW_EMB_LN_W, SA_LW_EMB_LN_B, SA_LW_POS_EMB, SA_LW_DEC_FNORM, SA_LW_DEC_LN_W, SA_LW_DEC_LN_B,
-       SA_LW_DEC_LM_W, SA_LW_DEC_BB_W, SA_LW_DEC_BB_B, SA_LW_DEC_INVFREQ, SA_LW_DEC_ZERO_BIAS, SA_LW_EMB_TABLES, SA_LW_GLOBALS = SA_LW_EMB_TABLES + 15 };
+       SA_LW_DEC_LM_W, SA_LW_DEC_BB_W, SA_LW_DEC_BB_B, SA_LW_DEC_INVFREQ, SA_LW_DEC_ZERO_BIAS, SA_LW_EMB_TABLES, SA_LW_GLOBALS = SA_LW_EMB_TABLES + 17 };
 enum { SA_LS_SINCOS = 0, SA_LS_MERGE_NORM_W, SA_LS_MERGE_NORM_B, SA_LS_MERGE_RED_W, SA_LS_COUNT };
 enum { SA_LB_LN1_W = 0, SA_LB_LN1_B, SA_LB_QKV_W, SA_LB_QKV_B, SA_LB_RELBIAS, SA_LB_PROJ_W, SA_LB_PROJ_B, SA_LB_LN2_W, SA_LB_LN2_B, SA_LB_FC1_W,
        SA_LB_FC1_B, SA_LB_FC2_W, SA_LB_FC2_B, SA_LB_COUNT };
@@ -368,9 +379,15 @@ int surya_layout_destroy(surya_layout* h);
  * inside the handle and projects every decoder layer's cross-attention keys / values; resets the self-attention caches. Enqueue only. */
 int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, void* stream);
 /* One decoder token per image at cache position `position` (0 = the start token): boxes host int32 [batch][7] = (cx, cy, w, h, xskew,
- * yskew, label) as the reference feeds them back; class_logits host fp32 [batch][label_count], bbox host fp32 [batch][6] (after the
+ * yskew, label) as the reference feeds them back (table family: [batch][10] = bbox 6, category, merges, colspan, is_header -- a prompt of
+ * T tokens is T calls, which is what a causal prefill computes); class_logits host fp32 [batch][label_count], bbox host fp32 [batch][6] (after the
  * sigmoid). Synchronises the stream (the reference moves both to the host after every step as well). */
 int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream);
+/* Re-batch the decoder after surya_layout_encode: the following decode steps run n rows (n <= max_batch), row i cross-attending the
+ * encoder states of image src_index[i] (host array, values < the encoded batch). Table recognition decodes the cells of every detected
+ * ROW against its table image (surya/table_rec/__init__.py:196-230: row_encoder_hidden_states = stacked copies); here the copies are an
+ * index. Synchronous. */
+int surya_layout_select(surya_layout* h, const int32_t* src_index, int n);
 /* Test hook: encoder output [batch * tokens, hidden] of the last encode (device, compute dtype). */
 int surya_layout_encoder_states(surya_layout* h, void* out, int batch, void* stream);
 

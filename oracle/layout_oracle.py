@@ -182,6 +182,26 @@ def embed_boxes(sd: SD, d, boxes: torch.Tensor) -> torch.Tensor:
     return label_e + size_e + skew_e + corner_e
 
 
+def embed_table_tokens(sd: SD, d, boxes: torch.Tensor) -> torch.Tensor:
+    """LabelEmbedding.forward of the table-recognition decoder (table_rec/model/decoder.py:46-73). boxes: long [B, T, 10] =
+    (cx, cy, w, h, xskew, yskew, category, merges, colspan, is_header); is_header is not embedded; x2 / y2 / x4 / y4 tables exist but
+    only x1, y1, x3, y3 are read."""
+    p = "decoder.model.embed_tokens."
+    boxes = boxes.to(torch.long).clamp(0, d.vocab_size)
+    cx, cy, w, h, xs, ys, cat, mer, col, _ = boxes.unbind(dim=-1)
+    xa = ((xs - d.bbox_size // 2) / 2).to(torch.long)
+    ya = ((ys - d.bbox_size // 2) / 2).to(torch.long)
+    cl = lambda t: t.clamp(0, d.bbox_size).to(torch.long)
+    x1, y1 = cl(cx - w // 2 - xa), cl(cy - h // 2 - ya)
+    x3, y3 = cl(cx + w // 2 + xa), cl(cy + h // 2 + ya)
+    E = lambda nm, idx: sd[p + nm + "_embed.weight"][idx]
+    size_e = E("w", w) + E("h", h) + E("cx", cx) + E("cy", cy)
+    skew_e = E("xskew", xs) + E("yskew", ys)
+    corner_e = E("x1", x1) + E("y1", y1) + E("x3", x3) + E("y3", y3)
+    prop_e = E("category", cat) + E("merge", mer) + E("colspan", col)
+    return torch.cat([size_e + skew_e + corner_e, prop_e], dim=-1)
+
+
 class LayoutDecoderState:
     """Caches of one batch: cross-attention K / V of the encoder states (computed at the first call, adetr/decoder.py:167-173) and
     the growing self-attention K / V (dynamic cache, :300-311)."""
@@ -195,10 +215,14 @@ class LayoutDecoderState:
 
 def decoder_forward(sd: SD, d, boxes: torch.Tensor, enc: torch.Tensor, pos0: int, st: LayoutDecoderState):
     """SuryaLayoutDecoder.forward (layout/model/decoder.py:96-131) for T new tokens at positions pos0 .. pos0 + T - 1:
-    returns (bbox_logits [B, T, 6] after sigmoid, class_logits [B, T, label_count])."""
+    returns (bbox_logits [B, T, 6] after sigmoid, class_logits [B, T, label_count]).
+    With a table_rec TableDecoderConfig: SuryaTableRecDecoder.forward (table_rec/model/decoder.py:115-154) -- LabelEmbedding, the plain
+    residual flow (double_residual_flow = False, config.py:219), one bias-free head per box property -- returning
+    (sigmoid(bbox) [B, T, 6], {property: logits [B, T, n]})."""
     B, T, _ = boxes.shape
     nq, nkv, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
-    x = embed_boxes(sd, d, boxes)
+    table = hasattr(d, "box_embed_size")
+    x = embed_table_tokens(sd, d, boxes) if table else embed_boxes(sd, d, boxes)
     pos = torch.arange(pos0, pos0 + T, dtype=torch.float32)
     inv = 1.0 / (d.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
     fr = pos[:, None] * inv[None, :]
@@ -235,12 +259,16 @@ def decoder_forward(sd: SD, d, boxes: torch.Tensor, enc: torch.Tensor, pos0: int
         st.self_v[li] = v if st.self_v[li] is None else torch.cat([st.self_v[li], v], dim=2)
         a = F.scaled_dot_product_attention(q, rep(st.self_k[li]), rep(st.self_v[li]), attn_mask=cm[None, None], scale=hd ** -0.5)
         a = a.transpose(1, 2).reshape(B, T, nq * hd)
-        res = F.linear(a, sd[p + "temporal_block.o_proj.weight"], sd[p + "temporal_block.o_proj.bias"]) + raw
+        # layout adds the layer's RAW input here (double_res_forward, adetr/decoder.py:419-457), table_rec the cross-attention output (:395-417)
+        res = F.linear(a, sd[p + "temporal_block.o_proj.weight"], sd[p + "temporal_block.o_proj.bias"]) + (cross if table else raw)
         h = adetr_rms_norm(res, sd[p + "channel_pre_norm.weight"], d.rms_norm_eps)
         h = F.gelu(F.linear(h, sd[p + "mlp_block.gate_proj.weight"]), approximate="tanh") * F.linear(h, sd[p + "mlp_block.up_proj.weight"])
         x = F.linear(h, sd[p + "mlp_block.down_proj.weight"]) + res
     x = adetr_rms_norm(x, sd["decoder.model.final_norm.weight"], d.rms_norm_eps)
     x = F.layer_norm(x, (d.hidden_size,), sd["decoder.pre_output_norm.weight"], sd["decoder.pre_output_norm.bias"], d.layer_norm_eps)
+    if table:
+        props = {k: F.linear(x, sd[f"decoder.box_property_heads.{k}.weight"]) for k, _ in d.head_widths()}
+        return torch.sigmoid(props.pop("bbox")), props
     cls = F.linear(x, sd["decoder.lm_head.weight"])
     box = torch.sigmoid(F.linear(x, sd["decoder.bbox_head.weight"], sd["decoder.bbox_head.bias"]))
     return box, cls

@@ -122,3 +122,16 @@ def import_layout_modules():
     adetr.SuryaADETRDecoderPreTrainedModel.tie_weights = lambda self, *a, **k: None
     decm = import_submodule("surya.layout.model.decoder")
     return cfgm, encm, decm
+
+
+def import_table_modules():
+    """(config, encoder, decoder, shaper, processor-less helpers) modules of the reference's table-recognition model, patched like
+    import_layout_modules (tie_weights signature)."""
+    install_layout()
+    cfgm = import_submodule("surya.table_rec.model.config")
+    encm = import_submodule("surya.table_rec.model.encoder")
+    adetr = import_submodule("surya.common.adetr.decoder")
+    adetr.SuryaADETRDecoderPreTrainedModel.tie_weights = lambda self, *a, **k: None
+    decm = import_submodule("surya.table_rec.model.decoder")
+    shaper = import_submodule("surya.table_rec.shaper")
+    return cfgm, encm, decm, shaper

@@ -347,6 +347,41 @@ __global__ __launch_bounds__(256) void box_embed_kernel(const int* __restrict__ 
     }
 }
 
+// LabelEmbedding of the table-recognition decoder (surya/table_rec/model/decoder.py:12-73): 10-number tokens (cx, cy, w, h, xskew, yskew,
+// category, merges, colspan, is_header); columns [0, BE) = the box embedding (w + h + cx + cy) + (xskew + yskew) + (x1 + y1 + x3 + y3) from
+// tables of width BE, columns [BE, Hd) = category + merge + colspan from tables of width Hd - BE; is_header is not embedded. Rounded to
+// the storage dtype after every addition, in the reference's order. tables: the 14 box tables (x2 / y2 / x4 / y4 exist but are not read,
+// :25-30 vs :63), then category, merge, colspan.
+template <typename T>
+__global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict__ boxes, const T* const* __restrict__ tabs, T* __restrict__ x,
+                                                          int Hd, int BE, int bbox_size, int vocab, int category_count, int merge_count) {
+    const int b = blockIdx.x;
+    const int* bx = boxes + b * 10;
+    auto clampv = [&](int v) { return min(max(v, 0), vocab - 1); };          // boxes.clamp(0, vocab_size) (:48); index vocab would be out of range
+    const int cx = clampv(bx[0]), cy = clampv(bx[1]), w = clampv(bx[2]), h = clampv(bx[3]), xs = clampv(bx[4]), ys = clampv(bx[5]);
+    const int cat = min(clampv(bx[6]), category_count - 1), mer = min(clampv(bx[7]), merge_count - 1), col = clampv(bx[8]);
+    const int xa = (int)((float)(xs - bbox_size / 2) / 2.0f), ya = (int)((float)(ys - bbox_size / 2) / 2.0f);
+    auto cl = [&](int v) { return min(max(v, 0), bbox_size); };
+    const int x1 = cl(cx - w / 2 - xa), y1 = cl(cy - h / 2 - ya), x3 = cl(cx + w / 2 + xa), y3 = cl(cy + h / 2 + ya);
+    const int P = Hd - BE;
+    auto R = [](float v) { return Ty<T>::rnd(v); };
+    for (int c = threadIdx.x; c < Hd; c += 256) {
+        float e;
+        if (c < BE) {
+            auto E = [&](int t, int idx) { return Ty<T>::ld(tabs[t] + (long)idx * BE + c); };
+            const float size_e = R(R(R(E(0, w) + E(1, h)) + E(2, cx)) + E(3, cy));
+            const float skew_e = R(E(4, xs) + E(5, ys));
+            const float corner = R(R(R(E(6, x1) + E(7, y1)) + E(10, x3)) + E(11, y3));
+            e = R(R(size_e + skew_e) + corner);
+        } else {
+            const int pc = c - BE;
+            auto E = [&](int t, int idx) { return Ty<T>::ld(tabs[t] + (long)idx * P + pc); };
+            e = R(R(E(14, cat) + E(15, mer)) + E(16, col));
+        }
+        Ty<T>::st(x + (long)b * Hd + c, e);
+    }
+}
+
 // SuryaADETRDecoderRMSNorm (adetr/decoder.py:23-47): variance CLAMPED at eps (not added), scale (1 + weight), clamp to the storage
 // dtype's finite range, NaN -> 0. One wave per row.
 template <typename T>
@@ -447,7 +482,8 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
 //   * the range's (max, sum, un-normalised output) goes to `scratch`; cross_attn_merge_kernel merges the NS ranges.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void cross_attn_split_kernel(const float* __restrict__ qpart, int S, int M, const T* __restrict__ kv,
-                                                               float* __restrict__ scratch, int nq, int nkv, int Lk, int chunk, float scale) {
+                                                               float* __restrict__ scratch, const int* __restrict__ item_map, int nq, int nkv,
+                                                               int Lk, int chunk, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int G = nq / nkv;
     float* sc = reinterpret_cast<float*>(smem_raw);                 // [G][chunk] scores -> exp()
@@ -458,7 +494,7 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const float* __re
     const int wave = tid >> 6, lane = tid & 63;
     const int row_w = 2 * nkv * D, Hq = nq * D;
     const int j0 = sp * chunk, nk = min(chunk, Lk - j0);
-    const T* kb = kv + ((long)b * Lk + j0) * row_w + kvh * D;
+    const T* kb = kv + ((long)item_map[b] * Lk + j0) * row_w + kvh * D;       // row b attends the encoder states of image item_map[b]
     const T* vb = kb + nkv * D;
     for (int i = tid; i < G * D; i += 256) {
         float a = 0.f;
@@ -575,8 +611,8 @@ __global__ __launch_bounds__(256) void cross_attn_merge_kernel(const float* __re
 //   y     <- clamp(x_out * rsqrt(max(mean(x_out^2), eps)) * (1 + w))        (skipped when w == nullptr)
 // One workgroup per row, blockDim = H / 4 rounded up to whole waves: every thread owns one 4-element chunk.
 template <typename T>
-__global__ __launch_bounds__(1024) void splitk_residual_adetr_norm_kernel(const float* __restrict__ part, int S, int M, const T* __restrict__ res,
-                                                                          const T* __restrict__ bias, T* __restrict__ x_out,
+__global__ __launch_bounds__(1024) void splitk_residual_adetr_norm_kernel(const float* __restrict__ part, int S, int M, const T* res,
+                                                                          const T* __restrict__ bias, T* x_out,     // res may be x_out
                                                                           const T* __restrict__ w, T* __restrict__ y, int H, float eps) {
     const int row = blockIdx.x, tid = threadIdx.x;
     __shared__ float red[16];

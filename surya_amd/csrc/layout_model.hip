@@ -31,6 +31,7 @@ struct LayoutBase {
     virtual int encode(const float* pixels, int B, hipStream_t s) = 0;
     virtual int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) = 0;
     virtual int encoder_states(void* out, int B, hipStream_t s) = 0;
+    virtual int select(const int32_t* src, int n) = 0;
 };
 
 static size_t lalign(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -57,10 +58,13 @@ struct LayoutModel : LayoutBase {
     float* part;
     float* cross_scratch;                        // [B][nq][ranges][hd + 2] partial cross-attention records
     int cross_ranges = 1, cross_chunk = 0;
+    int* cross_map_dev = nullptr;                // [max_batch] decoder row -> encoded image whose K / V it cross-attends
+    int batch_active = 0;                        // decoder rows of the current decode (encode: = batch; select: any re-batching)
     float2* rope_cs;
     int *boxes_dev, *slots_dev, *len_dev;
     float *cls_dev, *box_dev;
-    const T** tabs_dev = nullptr;                // 15 embedding table pointers
+    const T** tabs_dev = nullptr;                // 17 embedding table pointers
+    int tokw() const { return c.family == SA_FAMILY_TABLE ? 10 : 7; }
     char* pinned = nullptr;
     int Lk = 0, enc_rows_final = 0, batch_encoded = 0;
 
@@ -97,10 +101,10 @@ struct LayoutModel : LayoutBase {
         const size_t o_rope = take((size_t)c.max_boxes * (hd() / 2) * sizeof(float2));
         cross_chunk = (Lk + std::max(1, std::min(8, Lk / 128)) - 1) / std::max(1, std::min(8, Lk / 128));     // >= 128 keys per range
         cross_ranges = (Lk + cross_chunk - 1) / cross_chunk;
-        const size_t o_cscr = take(B * c.dec_heads * cross_ranges * (hd() + 2) * sizeof(float));
-        const size_t o_boxes = take(B * 7 * sizeof(int)), o_slots = take(B * sizeof(int)), o_len = take(B * sizeof(int));
+        const size_t o_cscr = take(B * c.dec_heads * cross_ranges * (hd() + 2) * sizeof(float)), o_cmap = take(B * sizeof(int));
+        const size_t o_boxes = take(B * 10 * sizeof(int)), o_slots = take(B * sizeof(int)), o_len = take(B * sizeof(int));
         const size_t o_cls = take(B * c.label_count * sizeof(float)), o_box = take(B * 6 * sizeof(float));
-        const size_t o_tabs = take(15 * sizeof(void*));
+        const size_t o_tabs = take(17 * sizeof(void*));
         // permutation tables: two per stage
         std::vector<size_t> o_perm;
         {
@@ -117,7 +121,7 @@ struct LayoutModel : LayoutBase {
         ckv = (T*)(b + o_ckv); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
         dx = (T*)(b + o_dx); dh = (T*)(b + o_dh); dq = (T*)(b + o_dq); dattn = (T*)(b + o_da); dres = (T*)(b + o_dr); dmlp = (T*)(b + o_dm);
         part = (float*)(b + o_part); rope_cs = (float2*)(b + o_rope);
-        cross_scratch = (float*)(b + o_cscr);
+        cross_scratch = (float*)(b + o_cscr); cross_map_dev = (int*)(b + o_cmap);
         boxes_dev = (int*)(b + o_boxes); slots_dev = (int*)(b + o_slots); len_dev = (int*)(b + o_len);
         cls_dev = (float*)(b + o_cls); box_dev = (float*)(b + o_box); tabs_dev = (const T**)(b + o_tabs);
         {   // window-order row of every token, per stage and shift (window_partition after torch.roll(-shift), donut/encoder.py:624-636)
@@ -147,15 +151,15 @@ struct LayoutModel : LayoutBase {
             std::vector<int> ident(B);
             for (size_t i = 0; i < B; ++i) ident[i] = (int)i;
             SA_HIP(hipMemcpy(slots_dev, ident.data(), B * sizeof(int), hipMemcpyHostToDevice));
-            const void* tabs[15];
-            for (int i = 0; i < 15; ++i) tabs[i] = w[SA_LW_EMB_TABLES + i];
+            const void* tabs[17];
+            for (int i = 0; i < 17; ++i) tabs[i] = w[SA_LW_EMB_TABLES + i];
             SA_HIP(hipMemcpy((void*)tabs_dev, tabs, sizeof(tabs), hipMemcpyHostToDevice));
             const int half = hd() / 2, nn = c.max_boxes * half;
             hipLaunchKernelGGL(rope_table_kernel<T>, dim3(cdiv(nn, 256)), dim3(256), 0, 0, reinterpret_cast<const float*>(w[SA_LW_DEC_INVFREQ]),
                                rope_cs, c.max_boxes, half);
             SA_HIP(hipGetLastError());
         }
-        SA_HIP(hipHostMalloc((void**)&pinned, B * (7 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
+        SA_HIP(hipHostMalloc((void**)&pinned, B * (10 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
         SA_HIP(hipDeviceSynchronize());
         return SA_OK;
     }
@@ -236,7 +240,8 @@ struct LayoutModel : LayoutBase {
             hipLaunchKernelGGL(lay::add_rows_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, W(SA_LW_POS_EMB), rows, h * wd, dim);
         }
         enc_rows_final = (int)rows;
-        batch_encoded = B;
+        batch_encoded = batch_active = B;
+        SA_HIP(hipMemcpyAsync(cross_map_dev, slots_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));     // identity
         // cross-attention keys / values of every decoder layer (adetr/decoder.py:167-173: projected once, then cached)
         const int kv2 = 2 * kvd();
         for (int l = 0; l < c.dec_layers; ++l) {
@@ -254,17 +259,32 @@ struct LayoutModel : LayoutBase {
         return SA_OK;
     }
 
+    // Decoder rows != encoded images: row i cross-attends image src[i] (table recognition's cell pass). Synchronous, tiny.
+    int select(const int32_t* src, int n) override {
+        if (n <= 0 || n > c.max_batch || batch_encoded <= 0) return SA_ERR_ARG;
+        for (int i = 0; i < n; ++i)
+            if (src[i] < 0 || src[i] >= batch_encoded) return SA_ERR_ARG;
+        SA_HIP(hipDeviceSynchronize());
+        SA_HIP(hipMemcpy(cross_map_dev, src, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        batch_active = n;
+        return SA_OK;
+    }
+
     int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) override {
-        if (B != batch_encoded) return SA_ERR_STATE;
+        if (B != batch_active) return SA_ERR_STATE;
         if (pos < 0 || pos >= c.max_boxes) return SA_ERR_ARG;
         const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
         const int qkv_d = Hd + 2 * kv, He = c.embed_dim << (c.n_stages - 1);
         int rc;
         int* hb = reinterpret_cast<int*>(pinned);
-        memcpy(hb, boxes, (size_t)B * 7 * sizeof(int));
-        SA_HIP(hipMemcpyAsync(boxes_dev, hb, (size_t)B * 7 * sizeof(int), hipMemcpyHostToDevice, s));
+        memcpy(hb, boxes, (size_t)B * tokw() * sizeof(int));
+        SA_HIP(hipMemcpyAsync(boxes_dev, hb, (size_t)B * tokw() * sizeof(int), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, len_dev, pos, B);
-        hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.bbox_size, c.vocab, c.label_count);
+        if (c.family == SA_FAMILY_TABLE)
+            hipLaunchKernelGGL(lay::table_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.box_embed, c.bbox_size, c.vocab,
+                               c.category_count, c.merge_count);
+        else
+            hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.bbox_size, c.vocab, c.label_count);
         const float scale = 1.0f / sqrtf((float)d);
         const size_t layer_kv = (size_t)c.max_batch * nkv * c.max_boxes * d;
         // Every M = B projection runs split-K (64 x 64 tiles over ~128-256 workgroups instead of 32) and hands its slabs to the
@@ -297,11 +317,11 @@ struct LayoutModel : LayoutBase {
                 if (G > 8 || G * (d / 4) > 256) return SA_ERR_UNSUPPORTED;
                 const int mblocks = cdiv(B * nq * (d / 4), 256);
                 if (d == 64) {
-                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, nq, nkv, Lk,
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, cross_map_dev, nq, nkv, Lk,
                                        cross_chunk, scale);
                     hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 64>), dim3(mblocks), dim3(256), 0, s, cross_scratch, dattn, B * nq, cross_ranges);
                 } else if (d == 32) {
-                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 32>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, nq, nkv, Lk,
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 32>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, cross_map_dev, nq, nkv, Lk,
                                        cross_chunk, scale);
                     hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 32>), dim3(mblocks), dim3(256), 0, s, cross_scratch, dattn, B * nq, cross_ranges);
                 } else return SA_ERR_UNSUPPORTED;
@@ -339,7 +359,8 @@ struct LayoutModel : LayoutBase {
 #undef SA_LAY_DEC
             }
             if ((rc = splitk(dattn, Hd, W(lb + SA_LD_TO_W), Hd, Hd, S))) return rc;
-            reduce_norm(S, dx, W(lb + SA_LD_TO_B), dres, W(lb + SA_LD_MNORM));              // dres = residual, dh = channel_pre_norm(residual)
+            // layout: + RAW layer input (double residual flow); table_rec: + the cross-attention output (adetr/decoder.py:395-417)
+            reduce_norm(S, c.family == SA_FAMILY_TABLE ? dres : dx, W(lb + SA_LD_TO_B), dres, W(lb + SA_LD_MNORM));   // dh = channel_pre_norm(residual)
             // MLP: x = down(gelu_tanh(gate(n)) * up(n)) + residual; dh <- the next layer's cross_pre_norm(x)
             if ((rc = gemm<EPI_GEGLU>(dh, Hd, W(lb + SA_LD_GU_W), Hd, dmlp, I, nullptr, nullptr, 0, B, 2 * I, Hd, s))) return rc;
             if ((rc = splitk(dmlp, I, W(lb + SA_LD_DOWN_W), Hd, I, S))) return rc;
@@ -349,7 +370,7 @@ struct LayoutModel : LayoutBase {
                            W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd, c.label_count,
                            c.rms_eps, c.ln_eps);
         if ((rc = (int)hipGetLastError())) return rc;
-        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * 7 * sizeof(int));
+        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * 10 * sizeof(int));
         float* hbx = hc + (size_t)c.max_batch * c.label_count;
         SA_HIP(hipMemcpyAsync(hc, cls_dev, (size_t)B * c.label_count * sizeof(float), hipMemcpyDeviceToHost, s));
         SA_HIP(hipMemcpyAsync(hbx, box_dev, (size_t)B * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -373,6 +394,9 @@ int surya_layout_create(const surya_layout_config* cfg, const void* const* weigh
     if (cfg->img_h % cfg->patch || cfg->img_w % cfg->patch || cfg->dec_hidden % 64 || cfg->dec_inter % 64 || cfg->dec_heads % cfg->dec_kv_heads)
         return SA_ERR_SHAPE;
     if (cfg->max_batch <= 0 || cfg->max_boxes <= 0 || cfg->label_count <= 0) return SA_ERR_ARG;
+    if (cfg->family != SA_FAMILY_LAYOUT && cfg->family != SA_FAMILY_TABLE) return SA_ERR_ARG;
+    if (cfg->family == SA_FAMILY_TABLE &&
+        (cfg->box_embed <= 0 || cfg->box_embed >= cfg->dec_hidden || cfg->category_count <= 0 || cfg->merge_count <= 0)) return SA_ERR_ARG;
     for (int i = 0; i < n_weights; ++i)
         if (!weights[i]) return SA_ERR_ARG;
     auto* h = new surya_layout();
@@ -408,6 +432,11 @@ int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, v
 int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream) {
     if (!h || !boxes || !class_logits || !bbox) return SA_ERR_ARG;
     return h->impl->decode_step(boxes, batch, position, class_logits, bbox, (hipStream_t)stream);
+}
+
+int surya_layout_select(surya_layout* h, const int32_t* src_index, int n) {
+    if (!h || !src_index) return SA_ERR_ARG;
+    return h->impl->select(src_index, n);
 }
 
 int surya_layout_encoder_states(surya_layout* h, void* out, int batch, void* stream) {

@@ -15,7 +15,8 @@ from .config import LayoutConfig
 
 (LW_PATCH_W, LW_PATCH_B, LW_EMB_LN_W, LW_EMB_LN_B, LW_POS_EMB, LW_DEC_FNORM, LW_DEC_LN_W, LW_DEC_LN_B, LW_DEC_LM_W, LW_DEC_BB_W, LW_DEC_BB_B,
  LW_DEC_INVFREQ, LW_DEC_ZERO_BIAS, LW_EMB_TABLES) = range(14)
-LW_GLOBALS = LW_EMB_TABLES + 15
+LW_GLOBALS = LW_EMB_TABLES + 17
+FAMILY_LAYOUT, FAMILY_TABLE = 0, 1
 LS_COUNT, LB_COUNT, LD_COUNT = 4, 13, 12
 EMB_ORDER = ("w", "h", "cx", "cy", "xskew", "yskew", "x1", "y1", "x2", "y2", "x3", "y3", "x4", "y4", "label")
 
@@ -26,7 +27,8 @@ class LayoutConfigC(C.Structure):
                 ("enc_eps", C.c_float), ("encoder_length", C.c_int32), ("dec_layers", C.c_int32), ("dec_hidden", C.c_int32),
                 ("dec_inter", C.c_int32), ("dec_heads", C.c_int32), ("dec_kv_heads", C.c_int32), ("vocab", C.c_int32),
                 ("label_count", C.c_int32), ("bbox_size", C.c_int32), ("rms_eps", C.c_float), ("ln_eps", C.c_float),
-                ("max_batch", C.c_int32), ("max_boxes", C.c_int32), ("dtype", C.c_int32)]
+                ("max_batch", C.c_int32), ("max_boxes", C.c_int32), ("dtype", C.c_int32),
+                ("family", C.c_int32), ("box_embed", C.c_int32), ("category_count", C.c_int32), ("merge_count", C.c_int32)]
 
 
 def _relative_position_index(ws: int) -> torch.Tensor:
@@ -55,9 +57,13 @@ def _interleave(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def repack_layout_weights(cfg: LayoutConfig, sd, dtype: torch.dtype, device) -> List[torch.Tensor]:
-    """Reference state dict (`encoder.*` = DonutSwinLayoutModel, `decoder.*` = SuryaLayoutDecoder) -> the table of
-    include/surya_amd.h (SA_LW_* / SA_LS_* / SA_LB_* / SA_LD_*)."""
+def is_table_config(cfg) -> bool:
+    return hasattr(cfg.decoder, "box_embed_size")
+
+
+def repack_layout_weights(cfg, sd, dtype: torch.dtype, device) -> List[torch.Tensor]:
+    """Reference state dict (`encoder.*` = DonutSwinLayoutModel / table_rec's DonutSwinModel, `decoder.*` = SuryaLayoutDecoder /
+    SuryaTableRecDecoder) -> the table of include/surya_amd.h (SA_LW_* / SA_LS_* / SA_LB_* / SA_LD_*)."""
     e, d = cfg.encoder, cfg.decoder
     out: List[torch.Tensor] = []
 
@@ -73,12 +79,24 @@ def repack_layout_weights(cfg: LayoutConfig, sd, dtype: torch.dtype, device) -> 
     put(f("encoder.embeddings.norm.weight")); put(f("encoder.embeddings.norm.bias"))
     put(f("encoder.position_embeddings")[0])
     put(f("decoder.model.final_norm.weight")); put(f("decoder.pre_output_norm.weight")); put(f("decoder.pre_output_norm.bias"))
-    put(f("decoder.lm_head.weight")); put(f("decoder.bbox_head.weight")); put(f("decoder.bbox_head.bias"))
+    table = is_table_config(cfg)
+    if table:
+        # the four non-bbox property heads stacked in BOX_PROPERTIES order (category | merges | colspan | is_header) take the lm_head
+        # slot, the bbox head (Linear without bias, sigmoid in the kernel) the bbox slot (table_rec/model/decoder.py:88-93, :147-151)
+        put(torch.cat([f(f"decoder.box_property_heads.{k}.weight") for k, _ in d.head_widths() if k != "bbox"], 0))
+        put(f("decoder.box_property_heads.bbox.weight")); put(torch.zeros(6))
+    else:
+        put(f("decoder.lm_head.weight")); put(f("decoder.bbox_head.weight")); put(f("decoder.bbox_head.bias"))
     hd = d.head_dim
     put(1.0 / (d.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd)), torch.float32)
     put(torch.zeros((d.num_attention_heads + 2 * d.num_key_value_heads) * hd))
-    for nm in EMB_ORDER:
+    for nm in EMB_ORDER[:14]:
         put(f(f"decoder.model.embed_tokens.{nm}_embed.weight"))
+    if table:
+        for nm in ("category", "merge", "colspan"):
+            put(f(f"decoder.model.embed_tokens.{nm}_embed.weight"))
+    else:
+        put(f("decoder.model.embed_tokens.label_embed.weight")); put(torch.zeros(4)); put(torch.zeros(4))
     assert len(out) == LW_GLOBALS
     gh, gw = e.grid
     ws = e.window_size
@@ -122,8 +140,9 @@ def repack_layout_weights(cfg: LayoutConfig, sd, dtype: torch.dtype, device) -> 
 
 
 class HipLayoutModel:
-    def __init__(self, cfg: LayoutConfig, state_dict, *, dtype: torch.dtype = torch.bfloat16, device="cuda:0", max_batch: int = 32,
+    def __init__(self, cfg, state_dict, *, dtype: torch.dtype = torch.bfloat16, device="cuda:0", max_batch: int = 32,
                  max_boxes: int = 100):
+        """cfg: layout.config.LayoutConfig or table_rec.config.TableRecConfig (the two callers of the model family)."""
         if not torch.cuda.is_available():
             raise L.SuryaAmdError("HipLayoutModel needs a GPU (MI355X); there is no CPU fallback")
         if dtype not in (torch.float32, torch.bfloat16):
@@ -134,21 +153,27 @@ class HipLayoutModel:
         torch.cuda.set_device(self.device)
         self.weights = repack_layout_weights(cfg, state_dict, dtype, self.device)
         e, d = cfg.encoder, cfg.decoder
+        self.is_table = is_table_config(cfg)
+        self.tok_width = 10 if self.is_table else 7
+        # rows of the class-logit output: layout = label_count; table = the non-bbox property heads side by side
+        self.label_count = sum(n for k, n in d.head_widths() if k != "bbox") if self.is_table else d.label_count
         c = LayoutConfigC(img_h=e.image_size[0], img_w=e.image_size[1], patch=e.patch_size, embed_dim=e.embed_dim, n_stages=len(e.depths),
                           window=e.window_size, enc_eps=e.layer_norm_eps, encoder_length=e.encoder_length, dec_layers=d.num_hidden_layers,
                           dec_hidden=d.hidden_size, dec_inter=d.intermediate_size, dec_heads=d.num_attention_heads,
-                          dec_kv_heads=d.num_key_value_heads, vocab=d.vocab_size, label_count=d.label_count, bbox_size=d.bbox_size,
+                          dec_kv_heads=d.num_key_value_heads, vocab=d.vocab_size, label_count=self.label_count, bbox_size=d.bbox_size,
                           rms_eps=d.rms_norm_eps, ln_eps=d.layer_norm_eps, max_batch=max_batch, max_boxes=max_boxes,
-                          dtype=L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16)
+                          dtype=L.DTYPE_F32 if dtype == torch.float32 else L.DTYPE_BF16,
+                          family=FAMILY_TABLE if self.is_table else FAMILY_LAYOUT, box_embed=d.box_embed_size if self.is_table else d.hidden_size,
+                          category_count=d.category_count if self.is_table else 0, merge_count=d.merge_count if self.is_table else 0)
         for i, (dep, nh, nkv) in enumerate(zip(e.depths, e.num_heads, e.num_kv_heads)):
             c.depths[i], c.heads[i], c.kv_heads[i] = dep, nh, nkv
         self.c = c
         table = (C.c_void_p * len(self.weights))(*[t.data_ptr() for t in self.weights])
         self.handle = C.c_void_p()
         L.check(self.lib.surya_layout_create(C.byref(c), table, len(self.weights), C.byref(self.handle)), "surya_layout_create")
-        self._cls = np.zeros((max_batch, d.label_count), np.float32)
+        self._cls = np.zeros((max_batch, self.label_count), np.float32)
         self._box = np.zeros((max_batch, 6), np.float32)
-        self.batch = 0
+        self.batch = self.encoded = 0
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -176,11 +201,23 @@ class HipLayoutModel:
         B = pixel_values.shape[0]
         assert tuple(pixel_values.shape[1:]) == (3,) + tuple(self.cfg.encoder.image_size) and B <= self.max_batch
         L.check(self.lib.surya_layout_encode(self.handle, L.ptr(pixel_values), C.c_int(B), self._stream), "surya_layout_encode")
-        self.batch = B
+        self.batch = self.encoded = B
+
+    def encode_host(self, pixel_values: torch.Tensor):
+        """encode() for a CPU fp32 tensor: pinned staging + asynchronous upload on the current stream."""
+        self.encode(pixel_values.float().pin_memory().to(self.device, non_blocking=True).contiguous())
+
+    def select(self, src_index):
+        """Re-batch the decoder: row i of the following decode steps cross-attends the encoder states of image src_index[i] of the
+        last encode() (table recognition decodes every ROW of a table against its image, table_rec/__init__.py:196-230)."""
+        idx = np.ascontiguousarray(src_index, np.int32)
+        assert idx.ndim == 1 and 0 < idx.size <= self.max_batch
+        L.check(self.lib.surya_layout_select(self.handle, L.np_ptr(idx), C.c_int(idx.size)), "surya_layout_select")
+        self.batch = int(idx.size)
 
     def decode_step(self, boxes: np.ndarray, position: int):
-        """boxes: int32 [B, 7]; returns (class_logits [B, label_count], bbox [B, 6]) numpy copies."""
-        b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, 7)
+        """boxes: int32 [B, 7] (table family: [B, 10]); returns (class_logits [B, label_count], bbox [B, 6]) numpy copies."""
+        b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, self.tok_width)
         L.check(self.lib.surya_layout_decode_step(self.handle, L.np_ptr(b), C.c_int(self.batch), C.c_int(position),
                                                   L.np_ptr(self._cls, C.c_float), L.np_ptr(self._box, C.c_float), self._stream),
                 "surya_layout_decode_step")
@@ -189,6 +226,6 @@ class HipLayoutModel:
     def encoder_states(self) -> torch.Tensor:
         e = self.cfg.encoder
         n = (e.grid[0] >> (len(e.depths) - 1)) * (e.grid[1] >> (len(e.depths) - 1))
-        out = torch.empty((self.batch, n, e.hidden_size), dtype=self.dtype, device=self.device)
-        L.check(self.lib.surya_layout_encoder_states(self.handle, L.ptr(out), C.c_int(self.batch), self._stream), "surya_layout_encoder_states")
+        out = torch.empty((self.encoded, n, e.hidden_size), dtype=self.dtype, device=self.device)
+        L.check(self.lib.surya_layout_encoder_states(self.handle, L.ptr(out), C.c_int(self.encoded), self._stream), "surya_layout_encoder_states")
         return out

@@ -381,9 +381,17 @@ def make_layout_weights(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
             sd[p + "norm.bias"] = _normal(g, (4 * dim,), 0.05)
     sd["encoder.position_embeddings"] = _normal(g, (1, e.encoder_length, e.hidden_size), 0.3)
     H, I, qd, kvd = d.hidden_size, d.intermediate_size, d.num_attention_heads * d.head_dim, d.num_key_value_heads * d.head_dim
+    table = hasattr(d, "box_embed_size")                      # table_rec.config.TableDecoderConfig: concat(box, property) embedding
+    BE = d.box_embed_size if table else H
     for nm in ("w", "h", "cx", "cy", "xskew", "yskew", "x1", "y1", "x2", "y2", "x3", "y3", "x4", "y4"):
-        sd[f"decoder.model.embed_tokens.{nm}_embed.weight"] = _normal(g, (d.vocab_size, H), 0.3)
-    sd["decoder.model.embed_tokens.label_embed.weight"] = _normal(g, (d.label_count, H), 0.5)
+        sd[f"decoder.model.embed_tokens.{nm}_embed.weight"] = _normal(g, (d.vocab_size, BE), 0.3)
+    if table:
+        P = d.property_embed_size
+        sd["decoder.model.embed_tokens.category_embed.weight"] = _normal(g, (d.category_count, P), 0.5)
+        sd["decoder.model.embed_tokens.merge_embed.weight"] = _normal(g, (d.merge_count, P), 0.5)
+        sd["decoder.model.embed_tokens.colspan_embed.weight"] = _normal(g, (d.vocab_size, P), 0.5)
+    else:
+        sd["decoder.model.embed_tokens.label_embed.weight"] = _normal(g, (d.label_count, H), 0.5)
     for li in range(d.num_hidden_layers):
         p = f"decoder.model.layers.{li}."
         for nm in ("cross_pre_norm", "temporal_pre_norm", "channel_pre_norm"):
@@ -400,9 +408,23 @@ def make_layout_weights(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     sd["decoder.model.final_norm.weight"] = _normal(g, (H,), 0.1)
     sd["decoder.pre_output_norm.weight"] = 1.0 + _normal(g, (H,), 0.05)
     sd["decoder.pre_output_norm.bias"] = _normal(g, (H,), 0.05)
+    if table:
+        # surya/table_rec/model/decoder.py:88-93: one bias-free Linear per box property
+        for k, rows in d.head_widths():
+            gain = {"bbox": 1.0, "colspan": 2.0}.get(k, 1.5)
+            sd[f"decoder.box_property_heads.{k}.weight"] = _normal(g, (rows, H), gain / math.sqrt(H))
+        # nothing ends a table early by itself: keep </S> / <PAD> unlikely as a category so a fixed number of boxes is decoded in tests
+        sd["decoder.box_property_heads.category.weight"][: d.special_token_count] *= 0.05
+        return sd
     sd["decoder.lm_head.weight"] = _normal(g, (d.label_count, H), 1.5 / math.sqrt(H))
     # nothing ends a page early by itself: keep </S> / <PAD> / pause unlikely so a fixed number of boxes is decoded in tests
     sd["decoder.lm_head.weight"][: d.special_token_count] *= 0.05
     sd["decoder.bbox_head.weight"] = _normal(g, (6, H), 1.0 / math.sqrt(H))
     sd["decoder.bbox_head.bias"] = _normal(g, (6,), 0.1)
     return sd
+
+
+def make_table_weights(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Table-recognition twin of make_layout_weights: `encoder.*` = table_rec's DonutSwinModel (the same Swin stack,
+    surya/table_rec/model/encoder.py), `decoder.*` = SuryaTableRecDecoder (surya/table_rec/model/decoder.py)."""
+    return make_layout_weights(cfg, seed)

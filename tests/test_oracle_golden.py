@@ -240,3 +240,43 @@ def test_layout_oracle_matches_reference(name, fixture):
             assert (box[:, -1] - ref_b).abs().max().item() <= 1e-5, step
             assert torch.equal(cls[:, -1].argmax(-1), ref_c.argmax(-1))
             boxes = g["fed_tokens"][step].unsqueeze(1)
+
+
+# ------------------------------------------------------------------------------------------ table recognition (second caller of the family)
+@pytest.mark.parametrize("name,fixture", [("TABLE-TINY", "table_tiny.pt"), ("TABLE-SMALL", "table_small.pt"), ("TABLE-DEFAULT", "table_default.pt")])
+def test_table_oracle_matches_reference(name, fixture):
+    """oracle/layout_oracle.py with a table_rec config (LabelEmbedding, plain residual flow, one head per box property) against
+    fixtures recorded from the reference's own table_rec DonutSwinModel / SuryaTableRecDecoder driven the way its inference loop drives
+    them (oracle/make_golden_table.py): encoder output; the multi-token prompt prefill both in ONE call and token by token (what the
+    HIP path does -- a causal prefill is the same arithmetic); then teacher-forced single steps. Classification argmaxes are bit-exact."""
+    from oracle import layout_oracle as lo
+    from oracle.make_golden_table import table_pixels
+    from surya_amd.table_rec.config import table_config, BOX_PROPERTIES
+    from surya_amd.synth import make_table_weights
+    g = torch.load(os.path.join(GOLD, fixture))
+    cfg = table_config(name)
+    d = cfg.decoder
+    sd = make_table_weights(cfg, 0)
+    x = table_pixels(cfg, g["batch"], g["seed"])
+    with torch.inference_mode():
+        enc = lo.encoder_forward(sd, cfg.encoder, x)
+        assert (enc[:, ::g["enc_stride"]] - g["encoder_out"]).abs().max().item() <= 1e-4 * g["encoder_absmax"]
+        T = g["prompt"].shape[1]
+        for token_by_token in (False, True):
+            st = lo.LayoutDecoderState(d.num_hidden_layers)
+            if token_by_token:
+                for t in range(T):
+                    box, props = lo.decoder_forward(sd, d, g["prompt"][:, t:t + 1], enc, t, st)
+            else:
+                box, props = lo.decoder_forward(sd, d, g["prompt"], enc, 0, st)
+            pos = T
+            for step in range(g["steps"]):
+                if step > 0:
+                    box, props = lo.decoder_forward(sd, d, g["fed_tokens"][step - 1].unsqueeze(1), enc, pos, st)
+                    pos += 1
+                for k, _, mode in BOX_PROPERTIES:
+                    got = box[:, -1] if k == "bbox" else props[k][:, -1]
+                    ref = g["logits"][k][step]
+                    assert (got - ref).abs().max().item() <= (1e-5 if k == "bbox" else 1e-4 * max(1.0, ref.abs().max().item())), (k, step)
+                    if mode == "classification":
+                        assert torch.equal(got.argmax(-1), ref.argmax(-1)), (k, step)

@@ -990,3 +990,158 @@ def test_live_layout_host_logic_against_reference():
     finally:
         for k in added:
             delattr(cv2_stub, k)
+
+
+def _load_reference_table_predictor():
+    import importlib.util
+    import os
+    mods = ref_shim.import_table_modules()
+    spec = importlib.util.spec_from_file_location("ref_table_rec_pkg", os.path.join(ref_shim.REFERENCE_ROOT, "surya", "table_rec", "__init__.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return mods, m
+
+
+def test_live_table_host_logic_against_reference():
+    """Table recognition, host side, against the reference's own code imported from /root/reference:
+      * LabelShaper (surya/table_rec/shaper.py) on random polygons / property dicts;
+      * SuryaTableRecProcessor's prompts (table_rec/processor.py) for query items with and without columns;
+      * TableRecPredictor.decode_batch_predictions (table_rec/__init__.py:236-387) on synthetic row / column / spanning-cell
+        predictions (merges, colspans, headers);
+      * the WHOLE predictor, both passes, with the reference's predictor driving the reference's DonutSwinModel + SuryaTableRecDecoder
+        (TABLE-TINY synthetic weights, dynamic cache) and ours driving the CPU oracle behind HipLayoutModel's interface
+        (tests/table_util.py): identical TableResults."""
+    import copy
+    import sys
+    from types import SimpleNamespace
+    import numpy as np
+    from PIL import Image
+    (cfgm, encm, decm, rshaper_mod), rpkg = _load_reference_table_predictor()
+    rproc_mod = ref_shim.import_submodule("surya.table_rec.processor")
+    from oracle.make_golden_table import build_reference_table
+    from surya_amd.synth import make_table_weights
+    from surya_amd.table_rec import predictor as tp
+    from surya_amd.table_rec.config import table_config
+    from surya_amd.table_rec.processor import TableRecProcessor
+    from surya_amd.table_rec.shaper import LabelShaper
+    from table_util import OracleTableModel
+    rng = np.random.default_rng(12)
+    ours, ref = LabelShaper(), rshaper_mod.LabelShaper()
+    assert ours.component_idx_dict() == ref.component_idx_dict() and ours.property_keys == ref.property_keys
+    for key in ours.property_keys:
+        assert ours.get_box_property(key) == ref.get_box_property(key)
+        assert ours.get_box_property(key, add_special_tokens=False) == ref.get_box_property(key, add_special_tokens=False)
+
+    def items(n, with_bbox=False):
+        out = []
+        for _ in range(n):
+            x0, y0 = rng.uniform(-50, 900), rng.uniform(-50, 900)
+            w, h = rng.uniform(5, 500), rng.uniform(5, 300)
+            sk = rng.uniform(-8, 8, size=2)
+            poly = [[x0 - sk[0], y0 - sk[1]], [x0 + w - sk[0], y0 + sk[1]], [x0 + w + sk[0], y0 + h + sk[1]], [x0 + sk[0], y0 + h - sk[1]]]
+            it = {"polygon": poly, "category": int(rng.integers(0, 5)), "colspan": int(rng.integers(0, 4)), "merges": int(rng.integers(0, 4)),
+                  "is_header": int(rng.integers(0, 2))}
+            out.append(it)
+        return out
+
+    a = items(40)
+    b = copy.deepcopy(a)
+    ca, cb = ours.convert_polygons_to_bboxes(a), ref.convert_polygons_to_bboxes(b)
+    assert [x["bbox"] for x in ca] == [list(x["bbox"]) for x in cb]
+    la, lb = ours.dict_to_labels(ca), ref.dict_to_labels(cb)
+    assert la == lb and [x["bbox"] for x in ca] == [x["bbox"] for x in cb]
+    for _ in range(200):
+        box = rng.uniform(0, 1024, size=6).tolist()
+        assert ours.convert_bbox_to_polygon(list(box)) == ref.convert_bbox_to_polygon(list(box))
+
+    # processor prompts
+    rp = object.__new__(rproc_mod.SuryaTableRecProcessor)
+    rp.box_size, rp.special_token_count, rp.shaper = (1024, 1024), 5, ref
+    rp.token_pad_id, rp.token_eos_id, rp.token_bos_id, rp.token_query_end_id = 0, 1, 1, 4
+    op = TableRecProcessor({"height": 128, "width": 128})
+    rp.image_processor = lambda images, *a_, **k_: {"pixel_values": op.image_processor(images)["pixel_values"]}
+    imgs = [Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in ((300, 500), (128, 128), (700, 260))]
+    q = [{"polygon": [[0, 0], [im.width, 0], [im.width, im.height], [0, im.height]], "category": 4, "colspan": 0, "merges": 0, "is_header": 0} for im in imgs]
+    ra, rb = op(images=imgs, query_items=copy.deepcopy(q)), rp(images=imgs, query_items=copy.deepcopy(q))
+    assert np.array_equal(ra["input_ids"], rb["input_ids"].numpy())
+    assert all(np.array_equal(x, y) for x, y in zip(ra["pixel_values"], rb["pixel_values"]))
+    rows_q, cols_q = items(5), items(3)
+    ra = op(images=None, query_items=copy.deepcopy(rows_q), columns=copy.deepcopy(cols_q), convert_images=False)
+    rb = rp(images=None, query_items=copy.deepcopy(rows_q), columns=copy.deepcopy(cols_q), convert_images=False)
+    assert np.array_equal(ra["input_ids"], rb["input_ids"].numpy()) and ra["input_ids"].shape == (5, 6, 10)
+
+    # assembly of a synthetic table: 4 rows x 3 columns, a colspan-2 cell, a vertical merge, a too-short spanning cell, a header row
+    def synthetic():
+        def bb(x0, y0, x1, y1):
+            return [(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0, 512.0, 512.0]
+        xs, ys = [40, 300, 620, 980], [30, 200, 420, 640, 900]
+        rowcol = []
+        for r in range(4):
+            rowcol.append({"bbox": bb(xs[0], ys[r], xs[3], ys[r + 1]), "category": 1, "merges": 0, "colspan": 1, "is_header": int(r == 0)})
+        for c in range(3):
+            rowcol.append({"bbox": bb(xs[c], ys[0], xs[c + 1], ys[4]), "category": 2, "merges": 0, "colspan": 1, "is_header": int(c == 0)})
+        rowcol.append({"bbox": bb(0, 0, 1024, 1024), "category": 4, "merges": 0, "colspan": 1, "is_header": 0})
+        cells = [
+            [{"bbox": bb(xs[0], ys[0], xs[2], ys[1]), "category": 3, "merges": 0, "colspan": 2, "is_header": 1}],
+            [{"bbox": bb(xs[2], ys[1], xs[3], ys[2]), "category": 3, "merges": 2, "colspan": 1, "is_header": 0},
+             {"bbox": bb(xs[0], ys[1], xs[1], ys[1] + 40), "category": 3, "merges": 1, "colspan": 1, "is_header": 0}],
+            [{"bbox": bb(xs[2], ys[2], xs[3], ys[3]), "category": 3, "merges": 1, "colspan": 1, "is_header": 0},
+             {"bbox": bb(xs[0], ys[2], xs[1], ys[3]), "category": 3, "merges": 0, "colspan": 1, "is_header": 0}],
+            [{"bbox": bb(xs[1], ys[3], xs[3], ys[4]), "category": 3, "merges": 0, "colspan": 3, "is_header": 0}],
+        ]
+        return [rowcol], cells, [(1600, 1100)], [0, 0, 0, 0]
+
+    o_self = SimpleNamespace(processor=op)
+    r_self = SimpleNamespace(processor=rp)
+    res_a = tp.TableRecPredictor.decode_batch_predictions(o_self, *synthetic(), ours)
+    res_b = rpkg.TableRecPredictor.decode_batch_predictions(r_self, *synthetic(), ref)
+    assert [r.model_dump() for r in res_a] == [r.model_dump() for r in res_b]
+    assert len(res_a[0].rows) == 4 and len(res_a[0].cols) == 3 and any(c.colspan == 2 for c in res_a[0].cells)
+    assert any(c.rowspan == 2 for c in res_a[0].cells)                       # the vertical merge happened
+
+    # the whole predictor, both passes
+    cfg = table_config("TABLE-TINY")
+    sd = make_table_weights(cfg, 0)
+    # random heads rarely say "Table-row" / "Table-column": tilt the category head so both passes have work
+    sd["decoder.box_property_heads.category.weight"][5 + 1] *= 3.0
+    sd["decoder.box_property_heads.category.weight"][5 + 2] *= 2.5
+    enc, dec, dec_cfg = build_reference_table(cfg, sd)
+    max_tokens = 14
+    settings_mod = sys.modules["surya.settings"]
+    old_max, old_tp = settings_mod.settings.TABLE_REC_MAX_BOXES, tp.TABLE_REC_MAX_BOXES
+    settings_mod.settings.TABLE_REC_MAX_BOXES = max_tokens
+    tp.TABLE_REC_MAX_BOXES = max_tokens
+    try:
+        # The fed-back box numbers are floats TRUNCATED to tokens: where the reference computes 607.0 and the oracle 606.99994 (one fp32
+        # ulp apart) the two runs part ways, which says nothing about the host logic. Seed 3's pages have no such coin flip (seed 12's
+        # have one).
+        prng = np.random.default_rng(3)
+        pages = [Image.fromarray(prng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in ((200, 320), (128, 128), (90, 400))]
+        rpred = object.__new__(rpkg.TableRecPredictor)
+        rp2 = copy.copy(rp)
+        rpred.processor = rp2
+        rpred.model = SimpleNamespace(encoder=enc, decoder=dec, device=torch.device("cpu"), dtype=torch.float32, config=dec_cfg)
+        rpred.disable_tqdm = True
+        rpred.get_batch_size = lambda: 2
+        want = rpred.batch_table_recognition(pages, batch_size=2)
+        opred = object.__new__(tp.TableRecPredictor)
+        opred.model = OracleTableModel(cfg, sd, max_batch=8)
+        opred.processor = op
+        got = opred.batch_table_recognition(pages, batch_size=2)
+    finally:
+        settings_mod.settings.TABLE_REC_MAX_BOXES = old_max
+        tp.TABLE_REC_MAX_BOXES = old_tp
+    assert len(got) == len(want) == 3
+    n_rows = sum(len(r.rows) for r in want)
+    assert n_rows > 0 and sum(len(r.cols) for r in want) > 0, "the synthetic weights produced no rows / columns: the second pass was not exercised"
+    for a_, b_ in zip(got, want):
+        da, db = a_.model_dump(), b_.model_dump()
+        assert da.keys() == db.keys()
+        for key in ("rows", "cols", "cells", "unmerged_cells"):
+            assert len(da[key]) == len(db[key]), key
+            for x, y in zip(da[key], db[key]):
+                px, py = np.array(x.pop("polygon"), np.float64), np.array(y.pop("polygon"), np.float64)
+                assert np.allclose(px, py, atol=1e-3), (key, px, py)
+                x.pop("bbox", None); y.pop("bbox", None)
+                assert x == y, (key, x, y)
+        assert da["image_bbox"] == db["image_bbox"]
