@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--texify-tokens", type=int, default=256, help="decode horizon of the texify leg (the task's own default is 768)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
     ap.add_argument("--no-layout", action="store_true", help="skip the layout-model leg (SURVEY 8(f) rank 4)")
-    ap.add_argument("--layout-only", action="store_true", help="profiling aid: run only the layout leg and print its object")
+    ap.add_argument("--layout-only", action="store_true", help="profiling aid: run only the layout + table_rec legs and print their objects")
     ap.add_argument("--texify-only", action="store_true", help="profiling aid: run only the texify leg and print its object")
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
@@ -672,6 +672,77 @@ def bench_layout(args, local_rank):
     return out
 
 
+def bench_table(args, local_rank):
+    """Table recognition, the second caller of the layout model family (not a BASELINE.json config): TABLE-DEFAULT
+    (Donut-Swin 128-d x [2, 2, 12, 2], ADETR decoder 6 x 512) with synthetic weights, 32 table crops at the processor size 768^2, bf16.
+    Timed: the encoder + the FIRST decoding pass (3-token prompt, then fed-back tokens up to TABLE_REC_MAX_BOXES = 150 positions; random
+    weights never emit </S>). The second pass (one prompt per detected row) repeats the same decode loop on a data-dependent number of
+    rows, so it is reported per decoder row-step, not as a rate. Parity: teacher-forced bf16 property logits vs the fixture recorded from
+    the REAL reference modules (tests/golden/table_default.pt)."""
+    from surya_amd.layout.model import HipLayoutModel
+    from surya_amd.synth import make_table_weights
+    from surya_amd.table_rec.config import table_config, BOX_PROPERTIES
+    cfg = table_config("TABLE-DEFAULT")
+    d = cfg.decoder
+    sd = make_table_weights(cfg, 0)
+    B, positions = 32, 150
+    dev = f"cuda:{local_rank}"
+    m = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=dev, max_batch=B, max_boxes=positions + 8)
+    px = torch.randn(B, 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(6)).to(dev).contiguous()
+    prompt = np.stack([np.full((B, 10), d.bos_token_id), np.tile(np.array([512, 512, 1024, 1024, 512, 512, 9, 5, 0, 5]), (B, 1)),
+                       np.full((B, 10), d.query_end_token_id)], 1).astype(np.int32)
+    widths = [n for k, n in d.head_widths() if k != "bbox"]
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.encode(px)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tok = None
+        for pos in range(positions):
+            cls, box = m.decode_step(prompt[:, pos] if pos < 3 else tok, pos)
+            if pos >= 2:
+                o, parts = 0, []
+                for n in widths:
+                    parts.append(cls[:, o:o + n]); o += n
+                cat, mer, col, hdr = parts
+                tok = np.concatenate([box * d.bbox_size, cat.argmax(-1)[:, None], mer.argmax(-1)[:, None],
+                                      np.round(np.maximum(col, 1.0)), hdr.argmax(-1)[:, None]], -1).astype(np.int64).astype(np.int32)
+        return t1 - t0, time.perf_counter() - t1
+
+    run()
+    t_enc, t_dec = min(run() for _ in range(3))
+    out = {"metric": "table crops/s, encoder + first decoding pass (150 decoder positions per table)", "tables_per_s": round(B / (t_enc + t_dec), 1),
+           "tables": B, "encode_ms": round(t_enc * 1e3, 2), "decode_step_us": round(t_dec / positions * 1e6, 1), "positions": positions,
+           "dtype": "bf16", "config": {"workload": f"{B} synthetic table crops at the processor size 768x768, TABLE-DEFAULT synthetic weights, "
+                                                   "pixel_values in HBM"}}
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "table_default.pt"))
+    m2 = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=dev, max_batch=g["batch"], max_boxes=32)
+    m2.encode(torch.randn(g["batch"], 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(g["seed"])).to(dev).contiguous())
+    T = g["prompt"].shape[1]
+    worst, agree, total = 0.0, 0, 0
+    for step in range(g["steps"]):
+        if step == 0:
+            for t in range(T):
+                cls, box = m2.decode_step(g["prompt"][:, t].numpy().astype(np.int32), t)
+        else:
+            cls, box = m2.decode_step(g["fed_tokens"][step - 1].numpy().astype(np.int32), T + step - 1)
+        scale = max(1.0, max(float(g["logits"][k][step].abs().max()) for k, _, _ in BOX_PROPERTIES if k != "bbox"))
+        o = 0
+        for k, n in d.head_widths():
+            if k == "bbox":
+                continue
+            ref = g["logits"][k][step].numpy()
+            got = cls[:, o:o + n]; o += n
+            worst = max(worst, float(np.abs(got - ref).max()) / scale)
+            if n > 1:
+                agree += int((got.argmax(-1) == ref.argmax(-1)).sum()); total += ref.shape[0]
+    out["parity"] = {"bf16_worst_property_logit_err_rel": round(worst, 4), "bf16_argmax_equal": f"{agree}/{total}",
+                     "note": "teacher-forced on the reference's prompt and fed-back tokens; fp32 mode is bit-exact on the classes (tests/test_gpu_table.py)"}
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -695,7 +766,7 @@ def main():
         print(json.dumps(bench_det(args, local_rank, world, rank, lambda: None)), flush=True)
         return
     if args.layout_only:
-        print(json.dumps(bench_layout(args, local_rank)), flush=True)
+        print(json.dumps({"layout": bench_layout(args, local_rank), "table_rec": bench_table(args, local_rank)}), flush=True)
         return
     os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
     if args.steps_per_sync:
@@ -813,7 +884,7 @@ def main():
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": peak,
                 "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic_for(dom["kernel"]),
                 "traffic_source": "profiles/hbm_traffic.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  "(profiles/r02_t_rec_hbm_traffic_pmc.md), bytes per launch of this bucket; not re-measured in this run",
+                                  "(profiles/r03_k_rec_hbm_traffic_pmc.md), bytes per launch of this bucket; not re-measured in this run",
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 # an event pair around an EMPTY kernel costs this much: rocprofv3's begin->end duration of the same launches
                 # lies between avg_launch_ms - event_pair_null_ms and avg_launch_ms
@@ -836,7 +907,7 @@ def main():
                    "parallelism": (f"dp{world}: {args.lines * world} width-sorted lines dealt round-robin, one all_gather of the outputs per step, "
                                    f"weights broadcast from rank 0 ({args.dist_backend})" if world > 1 else "1 GPU"),
                    "rank_ms_per_step": rank_ms},
-        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None, "layout": None,
+        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None, "layout": None, "table_rec": None,
     }
     emit_lock = threading.Lock()
     emitted = [False]
@@ -883,6 +954,7 @@ def main():
         out["e2e"] = leg("e2e", lambda: bench_e2e(args, pred, local_rank, world, rank, barrier))
     if rank == 0 and world == 1 and not args.no_layout:
         out["layout"] = leg("layout", lambda: bench_layout(args, local_rank))
+        out["table_rec"] = leg("table_rec", lambda: bench_table(args, local_rank))
     if rank == 0 and world == 1 and not args.no_texify:
         del pred
         torch.cuda.empty_cache()
