@@ -413,68 +413,10 @@ __global__ __launch_bounds__(256) void adetr_rmsnorm_kernel(const T* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Cross attention of ONE query token per image over the cached encoder keys / values (SuryaADETRDecoderSdpaCrossAttention,
-// adetr/decoder.py:151-190; no mask, no rotary embedding). One workgroup per (image, kv head): its G query heads share the K / V
-// rows. kv rows: [B][Lk][2 * nkv * D] = (k heads | v heads) as the fused k|v projection writes them.
-template <typename T, int D>
-__global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out, int nq,
-                                                                int nkv, int Lk, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* sc = reinterpret_cast<float*>(smem_raw);                 // [G][Lk] scores -> probabilities
-    float* qsh = sc + (nq / nkv) * Lk;                              // [G][D]
-    __shared__ float red[2][8][4];                                   // per-wave partials: [max | sum][head g][wave]
-    const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, G = nq / nkv;
-    const int row_w = 2 * nkv * D;
-    const T* kb = kv + (long)b * Lk * row_w + kvh * D;
-    const T* vb = kb + nkv * D;
-    for (int i = tid; i < G * D; i += 256) qsh[i] = Ty<T>::ld(q + (long)b * nq * D + (long)(kvh * G) * D + i);
-    __syncthreads();
-    // scores: thread -> key j (strided), all G heads from one K row read
-    for (int j = tid; j < Lk; j += 256) {
-        float kr[D];
-#pragma unroll
-        for (int c = 0; c < D; c += 4) load4(kb + (long)j * row_w + c, *reinterpret_cast<float(*)[4]>(&kr[c]));
-        for (int g = 0; g < G; ++g) {
-            float d = 0.f;
-#pragma unroll
-            for (int c = 0; c < D; ++c) d += qsh[g * D + c] * kr[c];
-            sc[g * Lk + j] = d * scale;
-        }
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int g = 0; g < G; ++g) {                                   // softmax per head: block max, block sum
-        float m = -INFINITY;
-        for (int j = tid; j < Lk; j += 256) m = fmaxf(m, sc[g * Lk + j]);
-        m = wave_max(m);
-        if (lane == 0) red[0][g][wave] = m;
-    }
-    __syncthreads();
-    for (int g = 0; g < G; ++g) {
-        const float m = fmaxf(fmaxf(red[0][g][0], red[0][g][1]), fmaxf(red[0][g][2], red[0][g][3]));
-        float l = 0.f;
-        for (int j = tid; j < Lk; j += 256) { const float e = expf(sc[g * Lk + j] - m); sc[g * Lk + j] = e; l += e; }
-        l = wave_sum(l);
-        if (lane == 0) red[1][g][wave] = l;
-    }
-    __syncthreads();
-    // P V: thread -> (head g, 4 output dims), V rows are read coalesced by the threads of a head
-    for (int it = tid; it < G * (D / 4); it += 256) {
-        const int g = it / (D / 4), c = (it % (D / 4)) * 4;
-        const float inv = 1.0f / (red[1][g][0] + red[1][g][1] + red[1][g][2] + red[1][g][3]);
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < Lk; ++j) {
-            float vv[4];
-            load4(vb + (long)j * row_w + c, vv);
-            const float p = sc[g * Lk + j];
-            o[0] += p * vv[0]; o[1] += p * vv[1]; o[2] += p * vv[2]; o[3] += p * vv[3];
-        }
-        store4(out + (long)b * nq * D + (long)(kvh * G + g) * D + c, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-    }
-}
-
-// The same cross attention spread over the chip: one workgroup per (image, kv head, key range), NS ranges per (image, kv head).
-// cross_attn_decode_kernel above runs B * nkv = 128 workgroups whose P V phase keeps 64 threads busy for Lk serial steps (88 us
-// per layer at Lk = 576); here
+// adetr/decoder.py:151-190; no mask, no rotary embedding). kv rows: [B][Lk][2 * nkv * D] = (k heads | v heads) as the fused k|v
+// projection writes them. The first version ran one workgroup per (image, kv head) -- B * nkv = 128 workgroups whose P V phase kept
+// 64 threads busy for Lk serial steps: 88 us per layer at Lk = 576 (profiles/r03_f_layout_kernel_stats_before.md). Now
+// one workgroup per (image, kv head, key range), NS ranges per (image, kv head):
 //   * the query row is the sum of the q projection's split-K slabs (qpart [S][M][nq * D] fp32, rounded to T like the unsplit
 //     GEMM's output), so that projection needs no reduce launch;
 //   * scores: 4 lanes per key (coalesced 2 D-byte row reads), quad-reduced; softmax statistics per range;

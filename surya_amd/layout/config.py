@@ -87,3 +87,37 @@ def layout_config(name: str) -> LayoutConfig:
                                   num_attention_heads=2, num_key_value_heads=1)
         return LayoutConfig(name="LAYOUT-TINY", encoder=enc, decoder=dec)
     raise KeyError(name)
+
+
+def _pick(cls, raw: dict, **extra):
+    """Keep the keys of a reference sub-config dict that are fields of our dataclass (lists -> tuples)."""
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items() if k in cls.__dataclass_fields__}
+    kw.update(extra)
+    return cls(**kw)
+
+
+def layout_config_from_reference_json(raw: dict) -> LayoutConfig:
+    """config.json of a layout checkpoint (SuryaLayoutConfig.to_dict: `encoder` = DonutSwinLayoutConfig, `decoder` =
+    SuryaLayoutDecoderConfig sub-dicts; surya/layout/loader.py:31-40 reads it the same way)."""
+    return LayoutConfig(name="checkpoint", encoder=_pick(SwinConfig, raw["encoder"]), decoder=_pick(LayoutDecoderConfig, raw["decoder"]))
+
+
+def read_checkpoint_dir(path: str):
+    """(config.json as a dict, merged tensors of every *.safetensors file, preprocessor_config.json as a dict or None) of a directory
+    in the reference's on-disk format (surya/common/s3.py:50-65)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        raw = json.load(f)
+    sd = {}
+    for fn in sorted(os.listdir(path)):
+        if fn.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(path, fn)))
+    if not sd:
+        raise FileNotFoundError(f"{path}: no *.safetensors file")
+    pp = None
+    if os.path.exists(os.path.join(path, "preprocessor_config.json")):
+        with open(os.path.join(path, "preprocessor_config.json")) as f:
+            pp = json.load(f)
+    return raw, sd, pp

@@ -5,6 +5,7 @@ schema. The model calls are `HipLayoutModel.encode` (once per batch) and `.decod
 synchronises with the host after every step as well). There is no CPU fallback for the model."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -48,8 +49,12 @@ class LayoutImageProcessor:
     image_mean = np.array((0.5, 0.5, 0.5), np.float32)
     image_std = np.array((0.5, 0.5, 0.5), np.float32)
 
-    def __init__(self, max_size):
+    def __init__(self, max_size, image_mean=None, image_std=None):
         self.max_size = max_size
+        if image_mean is not None:
+            self.image_mean = np.asarray(image_mean, np.float32)
+        if image_std is not None:
+            self.image_std = np.asarray(image_std, np.float32)
 
     def __call__(self, images: List[Image.Image]):
         out = []
@@ -65,13 +70,19 @@ class LayoutImageProcessor:
 
 
 class LayoutModelLoader(ModelLoader):
-    """checkpoint: None / config name (synthetic weights) or {"config": LayoutConfig, "state_dict": {...}}."""
+    """checkpoint: None / config name (synthetic weights), {"config": LayoutConfig, "state_dict": {...}}, or a directory in the
+    reference's on-disk format (surya/layout/loader.py:25-64): config.json with `encoder` / `decoder` sub-configs and *.safetensors
+    with the reference's parameter names (`encoder.*`, `decoder.*`). The image processor needs no file (loader.py:66-70)."""
 
     def __init__(self, checkpoint=None):
         super().__init__(checkpoint)
         ck = checkpoint
         if isinstance(ck, dict):
             self._cfg, self._sd = ck["config"], ck["state_dict"]
+        elif isinstance(ck, str) and os.path.isdir(ck):
+            from .config import layout_config_from_reference_json, read_checkpoint_dir
+            raw, self._sd, _ = read_checkpoint_dir(ck)
+            self._cfg = layout_config_from_reference_json(raw)
         else:
             from ..synth import make_layout_weights
             self._cfg = layout_config(ck if isinstance(ck, str) else "LAYOUT-DEFAULT")

@@ -88,3 +88,10 @@ def table_config(name: str) -> TableRecConfig:
                                  encoder_hidden_size=128, num_attention_heads=2, num_key_value_heads=1)
         return TableRecConfig(name="TABLE-TINY", encoder=enc, decoder=dec)
     raise KeyError(name)
+
+
+def table_config_from_reference_json(raw: dict) -> TableRecConfig:
+    """config.json of a table-recognition checkpoint (SuryaTableRecConfig.to_dict: `encoder` = DonutSwinTableRecConfig, `decoder` =
+    SuryaTableRecDecoderConfig sub-dicts; surya/table_rec/loader.py:33-41 reads it the same way)."""
+    from ..layout.config import _pick
+    return TableRecConfig(name="checkpoint", encoder=_pick(SwinConfig, raw["encoder"]), decoder=_pick(TableDecoderConfig, raw["decoder"]))

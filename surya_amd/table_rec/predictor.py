@@ -7,6 +7,7 @@ decoder onto the encoder states by index (HipLayoutModel.select) where the refer
 steps (a causal prefill is the same arithmetic, tests/test_oracle_golden.py::test_table_oracle_matches_reference). No CPU fallback."""
 from __future__ import annotations
 
+import os
 from copy import deepcopy
 from itertools import chain
 from typing import List, Optional
@@ -28,13 +29,24 @@ PROMPT_CAPACITY = 512                                       # decoder positions 
 
 
 class TableRecModelLoader(ModelLoader):
-    """checkpoint: None / config name (synthetic weights) or {"config": TableRecConfig, "state_dict": {...}}."""
+    """checkpoint: None / config name (synthetic weights), {"config": TableRecConfig, "state_dict": {...}}, or a directory in the
+    reference's on-disk format (surya/table_rec/loader.py:19-76): config.json with `encoder` / `decoder` sub-configs, *.safetensors
+    with the reference's parameter names, preprocessor_config.json (SuryaEncoderImageProcessor: image_mean, image_std; the processor's
+    size is overridden by TABLE_REC_IMAGE_SIZE = the encoder's image size, table_rec/processor.py:17-20)."""
 
     def __init__(self, checkpoint=None):
         super().__init__(checkpoint)
         ck = checkpoint
+        self._mean = self._std = None
         if isinstance(ck, dict):
             self._cfg, self._sd = ck["config"], ck["state_dict"]
+        elif isinstance(ck, str) and os.path.isdir(ck):
+            from ..layout.config import read_checkpoint_dir
+            from .config import table_config_from_reference_json
+            raw, self._sd, pp = read_checkpoint_dir(ck)
+            self._cfg = table_config_from_reference_json(raw)
+            if pp:
+                self._mean, self._std = pp.get("image_mean"), pp.get("image_std")
         else:
             from ..synth import make_table_weights
             self._cfg = table_config(ck if isinstance(ck, str) else "TABLE-DEFAULT")
@@ -49,7 +61,7 @@ class TableRecModelLoader(ModelLoader):
 
     def processor(self, device=None, dtype=None) -> TableRecProcessor:
         h, w = self._cfg.encoder.image_size
-        return TableRecProcessor({"height": h, "width": w})
+        return TableRecProcessor({"height": h, "width": w}, image_mean=self._mean, image_std=self._std)
 
 
 def split_property_logits(dcfg, cls: np.ndarray):

@@ -20,8 +20,8 @@ class TableRecProcessor:
     token_bos_id = 1
     token_query_end_id = 4                                     # surya/table_rec/loader.py:70-75
 
-    def __init__(self, max_size):
-        self.image_processor = LayoutImageProcessor(max_size)
+    def __init__(self, max_size, image_mean=None, image_std=None):
+        self.image_processor = LayoutImageProcessor(max_size, image_mean, image_std)
         self.box_size = (BOX_DIM, BOX_DIM)
         self.special_token_count = SPECIAL_TOKENS
         self.shaper = LabelShaper()

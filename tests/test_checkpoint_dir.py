@@ -119,3 +119,76 @@ def test_detection_predictor_from_checkpoint_dir(hip_lib, det_ckpt):
     b = DetectionPredictor(checkpoint={"config": cfg, "state_dict": sd, "size": 256}, dtype=torch.float32)(pages)
     assert [[x.polygon for x in r.bboxes] for r in a] == [[x.polygon for x in r.bboxes] for r in b]
     assert sum(len(r.bboxes) for r in a) > 0
+
+
+def _write_family_dir(path, cfg, sd, preprocessor=None):
+    """config.json with `encoder` / `decoder` sub-dicts + model.safetensors, the layout / table-rec on-disk format
+    (surya/layout/loader.py:31-50, surya/table_rec/loader.py:33-46); checked against the reference's own writer in
+    tests/test_oracle_vs_reference.py::test_live_layout_and_table_checkpoint_directories_written_by_the_reference."""
+    import dataclasses, json, os
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    raw = {"model_type": "vision-encoder-decoder", "is_encoder_decoder": True,
+           "encoder": {k: (list(v) if isinstance(v, tuple) else v) for k, v in dataclasses.asdict(cfg.encoder).items()},
+           "decoder": {k: (list(v) if isinstance(v, tuple) else v) for k, v in dataclasses.asdict(cfg.decoder).items()}}
+    raw["encoder"]["model_type"] = "donut-swin"
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(raw, f)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    if preprocessor:
+        with open(os.path.join(path, "preprocessor_config.json"), "w") as f:
+            json.dump(preprocessor, f)
+    return path
+
+
+def test_layout_and_table_loaders_read_directories(tmp_path):
+    import dataclasses
+    import numpy as np
+    from surya_amd.layout.config import layout_config
+    from surya_amd.layout.predictor import LayoutModelLoader
+    from surya_amd.synth import make_layout_weights, make_table_weights
+    from surya_amd.table_rec.config import table_config
+    from surya_amd.table_rec.predictor import TableRecModelLoader
+    cfg = layout_config("LAYOUT-TINY")
+    sd = make_layout_weights(cfg, 1)
+    ld = LayoutModelLoader(_write_family_dir(str(tmp_path / "layout"), cfg, sd))
+    assert dataclasses.replace(ld._cfg, name=cfg.name) == cfg
+    assert set(ld._sd) == set(sd) and all(torch.equal(ld._sd[k], sd[k]) for k in sd)
+    assert ld.processor().max_size == {"height": 128, "width": 128}
+    tcfg = table_config("TABLE-TINY")
+    tsd = make_table_weights(tcfg, 2)
+    tl = TableRecModelLoader(_write_family_dir(str(tmp_path / "table"), tcfg, tsd,
+                                               {"image_mean": [0.4, 0.5, 0.6], "image_std": [0.2, 0.25, 0.3], "image_processor_type": "SuryaEncoderImageProcessor"}))
+    assert dataclasses.replace(tl._cfg, name=tcfg.name) == tcfg
+    assert all(torch.equal(tl._sd[k], tsd[k]) for k in tsd)
+    p = tl.processor()
+    assert np.allclose(p.image_processor.image_mean, [0.4, 0.5, 0.6]) and np.allclose(p.image_processor.image_std, [0.2, 0.25, 0.3])
+    with pytest.raises(FileNotFoundError):
+        import os
+        os.remove(str(tmp_path / "table" / "model.safetensors"))
+        TableRecModelLoader(str(tmp_path / "table"))
+
+
+@pytest.mark.gpu
+def test_table_predictor_from_checkpoint_dir(hip_lib, tmp_path):
+    """Directory -> loader -> HIP model -> TableRecPredictor.__call__ (fp32): the same results as the in-memory checkpoint."""
+    import numpy as np
+    from PIL import Image
+    from surya_amd.synth import make_table_weights
+    from surya_amd.table_rec import predictor as tp
+    from surya_amd.table_rec.config import table_config
+    cfg = table_config("TABLE-TINY")
+    sd = make_table_weights(cfg, 0)
+    sd["decoder.box_property_heads.category.weight"][5 + 1] *= 3.0
+    sd["decoder.box_property_heads.category.weight"][5 + 2] *= 2.5
+    path = _write_family_dir(str(tmp_path / "table"), cfg, sd)
+    rng = np.random.default_rng(3)
+    pages = [Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in ((200, 320), (128, 128))]
+    old = tp.TABLE_REC_MAX_BOXES
+    tp.TABLE_REC_MAX_BOXES = 10
+    try:
+        a = tp.TableRecPredictor(checkpoint=path, dtype=torch.float32)(pages)
+        b = tp.TableRecPredictor(checkpoint={"config": cfg, "state_dict": sd}, dtype=torch.float32)(pages)
+    finally:
+        tp.TABLE_REC_MAX_BOXES = old
+    assert [r.model_dump() for r in a] == [r.model_dump() for r in b]

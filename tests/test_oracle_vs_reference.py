@@ -1145,3 +1145,57 @@ def test_live_table_host_logic_against_reference():
                 x.pop("bbox", None); y.pop("bbox", None)
                 assert x == y, (key, x, y)
         assert da["image_bbox"] == db["image_bbox"]
+
+
+def test_live_layout_and_table_checkpoint_directories_written_by_the_reference(tmp_path):
+    """SuryaLayoutModel.save_pretrained / TableRecEncoderDecoderModel.save_pretrained (+ SuryaEncoderImageProcessor.save_pretrained for
+    the table processor) -- the reference's own writers; surya/layout/loader.py:25-64 and surya/table_rec/loader.py:19-76 read them back
+    -- load through LayoutModelLoader / TableRecModelLoader: same configuration (every field our dataclasses carry), same tensors, same
+    image statistics."""
+    import dataclasses
+    import os
+    from oracle.make_golden_layout import build_reference_layout
+    from oracle.make_golden_table import build_reference_table
+    from surya_amd.layout.config import layout_config
+    from surya_amd.layout.predictor import LayoutModelLoader
+    from surya_amd.synth import make_layout_weights, make_table_weights
+    from surya_amd.table_rec.config import table_config
+    from surya_amd.table_rec.predictor import TableRecModelLoader
+    cfgm, encm, decm = ref_shim.import_layout_modules()
+    edm = ref_shim.import_submodule("surya.layout.model.encoderdecoder")
+    cfg = layout_config("LAYOUT-TINY")
+    sd = make_layout_weights(cfg, 3)
+    enc, dec, dec_cfg = build_reference_layout(cfg, sd)
+    full = cfgm.SuryaLayoutConfig(encoder=enc.config, decoder=dec_cfg)
+    full._attn_implementation = "eager"
+    model = edm.SuryaLayoutModel(full, encoder=enc, decoder=dec)
+    path = str(tmp_path / "layout_from_reference")
+    model.save_pretrained(path, safe_serialization=True)
+    ld = LayoutModelLoader(path)
+    assert dataclasses.replace(ld._cfg, name=cfg.name) == cfg, (ld._cfg, cfg)
+    rsd = model.state_dict()
+    assert set(ld._sd) == set(rsd) and all(torch.equal(ld._sd[k], rsd[k]) for k in rsd)
+    assert all(torch.equal(ld._sd[k], sd[k]) for k in sd)           # the names our synthetic / repack code uses ARE the checkpoint's
+
+    tcfgm, tencm, tdecm, _ = ref_shim.import_table_modules()
+    tedm = ref_shim.import_submodule("surya.table_rec.model.encoderdecoder")
+    rproc = ref_shim.import_submodule("surya.common.donut.processor")
+    tcfg = table_config("TABLE-TINY")
+    tsd = make_table_weights(tcfg, 4)
+    tenc, tdec, tdec_cfg = build_reference_table(tcfg, tsd)
+    tfull = tcfgm.SuryaTableRecConfig(encoder=tenc.config, decoder=tdec_cfg)
+    tfull._attn_implementation = "eager"
+    tmodel = tedm.TableRecEncoderDecoderModel(tfull, encoder=tenc, decoder=tdec)
+    tpath = str(tmp_path / "table_from_reference")
+    tmodel.save_pretrained(tpath, safe_serialization=True)
+    rproc.SuryaEncoderImageProcessor(max_size={"height": 128, "width": 128}, image_mean=[0.4, 0.5, 0.6], image_std=[0.2, 0.25, 0.3]).save_pretrained(tpath)
+    tl = TableRecModelLoader(tpath)
+    assert dataclasses.replace(tl._cfg, name=tcfg.name) == tcfg, (tl._cfg, tcfg)
+    trsd = tmodel.state_dict()
+    assert set(tl._sd) == set(trsd) and all(torch.equal(tl._sd[k], trsd[k]) for k in trsd)
+    assert all(torch.equal(tl._sd[k], tsd[k]) for k in tsd)
+    p = tl.processor()
+    import numpy as np
+    assert np.allclose(p.image_processor.image_mean, [0.4, 0.5, 0.6]) and np.allclose(p.image_processor.image_std, [0.2, 0.25, 0.3])
+    assert p.image_processor.max_size == {"height": 128, "width": 128}
+    assert os.path.exists(os.path.join(tpath, "preprocessor_config.json"))
