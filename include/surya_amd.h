@@ -198,7 +198,7 @@ int surya_rec_set_mx_weights(surya_rec* h, const void* const* table, int n);
  * the decode-attention kernel is the largest of the step and moves its rows at HBM speed, so the lever is the bytes. Format "KV8":
  * per (slot, kv head, token) one power-of-two scale (the smallest with absmax / scale <= 448) + round-to-nearest-even e4m3
  * elements; K rows [slot][kv_head][max_kv_len][head_dim] bytes, V transposed per 128-token tile [slot][kv_head][T8 / 128][head_dim][128] bytes, scales fp32
- * [slot][kv_head][T8], T8 = max_kv_len rounded up to 128; the arrays live inside the handle. Prefill still attends over the bf16
+ * [slot][kv_head][T8], T8 = max_kv_len rounded up to 256; the arrays live inside the handle. Prefill still attends over the bf16
  * cache and quantises the prompt's rows; decode steps read and append fp8 only (decode_attn_kv8.h). bf16 models, head_dim in
  * {32, 64, 128}. No reference counterpart (surya/recognition/__init__.py:379-395 offers HQQ 8-bit only): the format is pinned by
  * oracle/mx_oracle.py::kv8_quantize and tests/test_gpu_kv8.py. Call while no line is in flight. */

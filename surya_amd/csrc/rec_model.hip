@@ -210,7 +210,7 @@ struct RecModel : RecBase {
     uint8_t *k8c = nullptr, *v8tc = nullptr;     // [layer][slot][kvh][Tmax][D], [layer][slot][kvh][D][Tmax8]
     float *ksc8 = nullptr, *vsc8 = nullptr;      // [layer][slot][kvh][Tmax8]
     bool kv8 = false;
-    int tmax8() const { return (c.max_kv_len + 127) & ~127; }
+    int tmax8() const { return (c.max_kv_len + 255) & ~255; }   // whole 256-key tiles (decode_attn_kv8.h)
     uint8_t *dh8 = nullptr, *sdh = nullptr, *dattn8 = nullptr, *sattn = nullptr, *dmlp8 = nullptr, *smlp = nullptr, *dlast8 = nullptr,
             *slast = nullptr;
     bool mx() const { return !mxw.empty(); }
@@ -687,7 +687,7 @@ struct RecModel : RecBase {
         auto kern = decode_attn_kv8_kernel<DD, GG>;                                                                             \
         static AttrOnce attr;                                                                                                   \
         attr.ensure(kern, decode_attn_kv8_lds<DD, GG>());                                                                       \
-        hipLaunchKernelGGL(kern, grid, block, (decode_attn_kv8_lds<DD, GG>()), s, h.part, S, WD(l, SA_RD_QKV_B), at, k8l, v8l, ksl, \
+        hipLaunchKernelGGL(kern, grid, dim3(KV8_THREADS), (decode_attn_kv8_lds<DD, GG>()), s, h.part, S, WD(l, SA_RD_QKV_B), at, k8l, v8l, ksl, \
                            vsl, act, rl, rope_cs, nq, nkv, c.max_kv_len, (int)T8, scale, at8, sat, c.max_slots);                \
     }
                 launched = true;
@@ -1252,7 +1252,7 @@ int surya_op_kv8_quant_rows(int head_dim, const void* kcache, const void* vcache
                             void* k8, void* v8t, float* kscale, float* vscale, int kv_heads, int max_kv_len, void* stream) {
     if (!kcache || !vcache || !tok_slot || !tok_pos || !k8 || !v8t || !kscale || !vscale || n_tokens <= 0 || kv_heads <= 0) return SA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int T8 = (max_kv_len + 127) & ~127;
+    const int T8 = (max_kv_len + 255) & ~255;
     dim3 qg(cdiv(n_tokens * kv_heads, 4));
 #define SA_Q8(DD)                                                                                                                  \
     hipLaunchKernelGGL(kv8_quant_rows_kernel<DD>, qg, dim3(256), 0, s, (const bf16_t*)kcache, (const bf16_t*)vcache, tok_slot, tok_pos, \
@@ -1271,7 +1271,7 @@ int surya_op_decode_attn_kv8(int head_dim, const float* qkv_part, int n_slabs, c
     if (!qkv_part || !qkv_bias || !out || !k8 || !v8t || !kscale || !vscale || !active_slots || !row_len || !rope_cs) return SA_ERR_ARG;
     if (rows <= 0 || n_slabs < 1 || n_slabs > 8 || kv_heads <= 0 || heads % kv_heads) return SA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int G = heads / kv_heads, d = head_dim, T8 = (max_kv_len + 127) & ~127;
+    const int G = heads / kv_heads, d = head_dim, T8 = (max_kv_len + 255) & ~255;
     dim3 grid(rows, kv_heads), block(256);
     const float2* cs = reinterpret_cast<const float2*>(rope_cs);
 #define SA_OPD8(DD, GG)                                                                                                          \
@@ -1279,7 +1279,7 @@ int surya_op_decode_attn_kv8(int head_dim, const float* qkv_part, int n_slabs, c
         auto kern = decode_attn_kv8_kernel<DD, GG>;                                                                             \
         static AttrOnce attr;                                                                                                   \
         attr.ensure(kern, decode_attn_kv8_lds<DD, GG>());                                                                       \
-        hipLaunchKernelGGL(kern, grid, block, (decode_attn_kv8_lds<DD, GG>()), s, qkv_part, n_slabs, (const bf16_t*)qkv_bias,   \
+        hipLaunchKernelGGL(kern, grid, dim3(KV8_THREADS), (decode_attn_kv8_lds<DD, GG>()), s, qkv_part, n_slabs, (const bf16_t*)qkv_bias, \
                            (bf16_t*)out, (uint8_t*)k8, (uint8_t*)v8t, kscale, vscale, active_slots, row_len, cs, heads, kv_heads, \
                            max_kv_len, T8, scale, (uint8_t*)nullptr, (uint8_t*)nullptr, 0);                                     \
     }

@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 def _kv8_arrays(kc, vc, lens, slots, Tmax):
     """Quantise rows [0, len) of the given slots through surya_op_kv8_quant_rows; returns the device arrays."""
     n_slots, nkv, _, d = kc.shape
-    T8 = (Tmax + 127) // 128 * 128
+    T8 = (Tmax + 255) // 256 * 256
     k8 = torch.zeros(n_slots, nkv, Tmax, d, dtype=torch.uint8, device="cuda")
     v8t = torch.zeros(n_slots, nkv, T8 // 128, d, 128, dtype=torch.uint8, device="cuda")      # transposed inside each 128-token tile
     ks = torch.zeros(n_slots, nkv, T8, dtype=torch.float32, device="cuda")
