@@ -68,7 +68,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
     const int wm = wave / WN, wn = wave % WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_n = (p.Cout + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    // XCD x (= blockIdx.x % 8) takes the x-th contiguous eighth of the tile raster, so that output rows sharing input rows sit in one
+    // XCD's L2 (see dwconv_tx_kernel: FETCH_SIZE of the stem convolutions was 2.2x their input in launch order)
+    const unsigned nb_ = gridDim.x, xcd_ = blockIdx.x & 7, per_ = nb_ >> 3, rem_ = nb_ & 7;
+    const int bid = (int)(xcd_ * per_ + min(xcd_, rem_) + (blockIdx.x >> 3));
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const int ntaps = p.KH * p.KW;
 
     // per-chunk constants: output pixel of the row, chunk position inside the 128-byte K-row
@@ -338,7 +342,13 @@ __global__ __launch_bounds__(256) void dwconv_tx_kernel(const T* __restrict__ in
     constexpr int V = Ty<T>::V16;
     constexpr int NIN = (TX - 1) * S + K;            // input columns feeding TX outputs
     const int cv = C / V, wx = (Wo + TX - 1) / TX;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroup b runs on XCD b % 8, each XCD with its own L2. In launch order the workgroups of vertically adjacent output rows landed
+    // on different XCDs, so every input row crossed the fabric once per XCD that needed it: FETCH_SIZE was 2.4x the tensor for 3 x 3
+    // and 8x for 5 x 5 (profiles/r03_k_det_hbm_traffic_pmc.md). Give XCD x the x-th contiguous eighth of the raster instead: rows that
+    // share input rows are then neighbours in ONE XCD's queue.
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3, rem = nb & 7;
+    const unsigned lb = xcd * per + min(xcd, rem) + (blockIdx.x >> 3);
+    const long idx = (long)lb * blockDim.x + threadIdx.x;
     if (idx >= (long)B * Ho * wx * cv) return;
     const int c0 = (int)(idx % cv) * V;
     const long t = idx / cv;
