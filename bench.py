@@ -740,6 +740,25 @@ def bench_table(args, local_rank):
                 agree += int((got.argmax(-1) == ref.argmax(-1)).sum()); total += ref.shape[0]
     out["parity"] = {"bf16_worst_property_logit_err_rel": round(worst, 4), "bf16_argmax_equal": f"{agree}/{total}",
                      "note": "teacher-forced on the reference's prompt and fed-back tokens; fp32 mode is bit-exact on the classes (tests/test_gpu_table.py)"}
+    del m, m2
+    torch.cuda.empty_cache()
+    if not args.no_cpu_baseline:
+        from oracle import layout_oracle as lo
+        x2 = px[:2].float().cpu()
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            enc = lo.encoder_forward(sd, cfg.encoder, x2)
+            t_e = time.perf_counter() - t0
+            st = lo.LayoutDecoderState(d.num_hidden_layers)
+            ids = torch.from_numpy(prompt[:2].astype(np.int64))
+            t0 = time.perf_counter()
+            lo.decoder_forward(sd, d, ids, enc, 0, st)
+            for k in range(4):
+                lo.decoder_forward(sd, d, ids[:, 1:2], enc, 3 + k, st)
+            t_s = (time.perf_counter() - t0) / 5
+        out["cpu_baseline"] = {"value": round(2 / (t_e + (positions - 2) * t_s), 3), "unit": "tables/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"2 of the same crops: encoder {t_e:.2f}s + prompt prefill and 4 decode steps at {t_s * 1e3:.1f} ms per call, "
+                                         f"extrapolated to {positions} positions; fp32 oracle, bit-identical to the reference modules"}
     return out
 
 
