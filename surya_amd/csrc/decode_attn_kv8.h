@@ -9,6 +9,9 @@
 //   v2 (the same with four buffers, three tiles in flight)                 20.7 us   -- not latency-bound either: ~3.6 us of serial work per tile
 //   v3 (this file: 8 waves = two per SIMD, 16 x 16 x 32 MFMA, 256-key tiles) 16.8 us -- compute per tile down to ~1.2 us; what remains is the
 //      HBM side: 256 workgroups x 64 KB per tile are served at ~2.9 TB/s, and the first tile's burst is ~45 % of the kernel at 586 tokens
+//   v4 (tried after v3, not kept: 128-key tiles in four buffers, 16 keys per wave, P V on 16 x 16 x 16 MFMAs) 17.4-18.1 us -- the smaller
+//      first burst shortens the prologue (19.7k -> 16.4k cycles) but the per-tile fixed work of a wave (scale reads, two ds_bpermute for
+//      the shared maximum, exp, 32 accumulator rescales, 8 P V MFMAs) is paid twice as often: 3.2k cycles per 128 keys vs 2.9k per 256
 // texify run (128 crops x 768 tokens): 1.17x over bf16 with MXFP8 weights alone -> 1.29-1.30x with this cache on top.
 //
 // Format ("KV8"): per (slot, kv head, token) ONE power-of-two scale 2^e, the smallest with absmax / 2^e <= 448 (mx_block_exp:
