@@ -383,6 +383,12 @@ int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, v
  * T tokens is T calls, which is what a causal prefill computes); class_logits host fp32 [batch][label_count], bbox host fp32 [batch][6] (after the
  * sigmoid). Synchronises the stream (the reference moves both to the host after every step as well). */
 int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream);
+/* A decoder PROMPT of n_tokens (<= 64) tokens per row in one pass -- the reference's first decoder call, prefill = True
+ * (surya/table_rec/__init__.py:60-68; the layout prompt is a single token) -- at positions 0 .. n_tokens - 1; boxes host int32
+ * [batch][n_tokens][token width]; outputs as surya_layout_decode_step, for every row's LAST prompt token; the following decode steps
+ * continue at position n_tokens. Equivalent to n_tokens decode steps (a causal prefill is the same arithmetic); SA_ERR_ARG when the prompt
+ * does not fit the borrowed encoder workspaces -- callers then take the step-by-step route. Synchronises the stream. */
+int surya_layout_prefill(surya_layout* h, const int32_t* boxes, int batch, int n_tokens, float* class_logits, float* bbox, void* stream);
 /* Re-batch the decoder after surya_layout_encode: the following decode steps run n rows (n <= max_batch), row i cross-attending the
  * encoder states of image src_index[i] (host array, values < the encoded batch). Table recognition decodes the cells of every detected
  * ROW against its table image (surya/table_rec/__init__.py:196-230: row_encoder_hidden_states = stacked copies); here the copies are an

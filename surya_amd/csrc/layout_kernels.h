@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const float* __re
     const T* vb = kb + nkv * D;
     for (int i = tid; i < G * D; i += 256) {
         float a = 0.f;
+        if (S == 0) a = Ty<T>::ld(reinterpret_cast<const T*>(qpart) + (long)b * Hq + kvh * G * D + i);     // prompt prefill: a plain [M][nq * D] matrix
         for (int s = 0; s < S; ++s) a += qpart[((long)s * M + b) * Hq + kvh * G * D + i];
         qsh[i] = Ty<T>::rnd(a);
     }
@@ -601,6 +602,76 @@ __global__ __launch_bounds__(1024) void splitk_residual_adetr_norm_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Causal self-attention of a short decoder PROMPT (table recognition: [bos, query, query_end] + one token per column, Tn <= 64 tokens per
+// row; SuryaADETRDecoderSdpaAttention with prefill = True, adetr/decoder.py:239-284): RoPE at positions 0 .. Tn - 1, K / V written to the
+// cache rows the decode steps continue from, every query attends keys <= its own position. One workgroup per (row, kv head); the prompt is
+// tiny (Tn^2 * G * D MACs), so this is plain fp32 VALU work from LDS. qkv rows: [row * Tn + t][(nq + 2 nkv) * D] (no bias in this model).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void adetr_prefill_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ kc, T* __restrict__ vc,
+                                                                 const float2* __restrict__ rope_cs, int Tn, int nq, int nkv, int Tmax, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ksh = reinterpret_cast<float*>(smem_raw);               // [Tn][D]
+    float* vsh = ksh + Tn * D;                                      // [Tn][D]
+    const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, G = nq / nkv, half = D / 2;
+    const long qkv_d = (long)(nq + 2 * nkv) * D;
+    const T* rows = qkv + (long)b * Tn * qkv_d;
+    T* kdst = kc + ((long)b * nkv + kvh) * Tmax * D;
+    T* vdst = vc + ((long)b * nkv + kvh) * Tmax * D;
+    auto R = [](float v) { return Ty<T>::rnd(v); };
+    for (int it = tid; it < Tn * half; it += 256) {
+        const int t = it / half, i = it % half;
+        const float2 cs = rope_cs[(long)t * half + i];
+        const T* kr = rows + t * qkv_d + (long)(nq + kvh) * D;
+        const float x1 = Ty<T>::ld(kr + i), x2 = Ty<T>::ld(kr + i + half);
+        const float y1 = R(x1 * cs.x - x2 * cs.y), y2 = R(x2 * cs.x + x1 * cs.y);
+        ksh[t * D + i] = y1; ksh[t * D + i + half] = y2;
+        Ty<T>::st(kdst + (long)t * D + i, y1); Ty<T>::st(kdst + (long)t * D + i + half, y2);
+    }
+    for (int it = tid; it < Tn * D; it += 256) {
+        const int t = it / D, i = it % D;
+        const T v = rows[t * qkv_d + (long)(nq + nkv + kvh) * D + i];
+        vsh[it] = Ty<T>::ld(&v);
+        vdst[(long)t * D + i] = v;
+    }
+    __syncthreads();
+    for (int it = tid; it < Tn * G; it += 256) {                    // one (query position, head) per thread
+        const int t = it / G, g = it % G, head = kvh * G + g;
+        const T* qr = rows + t * qkv_d + (long)head * D;
+        float q[D], o[D];
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float2 cs = rope_cs[(long)t * half + i];
+            const float x1 = Ty<T>::ld(qr + i), x2 = Ty<T>::ld(qr + i + half);
+            q[i] = R(R(x1 * cs.x - x2 * cs.y) * scale); q[i + half] = R(R(x2 * cs.x + x1 * cs.y) * scale);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[i] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j <= t; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) sdot += q[i] * ksh[j * D + i];
+            const float mn = fmaxf(m, sdot), al = __expf(m - mn), pv = __expf(sdot - mn);
+            l = l * al + pv;
+            const float pr = R(pv);                                 // the decode kernels round P to the storage dtype before P V as well
+#pragma unroll
+            for (int i = 0; i < D; ++i) o[i] = o[i] * al + pr * vsh[j * D + i];
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        T* op = out + ((long)b * Tn + t) * nq * D + (long)head * D;
+#pragma unroll
+        for (int i = 0; i < D; i += 4) store4(op + i, o[i] * inv, o[i + 1] * inv, o[i + 2] * inv, o[i + 3] * inv);
+    }
+}
+
+// row b * Tn + t of a prompt cross-attends the image of decoder row b
+__global__ void expand_map_kernel(const int* __restrict__ src, int* __restrict__ dst, int B, int Tn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * Tn) dst[i] = src[i / Tn];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Output heads of SuryaLayoutDecoder.forward (layout/model/decoder.py:119-131): final ADETR RMSNorm -> LayerNorm -> class logits
 // (label_count rows, no bias) and sigmoid(bbox_head). One workgroup per image; every intermediate is rounded to the storage dtype
 // where the reference materialises a tensor. class_logits fp32 [B][label_count], bbox fp32 [B][6].
@@ -608,12 +679,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void layout_heads_kernel(const T* __restrict__ x, const T* __restrict__ fnorm_w, const T* __restrict__ ln_w,
                                                            const T* __restrict__ ln_b, const T* __restrict__ lm_w, const T* __restrict__ bb_w,
                                                            const T* __restrict__ bb_b, float* __restrict__ cls, float* __restrict__ box, int Hd,
-                                                           int label_count, float rms_eps, float ln_eps) {
+                                                           int label_count, float rms_eps, float ln_eps, long ldx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* h = reinterpret_cast<float*>(smem_raw);                  // [Hd]
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const T* xr = x + (long)b * Hd;
+    const T* xr = x + (long)b * ldx;
     auto block_sum = [&](float v) {
         v = wave_sum(v);
         __syncthreads();

@@ -32,6 +32,7 @@ struct LayoutBase {
     virtual int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) = 0;
     virtual int encoder_states(void* out, int B, hipStream_t s) = 0;
     virtual int select(const int32_t* src, int n) = 0;
+    virtual int prefill(const int32_t* boxes, int B, int Tn, float* cls, float* box, hipStream_t s) = 0;
 };
 
 static size_t lalign(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -57,6 +58,8 @@ struct LayoutModel : LayoutBase {
     T *dx, *dh, *dq, *dattn, *dres, *dmlp;
     float* part;
     float* cross_scratch;                        // [B][nq][ranges][hd + 2] partial cross-attention records
+    static constexpr int MAX_PROMPT = 64;        // tokens of a decoder prompt that prefill() takes in one pass
+    size_t enc_mlp_bytes = 0, enc_qkv_bytes = 0; // sizes of the encoder workspaces prefill() borrows between two encodes
     int cross_ranges = 1, cross_chunk = 0;
     int* cross_map_dev = nullptr;                // [max_batch] decoder row -> encoded image whose K / V it cross-attends
     int batch_active = 0;                        // decoder rows of the current decode (encode: = batch; select: any re-batching)
@@ -92,6 +95,7 @@ struct LayoutModel : LayoutBase {
         auto take = [&](size_t bytes) { size_t o = off; off = lalign(off + bytes); return o; };
         const size_t o_patch = take(rows0 * 64 * sizeof(T)), o_x = take(rows0 * E * sizeof(T)), o_h = take(rows0 * E * sizeof(T));
         const size_t o_qkv = take(rows0 * 3 * E * sizeof(T)), o_att = take(rows0 * E * sizeof(T)), o_mlp = take(rows0 * 4 * E * sizeof(T));
+        enc_qkv_bytes = rows0 * 3 * E * sizeof(T); enc_mlp_bytes = rows0 * 4 * E * sizeof(T);
         const size_t o_ckv = take((size_t)c.dec_layers * B * Lk * 2 * kv * sizeof(T));
         const size_t kv_elems = (size_t)c.dec_layers * B * c.dec_kv_heads * c.max_boxes * hd();
         const size_t o_k = take(kv_elems * sizeof(T)), o_v = take(kv_elems * sizeof(T));
@@ -159,7 +163,7 @@ struct LayoutModel : LayoutBase {
                                rope_cs, c.max_boxes, half);
             SA_HIP(hipGetLastError());
         }
-        SA_HIP(hipHostMalloc((void**)&pinned, B * (10 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
+        SA_HIP(hipHostMalloc((void**)&pinned, B * (MAX_PROMPT * 10 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
         SA_HIP(hipDeviceSynchronize());
         return SA_OK;
     }
@@ -270,6 +274,99 @@ struct LayoutModel : LayoutBase {
         return SA_OK;
     }
 
+    // A decoder prompt of Tn tokens per row in ONE pass (positions 0 .. Tn - 1; the decode steps continue at Tn): GEMMs over B * Tn rows,
+    // cross attention per (row, token), causal self-attention inside each row's prompt with the K / V rows written to the cache. What
+    // the reference's first decoder call does with prefill = True (surya/table_rec/__init__.py:60-68). Activations live in the
+    // encoder's idle MLP / qkv workspaces. Returns the heads' outputs of every row's LAST prompt token.
+    int prefill(const int32_t* boxes, int B, int Tn, float* cls, float* box, hipStream_t s) override {
+        if (B != batch_active) return SA_ERR_STATE;
+        if (Tn < 1 || Tn > MAX_PROMPT || Tn > c.max_boxes) return SA_ERR_ARG;
+        const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
+        const int qkv_d = Hd + 2 * kv, rows = B * Tn, G = nq / nkv;
+        if (G > 8 || (d != 64 && d != 32)) return SA_ERR_UNSUPPORTED;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = lalign(off + bytes); return o; };
+        const size_t o_x = take((size_t)rows * Hd * sizeof(T)), o_h = take((size_t)rows * Hd * sizeof(T)), o_q = take((size_t)rows * Hd * sizeof(T));
+        const size_t o_qkv = take((size_t)rows * qkv_d * sizeof(T)), o_at = take((size_t)rows * Hd * sizeof(T)), o_rs = take((size_t)rows * Hd * sizeof(T));
+        const size_t o_ml = take((size_t)rows * I * sizeof(T));
+        if (off > enc_mlp_bytes) return SA_ERR_ARG;                   // callers fall back to one decode step per prompt token
+        char* wb = reinterpret_cast<char*>(mlp);
+        T *px = (T*)(wb + o_x), *ph = (T*)(wb + o_h), *pq = (T*)(wb + o_q), *pqkv = (T*)(wb + o_qkv), *pat = (T*)(wb + o_at), *prs = (T*)(wb + o_rs),
+          *pml = (T*)(wb + o_ml);
+        off = 0;
+        const size_t o_sc = take((size_t)rows * nq * cross_ranges * (d + 2) * sizeof(float)), o_mp = take((size_t)rows * sizeof(int)),
+                     o_bx = take((size_t)rows * tokw() * sizeof(int));
+        if (off > enc_qkv_bytes) return SA_ERR_ARG;
+        char* qb = reinterpret_cast<char*>(qkv);
+        float* pscr = (float*)(qb + o_sc);
+        int *pmap = (int*)(qb + o_mp), *pbox = (int*)(qb + o_bx);
+        int rc;
+        int* hb = reinterpret_cast<int*>(pinned);
+        memcpy(hb, boxes, (size_t)rows * tokw() * sizeof(int));
+        SA_HIP(hipMemcpyAsync(pbox, hb, (size_t)rows * tokw() * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(lay::expand_map_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, cross_map_dev, pmap, B, Tn);
+        if (c.family == SA_FAMILY_TABLE)
+            hipLaunchKernelGGL(lay::table_embed_kernel<T>, dim3(rows), dim3(256), 0, s, pbox, tabs_dev, px, Hd, c.box_embed, c.bbox_size, c.vocab,
+                               c.category_count, c.merge_count);
+        else
+            hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(rows), dim3(256), 0, s, pbox, tabs_dev, px, Hd, c.bbox_size, c.vocab, c.label_count);
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t layer_kv = (size_t)c.max_batch * nkv * c.max_boxes * d;
+        auto norm = [&](const T* in, int wi, T* outp) {
+            hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, in, W(wi), outp, rows, Hd, c.rms_eps);
+        };
+        for (int l = 0; l < c.dec_layers; ++l) {
+            const int lb = dec_base + l * SA_LD_COUNT;
+            norm(px, lb + SA_LD_CNORM, ph);
+            if ((rc = gemm<EPI_BIAS>(ph, Hd, W(lb + SA_LD_CQ_W), Hd, pq, Hd, nullptr, nullptr, 0, rows, Hd, Hd, s))) return rc;
+            {
+                const T* kvp = ckv + (size_t)l * c.max_batch * Lk * 2 * kv;
+                const size_t lds = ((size_t)G * cross_chunk + (size_t)G * d + 1024) * sizeof(float);
+                dim3 grid(rows, nkv, cross_ranges);
+                const int mblocks = cdiv(rows * nq * (d / 4), 256);
+                if (d == 64) {
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, reinterpret_cast<const float*>(pq), 0, rows, kvp, pscr,
+                                       pmap, nq, nkv, Lk, cross_chunk, scale);
+                    hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 64>), dim3(mblocks), dim3(256), 0, s, pscr, pat, rows * nq, cross_ranges);
+                } else {
+                    hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 32>), grid, dim3(256), lds, s, reinterpret_cast<const float*>(pq), 0, rows, kvp, pscr,
+                                       pmap, nq, nkv, Lk, cross_chunk, scale);
+                    hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 32>), dim3(mblocks), dim3(256), 0, s, pscr, pat, rows * nq, cross_ranges);
+                }
+            }
+            if ((rc = gemm<EPI_RESIDUAL>(pat, Hd, W(lb + SA_LD_CO_W), Hd, prs, Hd, W(lb + SA_LD_CO_B), px, Hd, rows, Hd, Hd, s))) return rc;
+            norm(prs, lb + SA_LD_TNORM, ph);
+            if ((rc = gemm<EPI_BIAS>(ph, Hd, W(lb + SA_LD_QKV_W), Hd, pqkv, qkv_d, nullptr, nullptr, 0, rows, qkv_d, Hd, s))) return rc;
+            {
+                T* kc = kcache + (size_t)l * layer_kv;
+                T* vc = vcache + (size_t)l * layer_kv;
+                const size_t lds = (size_t)2 * Tn * d * sizeof(float);
+                if (d == 64) hipLaunchKernelGGL((lay::adetr_prefill_attn_kernel<T, 64>), dim3(B, nkv), dim3(256), lds, s, pqkv, pat, kc, vc, rope_cs, Tn, nq, nkv,
+                                                c.max_boxes, scale);
+                else hipLaunchKernelGGL((lay::adetr_prefill_attn_kernel<T, 32>), dim3(B, nkv), dim3(256), lds, s, pqkv, pat, kc, vc, rope_cs, Tn, nq, nkv,
+                                        c.max_boxes, scale);
+            }
+            // layout: + RAW layer input (double residual flow); table_rec: + the cross-attention output
+            if ((rc = gemm<EPI_RESIDUAL>(pat, Hd, W(lb + SA_LD_TO_W), Hd, prs, Hd, W(lb + SA_LD_TO_B), c.family == SA_FAMILY_TABLE ? prs : px, Hd, rows, Hd,
+                                         Hd, s))) return rc;
+            norm(prs, lb + SA_LD_MNORM, ph);
+            if ((rc = gemm<EPI_GEGLU>(ph, Hd, W(lb + SA_LD_GU_W), Hd, pml, I, nullptr, nullptr, 0, rows, 2 * I, Hd, s))) return rc;
+            if ((rc = gemm<EPI_RESIDUAL>(pml, I, W(lb + SA_LD_DOWN_W), I, px, Hd, nullptr, prs, Hd, rows, Hd, I, s))) return rc;
+        }
+        hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, px + (size_t)(Tn - 1) * Hd, W(SA_LW_DEC_FNORM),
+                           W(SA_LW_DEC_LN_W), W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd,
+                           c.label_count, c.rms_eps, c.ln_eps, (long)Tn * Hd);
+        if ((rc = (int)hipGetLastError())) return rc;
+        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * MAX_PROMPT * 10 * sizeof(int));
+        float* hbx = hc + (size_t)c.max_batch * c.label_count;
+        SA_HIP(hipMemcpyAsync(hc, cls_dev, (size_t)B * c.label_count * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(hbx, box_dev, (size_t)B * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipStreamSynchronize(s));
+        memcpy(cls, hc, (size_t)B * c.label_count * sizeof(float));
+        memcpy(box, hbx, (size_t)B * 6 * sizeof(float));
+        return SA_OK;
+    }
+
     int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) override {
         if (B != batch_active) return SA_ERR_STATE;
         if (pos < 0 || pos >= c.max_boxes) return SA_ERR_ARG;
@@ -368,9 +465,9 @@ struct LayoutModel : LayoutBase {
         }
         hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
                            W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd, c.label_count,
-                           c.rms_eps, c.ln_eps);
+                           c.rms_eps, c.ln_eps, (long)Hd);
         if ((rc = (int)hipGetLastError())) return rc;
-        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * 10 * sizeof(int));
+        float* hc = reinterpret_cast<float*>(pinned + 256 + (size_t)c.max_batch * MAX_PROMPT * 10 * sizeof(int));
         float* hbx = hc + (size_t)c.max_batch * c.label_count;
         SA_HIP(hipMemcpyAsync(hc, cls_dev, (size_t)B * c.label_count * sizeof(float), hipMemcpyDeviceToHost, s));
         SA_HIP(hipMemcpyAsync(hbx, box_dev, (size_t)B * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -432,6 +529,11 @@ int surya_layout_encode(surya_layout* h, const float* pixel_values, int batch, v
 int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, int position, float* class_logits, float* bbox, void* stream) {
     if (!h || !boxes || !class_logits || !bbox) return SA_ERR_ARG;
     return h->impl->decode_step(boxes, batch, position, class_logits, bbox, (hipStream_t)stream);
+}
+
+int surya_layout_prefill(surya_layout* h, const int32_t* boxes, int batch, int n_tokens, float* class_logits, float* bbox, void* stream) {
+    if (!h || !boxes || !class_logits || !bbox) return SA_ERR_ARG;
+    return h->impl->prefill(boxes, batch, n_tokens, class_logits, bbox, (hipStream_t)stream);
 }
 
 int surya_layout_select(surya_layout* h, const int32_t* src_index, int n) {

@@ -215,6 +215,26 @@ class HipLayoutModel:
         L.check(self.lib.surya_layout_select(self.handle, L.np_ptr(idx), C.c_int(idx.size)), "surya_layout_select")
         self.batch = int(idx.size)
 
+    MAX_PROMPT = 64
+
+    def prefill(self, boxes: np.ndarray):
+        """boxes: int32 [B, T, token width], the decoder prompt of every row (T <= MAX_PROMPT); one pass over all T positions
+        (surya_layout_prefill). Returns (class_logits, bbox) of the LAST prompt token; decode steps continue at position T.
+        Falls back to T decode steps when the prompt does not fit the engine's borrowed workspaces."""
+        b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, -1, self.tok_width)
+        T = b.shape[1]
+        if T <= self.MAX_PROMPT:
+            rc = self.lib.surya_layout_prefill(self.handle, L.np_ptr(b), C.c_int(self.batch), C.c_int(T), L.np_ptr(self._cls, C.c_float),
+                                               L.np_ptr(self._box, C.c_float), self._stream)
+            if rc == 0:
+                return self._cls[: self.batch].copy(), self._box[: self.batch].copy()
+            if rc != -1:                                     # SA_ERR_ARG = the prompt does not fit: step by step below
+                L.check(rc, "surya_layout_prefill")
+        out = None
+        for t in range(T):
+            out = self.decode_step(b[:, t], t)
+        return out
+
     def decode_step(self, boxes: np.ndarray, position: int):
         """boxes: int32 [B, 7] (table family: [B, 10]); returns (class_logits [B, label_count], bbox [B, 6]) numpy copies."""
         b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, self.tok_width)

@@ -3,8 +3,8 @@ engine (csrc/layout_model.hip, SA_FAMILY_TABLE).
 
 Two decoding passes per batch of table images, as in the reference: (1) prompt = the whole table -> rows and columns; (2) one prompt per
 detected row (+ all the batch's columns as context) -> the row's spanning cells. The encoder runs once; the second pass re-batches the
-decoder onto the encoder states by index (HipLayoutModel.select) where the reference stacks copies. The prompt's T tokens are T decode
-steps (a causal prefill is the same arithmetic, tests/test_oracle_golden.py::test_table_oracle_matches_reference). No CPU fallback."""
+decoder onto the encoder states by index (HipLayoutModel.select) where the reference stacks copies. The prompt's T tokens go through
+HipLayoutModel.prefill in one pass (surya_layout_prefill), as the reference's first decoder call does. No CPU fallback."""
 from __future__ import annotations
 
 import os
@@ -98,8 +98,11 @@ class TableRecPredictor(BasePredictor):
         position, token_count, step_tokens = 0, 0, T
         ids = batch_input_ids.astype(np.int32)
         while token_count < TABLE_REC_MAX_BOXES:
-            for t in range(ids.shape[1]):                    # the prompt (first pass) or the one fed-back token
-                cls, box = self.model.decode_step(ids[:, t], position)
+            if position == 0:                                # the prompt: one pass over its T tokens (the reference's prefill = True call)
+                cls, box = self.model.prefill(ids)
+                position = ids.shape[1]
+            else:                                            # the one fed-back token
+                cls, box = self.model.decode_step(ids[:, 0], position)
                 position += 1
             props = split_property_logits(dcfg, cls)
             category = props["category"].argmax(-1)

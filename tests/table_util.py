@@ -31,6 +31,15 @@ class OracleTableModel:
         self.map = idx
         self.state = None
 
+    def prefill(self, boxes):
+        d = self.cfg.decoder
+        self.state = lo.LayoutDecoderState(d.num_hidden_layers)
+        b = torch.from_numpy(np.asarray(boxes, np.int64)).view(len(self.map), -1, 10)
+        with torch.inference_mode():
+            box, props = lo.decoder_forward(self.sd, d, b, self.enc[self.map], 0, self.state)
+        cls = torch.cat([props[k][:, -1] for k, _ in d.head_widths() if k != "bbox"], -1)
+        return cls.numpy().copy(), box[:, -1].numpy().copy()
+
     def decode_step(self, boxes, position):
         d = self.cfg.decoder
         if position == 0:

@@ -219,3 +219,51 @@ def test_table_predictor_bf16_call_and_schema(hip_lib):
         assert len(r.unmerged_cells) >= len(r.cells)
         for c in r.cells:
             assert 0 <= c.row_id < max(1, len(r.rows)) and c.colspan >= 1 and np.isfinite(np.array(c.polygon)).all()
+
+
+@pytest.mark.parametrize("name,fixture", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_table_prompt_prefill_in_one_pass(hip_lib, name, fixture, dtype):
+    """surya_layout_prefill (the prompt's T tokens in one pass: GEMMs over B * T rows, per-token cross attention, causal self-attention
+    inside the prompt, K / V rows written to the cache) == the fixture's prefill logits (the reference's own prefill = True call) and
+    == T single-token steps; the decode steps that follow continue from its cache rows."""
+    g = torch.load(os.path.join(GOLD, fixture))
+    cfg, m = _model(name, dtype, g["batch"])
+    m.encode(_pixels(cfg, g["batch"], g["seed"]).cuda().contiguous())
+    T = g["prompt"].shape[1]
+    prompt = g["prompt"].numpy().astype(np.int32)
+    cls_s, box_s = _prefill(m, g["prompt"])                      # token by token
+    cls_p, box_p = m.prefill(prompt)                             # one pass (also rewrites the cache rows 0 .. T - 1)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    scale = max(1.0, float(np.abs(cls_s).max()))
+    assert np.abs(cls_p - cls_s).max() <= tol * scale and np.abs(box_p - box_s).max() <= (1e-5 if dtype == torch.float32 else 2e-2)
+    props = _split(cfg, cls_p)
+    for k, _, mode in BOX_PROPERTIES:
+        got = box_p if k == "bbox" else props[k]
+        ref = g["logits"][k][0].numpy()
+        assert np.abs(got - ref).max() <= (tol if k != "bbox" else (1e-5 if dtype == torch.float32 else 2e-2)) * (scale if k != "bbox" else 1.0), k
+        if mode == "classification" and dtype == torch.float32:
+            assert np.array_equal(got.argmax(-1), ref.argmax(-1)), k
+    # the steps after the prefill read its cache rows
+    for step in range(1, min(4, g["steps"])):
+        cls, box = m.decode_step(g["fed_tokens"][step - 1].numpy().astype(np.int32), T + step - 1)
+        props = _split(cfg, cls)
+        for k, _, mode in BOX_PROPERTIES:
+            got = box if k == "bbox" else props[k]
+            ref = g["logits"][k][step].numpy()
+            hs = max(1.0, max(float(g["logits"][kk][step].abs().max()) for kk, _, _ in BOX_PROPERTIES if kk != "bbox"))
+            assert np.abs(got - ref).max() <= ((1e-5 if dtype == torch.float32 else 2e-2) if k == "bbox" else tol * hs), (k, step)
+
+
+def test_layout_prompt_prefill_single_token(hip_lib):
+    """The layout family's prompt is one token: prefill == decode_step(position 0)."""
+    from surya_amd.layout.config import layout_config
+    from surya_amd.layout.model import HipLayoutModel
+    from surya_amd.synth import make_layout_weights
+    cfg = layout_config("LAYOUT-SMALL")
+    m = HipLayoutModel(cfg, make_layout_weights(cfg, 0), dtype=torch.float32, max_batch=4, max_boxes=16)
+    m.encode(torch.randn(3, 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(1)).cuda().contiguous())
+    boxes = np.full((3, 1, 7), cfg.decoder.bos_token_id, np.int32)
+    a = m.decode_step(boxes[:, 0], 0)
+    b = m.prefill(boxes)
+    assert np.allclose(a[0], b[0], atol=1e-4) and np.allclose(a[1], b[1], atol=1e-6)
