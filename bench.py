@@ -700,8 +700,8 @@ def bench_table(args, local_rank):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         tok = None
-        for pos in range(positions):
-            cls, box = m.decode_step(prompt[:, pos] if pos < 3 else tok, pos)
+        for pos in range(2, positions):
+            cls, box = m.prefill(prompt) if pos == 2 else m.decode_step(tok, pos)      # the 3-token prompt in one pass, then fed-back tokens
             if pos >= 2:
                 o, parts = 0, []
                 for n in widths:
