@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         // whole super-tiles including the clipped ones, and with N = 1280 (10 tile columns = one full + one quarter
         // super-column) the odd XCDs drew only quarter super-tiles and the launch ran at 63 % (r01 microbench).
         const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        constexpr int GRP = (BM * BN >= 256 * 256) ? 32 : 64;           // workgroups resident on one XCD (32 CUs x 1 or 2)
+        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 ? GLDS : 2) > 80 * 1024) ? 32 : 64;     // workgroups resident on one XCD (32 CUs x 1 or 2, by LDS)
         const int idx = ((j / GRP) * 8 + x) * GRP + (j % GRP);
         const int tiles_m = (p.M + BM - 1) / BM;
         if (idx >= tiles_m * tiles_n) return;
@@ -644,7 +644,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     GemmArgs<TI, TO> aa = a;
     if (!SPLIT && BM >= 128 && BN >= 128) {          // XCD-aware super-tiles for the large-tile configurations
         const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
-        constexpr int GRP = (BM * BN >= 256 * 256) ? 32 : 64;
+        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 ? GLDS : 2) > 80 * 1024) ? 32 : 64;
         if (tm * tn >= 8 * GRP) {
             aa.swz_n = cdiv(tn, cdiv(tn, 8));                 // equal-width super-columns of <= 8 tile columns
             aa.swz_m = std::max(1, GRP / aa.swz_n);
@@ -720,6 +720,9 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         // measured throughput ratio of the two kernels on full rounds ~1.17 (r01 microbench)
         const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
         const double cost256 = (double)cdivl(t256, 256) * 256 * 4 / 1.17, cost128 = (double)cdivl(big, 512) * 512;
+        // (r03: 256 x 128 tiles with a 3-stage ring -- 144 KB, deeper prefetch, 1.37x the L2 bytes per flop -- lost 5-15 % on every
+        // encoder / prefill shape and on 8k^3 (1212 -> 1026 TF/s, profiles/r03_sweeps.txt): the big-tile loop is bound by L2 -> LDS bytes
+        // per flop, not by prefetch depth.)
         if (bigtile && a.K >= tuning().bigtile_min_k && t256 >= 256 && cost256 <= cost128) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
     }
     if (big >= 256) {
