@@ -267,3 +267,26 @@ def test_layout_prompt_prefill_single_token(hip_lib):
     a = m.decode_step(boxes[:, 0], 0)
     b = m.prefill(boxes)
     assert np.allclose(a[0], b[0], atol=1e-4) and np.allclose(a[1], b[1], atol=1e-6)
+
+
+def test_table_prefill_prompt_length_boundaries(hip_lib):
+    """Prompts of 64 tokens (the one-pass limit) and 70 tokens (HipLayoutModel.prefill falls back to 70 decode steps) give the same
+    last-token outputs as the explicit step-by-step route; a prompt that exceeds the decoder's positions is refused by the engine."""
+    cfg, m = _model("TABLE-SMALL", torch.float32, 3, max_boxes=96)
+    m.encode(_pixels(cfg, 3, 5).cuda().contiguous())
+    rng = np.random.default_rng(0)
+    for T in (64, 70):
+        prompt = np.concatenate([rng.integers(0, 1025, size=(3, T, 6)), rng.integers(5, 10, size=(3, T, 1)), rng.integers(5, 9, size=(3, T, 1)),
+                                 rng.integers(0, 4, size=(3, T, 1)), rng.integers(5, 7, size=(3, T, 1))], -1).astype(np.int32)
+        ref = None
+        for t in range(T):
+            ref = m.decode_step(prompt[:, t], t)
+        got = m.prefill(prompt)
+        assert np.abs(got[0] - ref[0]).max() <= 2e-4 * max(1.0, np.abs(ref[0]).max()) and np.abs(got[1] - ref[1]).max() <= 1e-5, T
+        nxt_a = m.decode_step(prompt[:, 0], T)                   # continues from the prefill's cache rows
+        for t in range(T):
+            m.decode_step(prompt[:, t], t)
+        nxt_b = m.decode_step(prompt[:, 0], T)
+        assert np.abs(nxt_a[0] - nxt_b[0]).max() <= 2e-4 * max(1.0, np.abs(nxt_b[0]).max()), T
+    with pytest.raises(Exception):
+        m.decode_step(prompt[:, 0], 96)                          # position == max_boxes
