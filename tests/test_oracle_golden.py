@@ -280,3 +280,50 @@ def test_table_oracle_matches_reference(name, fixture):
                     assert (got - ref).abs().max().item() <= (1e-5 if k == "bbox" else 1e-4 * max(1.0, ref.abs().max().item())), (k, step)
                     if mode == "classification":
                         assert torch.equal(got.argmax(-1), ref.argmax(-1)), (k, step)
+
+
+def test_family_host_logic_matches_reference_vectors():
+    """tests/golden/family_host_reference.json (oracle/make_golden_family_host.py: the REAL reference's table LabelShaper, processor
+    prompts, TableRecPredictor.decode_batch_predictions, layout prediction_to_polygon and ImageSlicer, recorded in the build container)
+    against surya_amd.table_rec / surya_amd.layout -- the travelling form of the live cross-checks in tests/test_oracle_vs_reference.py."""
+    import copy
+    import json
+    from types import SimpleNamespace
+    import numpy as np
+    from PIL import Image
+    from surya_amd.layout import predictor as lp, slicer as ls
+    from surya_amd.table_rec import predictor as tp
+    from surya_amd.table_rec.processor import TableRecProcessor
+    from surya_amd.table_rec.shaper import LabelShaper
+    with open(os.path.join(GOLD, "family_host_reference.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    sh = LabelShaper()
+    s = g["shaper"]
+    conv = sh.convert_polygons_to_bboxes(copy.deepcopy(s["items"]))
+    assert [[float(v) for v in c["bbox"]] for c in conv] == s["bboxes"]
+    assert sh.dict_to_labels(conv) == s["labels"]
+    for e in s["box_to_polygon"]:
+        assert sh.convert_bbox_to_polygon(list(e["box"])) == e["polygon"]
+    assert {k: list(v) for k, v in sh.component_idx_dict().items()} == s["component_idx"]
+    p = g["processor"]
+    proc = TableRecProcessor({"height": 128, "width": 128})
+    got = proc(images=None, query_items=copy.deepcopy(p["rows"]), columns=copy.deepcopy(p["columns"]), convert_images=False)["input_ids"]
+    assert got.tolist() == p["ids_with_columns"]
+    got = proc(images=None, query_items=copy.deepcopy(p["rows"]), columns=None, convert_images=False)["input_ids"]
+    assert got.tolist() == p["ids_without_columns"]
+    proc.image_processor = lambda images: {"pixel_values": []}
+    q = [{"polygon": [[0, 0], [w, 0], [w, h], [0, h]], "category": 4, "colspan": 0, "merges": 0, "is_header": 0} for w, h in p["image_sizes"]]
+    got = proc(images=[Image.new("RGB", tuple(sz)) for sz in p["image_sizes"]], query_items=q)["input_ids"]
+    assert got.tolist() == p["ids_table_queries"]
+    o_self = SimpleNamespace(processor=proc)
+    for a in g["assembly"]:
+        res = tp.TableRecPredictor.decode_batch_predictions(o_self, [copy.deepcopy(a["rowcol"])], copy.deepcopy(a["cells"]), [tuple(a["size"])],
+                                                            [0] * len(a["cells"]), sh)
+        assert json.loads(json.dumps(res[0].model_dump())) == a["expected"]
+    for e in g["layout"]["prediction_to_polygon"]:
+        assert lp.prediction_to_polygon(np.asarray(e["token"], np.float32), tuple(e["size"]), 1024, 512) == e["polygon"]
+    sl = ls.ImageSlicer({"height": 1500, "width": 1500}, {"height": 1200, "width": 1200})
+    for e in g["layout"]["slicer"]:
+        im = Image.new("RGB", tuple(e["size"]))
+        pieces, positions = sl.slice([im])
+        assert sl.slice_count(im) == e["count"] and [list(x) for x in positions] == e["positions"] and [list(x.size) for x in pieces] == e["piece_sizes"]
