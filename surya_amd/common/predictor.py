@@ -77,3 +77,27 @@ def gc_paused():
                 gc.freeze()
                 gc.unfreeze()
             gc.enable()
+
+
+def sharded_over_ranks(images, run_local, model_device, group=None, chunk: int = 1):
+    """Multi-GPU for predictors whose inputs are independent images (detection pages, layout pages, table crops): the
+    images of ONE call are dealt over the ranks of the initialised process group, each rank runs `run_local` on its share and the
+    per-image results (small objects) are all-gathered back in the caller's order on every rank. Every rank must pass the same images
+    (checked: count, sizes and a pixel probe). `chunk` > 1 deals whole runs of `chunk` consecutive images (the caller's batches) instead
+    of single images -- for predictors whose result for an image depends on its batch mates (table recognition appends the columns of
+    ALL the batch's tables to every row prompt, surya/table_rec/__init__.py:196-222). Returns None when there is nothing to shard (world
+    size 1): the caller runs locally."""
+    import zlib
+    import numpy as np
+    from .. import dist as sdist
+    rank, world = sdist.world_info(group)
+    if world <= 1:
+        return None
+    dev = sdist.collective_device(model_device, group)
+    sizes = np.asarray([im.size for im in images], np.int64).reshape(-1, 2)
+    probe = b"".join(im.tobytes()[:4096] for im in images[:: max(1, len(images) // 16)])
+    sdist.assert_same_inputs([len(images), zlib.crc32(sizes.tobytes()), zlib.crc32(probe)], group, dev)
+    n_chunks = (len(images) + chunk - 1) // chunk
+    mine = [i for c in sdist.shard_indices(n_chunks, world, rank) for i in range(c * chunk, min((c + 1) * chunk, len(images)))]
+    local = run_local([images[i] for i in mine]) if mine else []
+    return sdist.gather_objects(local, mine, len(images), group)

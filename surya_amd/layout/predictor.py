@@ -104,7 +104,18 @@ class LayoutPredictor(BasePredictor):
     batch_size = None
     default_batch_sizes = {"cpu": 4, "mps": 4, "cuda": 32, "xla": 16}
 
+    # Multi-GPU: when set, ONE call's pages are dealt over the ranks of the initialised process group and the per-page
+    # results all-gathered (common/predictor.sharded_over_ranks). Off by default, like DetectionPredictor.shard_pages.
+    shard_pages: bool = settings.SURYA_AMD_SHARD
+    process_group = None
+
     def __call__(self, images: List[Image.Image], batch_size: Optional[int] = None, top_k: int = 5) -> List[LayoutResult]:
+        if self.shard_pages:
+            from ..common.predictor import sharded_over_ranks
+            out = sharded_over_ranks(images, lambda mine: self.batch_layout_detection(mine, top_k=top_k, batch_size=batch_size),
+                                     self.model.device, self.process_group)
+            if out is not None:
+                return out
         return self.batch_layout_detection(images, top_k=top_k, batch_size=batch_size)
 
     def batch_layout_detection(self, images: List[Image.Image], batch_size: Optional[int] = None, top_k: int = 5) -> List[LayoutResult]:

@@ -19,6 +19,7 @@ from PIL import Image
 from ..common.geometry import PolygonBox
 from ..common.predictor import BasePredictor, ModelLoader
 from ..layout.model import HipLayoutModel
+from ..settings import settings
 from .config import BOX_DIM, BOX_PROPERTIES, CATEGORY_TO_ID, MAX_BOXES, MERGE_KEYS, MERGE_VALUES, SPECIAL_TOKENS, TableRecConfig, table_config
 from .processor import TableRecProcessor
 from .schema import TableCell, TableCol, TableResult, TableRow
@@ -79,7 +80,19 @@ class TableRecPredictor(BasePredictor):
     batch_size = None
     default_batch_sizes = {"cpu": 8, "mps": 8, "cuda": 32, "xla": 16}
 
+    # Multi-GPU: when set, ONE call's table crops are dealt over the ranks of the initialised process group in whole
+    # batches (the reference's second pass makes a table's cells depend on the other tables of its batch) and the per-table results
+    # all-gathered (common/predictor.sharded_over_ranks). Off by default, like DetectionPredictor.shard_pages.
+    shard_pages: bool = settings.SURYA_AMD_SHARD
+    process_group = None
+
     def __call__(self, images: List[Image.Image], batch_size: Optional[int] = None) -> List[TableResult]:
+        if self.shard_pages:
+            from ..common.predictor import sharded_over_ranks
+            bs = min(batch_size or self.get_batch_size(), self.model.max_batch)       # whole batches per rank: a table's cells depend on its batch mates
+            out = sharded_over_ranks(images, lambda mine: self.batch_table_recognition(mine, bs), self.model.device, self.process_group, chunk=bs)
+            if out is not None:
+                return out
         return self.batch_table_recognition(images, batch_size)
 
     # ------------------------------------------------------------------------------------------------------------ decoding

@@ -155,3 +155,68 @@ def test_sharded_prediction_loop_two_ranks_equal_one(n_lines, slots):
             assert len(scores[i]) == len(exp)
             assert (boxes[i, :len(exp), 0] == i).all()            # every gathered box row belongs to the right line
     assert results[0][1] == results[1][1] and np.array_equal(results[0][2], results[1][2])
+
+
+def _table_worker(rank, world, port, q):
+    """TableRecPredictor.__call__ with shard_pages on the PRODUCT host code (both decoding passes, grid assembly), the model behind it
+    being the CPU oracle with HipLayoutModel's interface (tests/table_util.py)."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from PIL import Image
+    from surya_amd.synth import make_table_weights
+    from surya_amd.table_rec import predictor as tp
+    from surya_amd.table_rec.config import table_config
+    from surya_amd.table_rec.processor import TableRecProcessor
+    from table_util import OracleTableModel
+    torch.set_num_threads(4)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = table_config("TABLE-TINY")
+    sd_ = make_table_weights(cfg, 0)
+    sd_["decoder.box_property_heads.category.weight"][5 + 1] *= 3.0
+    sd_["decoder.box_property_heads.category.weight"][5 + 2] *= 2.5
+    tp.TABLE_REC_MAX_BOXES = 8
+    pred = object.__new__(tp.TableRecPredictor)
+    pred.model = OracleTableModel(cfg, sd_, max_batch=4)
+    pred.processor = TableRecProcessor({"height": 128, "width": 128})
+    pred.shard_pages = world > 1
+    pred.process_group = None
+    rng = np.random.default_rng(3)
+    pages = [Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for h, w in ((200, 320), (128, 128), (90, 400), (150, 150), (64, 300))]
+    out = pred(pages, batch_size=2)
+    q.put((rank, [r.model_dump() for r in out]))
+    if world > 1:
+        try:
+            pred([pages[0]] if rank == 0 else [pages[1]], batch_size=2)          # different inputs per rank must fail loudly
+            q.put((rank, "no error"))
+        except Exception as e:
+            q.put((rank, "raised " + type(e).__name__))
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_table_predictor_two_ranks_equal_one():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_table_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_table_worker, args=(0, 1, port, q1))
+    p1.start()
+    _, single = q1.get(timeout=300)
+    p1.join(timeout=60)
+    results = [g for g in got if isinstance(g[1], list)]
+    errors = [g for g in got if isinstance(g[1], str)]
+    assert len(results) == 2 and all(r[1] == single for r in results)       # every rank holds all 5 tables, equal to the 1-rank run
+    assert len(single) == 5 and sum(len(t["rows"]) for t in single) > 0
+    assert len(errors) == 2 and all(e[1].startswith("raised") for e in errors), errors
