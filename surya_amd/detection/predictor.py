@@ -147,17 +147,10 @@ class DetectionPredictor(BasePredictor):
 
     def _call(self, images, batch_size=None, include_maps=False) -> List[TextDetectionResult]:
         if self.shard_pages:
-            from .. import dist as sdist
-            rank, world = sdist.world_info(self.process_group)
-            if world > 1:
-                import zlib
-                dev = sdist.collective_device(self.model.device, self.process_group)
-                sizes = np.asarray([im.size for im in images], np.int64).reshape(-1, 2)
-                probe = b"".join(im.tobytes()[:4096] for im in images[:: max(1, len(images) // 16)])
-                sdist.assert_same_inputs([len(images), zlib.crc32(sizes.tobytes()), zlib.crc32(probe)], self.process_group, dev)
-                mine = sdist.shard_indices(len(images), world, rank)
-                local = self._detect([images[i] for i in mine], batch_size, include_maps) if mine else []
-                return sdist.gather_objects(local, mine, len(images), self.process_group)
+            from ..common.predictor import sharded_over_ranks
+            out = sharded_over_ranks(images, lambda mine: self._detect(mine, batch_size, include_maps), self.model.device, self.process_group)
+            if out is not None:
+                return out
         return self._detect(images, batch_size, include_maps)
 
     # Heat map -> boxes runs on the device (surya_det_boxes): what leaves the GPU per page is a few hundred 4-point boxes instead
