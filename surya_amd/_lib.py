@@ -43,6 +43,7 @@ class SuryaAmdError(RuntimeError):
     pass
 
 
+SA_OK, SA_ERR_ARG, SA_ERR_SHAPE, SA_ERR_UNSUPPORTED, SA_ERR_STATE, SA_ERR_NOMEM = 0, -1, -2, -3, -4, -5      # include/surya_amd.h
 _ERR = {-1: "SA_ERR_ARG", -2: "SA_ERR_SHAPE", -3: "SA_ERR_UNSUPPORTED", -4: "SA_ERR_STATE", -5: "SA_ERR_NOMEM"}
 _lib = None
 

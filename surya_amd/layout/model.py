@@ -226,9 +226,9 @@ class HipLayoutModel:
         if T <= self.MAX_PROMPT:
             rc = self.lib.surya_layout_prefill(self.handle, L.np_ptr(b), C.c_int(self.batch), C.c_int(T), L.np_ptr(self._cls, C.c_float),
                                                L.np_ptr(self._box, C.c_float), self._stream)
-            if rc == 0:
+            if rc == L.SA_OK:
                 return self._cls[: self.batch].copy(), self._box[: self.batch].copy()
-            if rc != -1:                                     # SA_ERR_ARG = the prompt does not fit: step by step below
+            if rc != L.SA_ERR_ARG:                           # SA_ERR_ARG = the prompt does not fit the borrowed workspaces: step by step below
                 L.check(rc, "surya_layout_prefill")
         out = None
         for t in range(T):
