@@ -242,7 +242,7 @@ class RecognitionPredictor(BasePredictor):
     default_batch_sizes = {"cpu": 32, "mps": 64, "cuda": 256, "xla": 128}
     encoder_chunk_size: int = 4096
     encoder_chunk_sizes = {"cpu": 4096, "mps": 4096, "cuda": 32768, "xla": 32768}
-    min_prefill_ratio: float = 0.2
+    min_prefill_ratio: float = settings.RECOGNITION_MIN_PREFILL_RATIO
     min_trim_length: int = 50        # kept for API compatibility; the slot cache has no left padding to trim
     tasks = {
         TaskNames.ocr_with_boxes: {"needs_bboxes": True, "img_size": (1024, 256), "max_tokens": 224},

@@ -54,6 +54,9 @@ class Settings:
         self.RECOGNITION_DECODE_FP8: bool = _env("RECOGNITION_DECODE_FP8", bool, False)
         # decode steps on an fp8 KV cache (csrc/decode_attn_kv8.h): pays at long horizons (texify); off by default for the same reason
         self.RECOGNITION_KV_FP8: bool = _env("RECOGNITION_KV_FP8", bool, False)
+        # continuous batching: refill (prefill new lines) once more than this share of the slots is empty; 0.2 = the reference's
+        # RecognitionPredictor.min_prefill_ratio (surya/recognition/__init__.py:71). Scheduling only: results do not depend on it.
+        self.RECOGNITION_MIN_PREFILL_RATIO: float = _env("RECOGNITION_MIN_PREFILL_RATIO", float, 0.2)
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
         # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the
