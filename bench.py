@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--texify-tokens", type=int, default=256, help="decode horizon of the texify leg (the task's own default is 768)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end detect + recognise leg (configs[3])")
     ap.add_argument("--no-layout", action="store_true", help="skip the layout-model leg (SURVEY 8(f) rank 4)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B aid: sa::Tuning launch-policy knob set through surya_set_tuning before anything runs (e.g. bigtile=0)")
     ap.add_argument("--layout-only", action="store_true", help="profiling aid: run only the layout + table_rec legs and print their objects")
     ap.add_argument("--texify-only", action="store_true", help="profiling aid: run only the texify leg and print its object")
     ap.add_argument("--e2e-pages", type=int, default=128)
@@ -781,6 +783,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+    for kv in args.tuning:
+        from surya_amd import _lib as _L
+        k, v = kv.split("=")
+        _L.check(_L.lib().surya_set_tuning(k.encode(), int(v)), f"surya_set_tuning({kv})")
     if args.det_only:
         print(json.dumps(bench_det(args, local_rank, world, rank, lambda: None)), flush=True)
         return
