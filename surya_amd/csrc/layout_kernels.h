@@ -548,6 +548,161 @@ __global__ __launch_bounds__(256) void cross_attn_merge_kernel(const float* __re
     store4(out + (long)r * D + c, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
 }
 
+// bf16 cross attention on the matrix cores, straight from global memory into MFMA operands (the encoder keys / values of a layer are
+// read once per (row, kv head) per step: nothing to stage or share through LDS). 512 threads = 8 waves; wave w owns a contiguous run of
+// keys; v_mfma_f32_16x16x32_bf16 with a lane owning head (lane & 15) and, per 16-key block, keys 4g .. 4g + 3 (g = lane >> 4):
+//   S^T block = K (16 keys x 32 dims per step) . q^T : A = 16 bytes of a key row (kv rows as the fused k | v projection wrote them),
+//                                                      B = 16 bytes of the lane's q head (LDS, summed from the split-K slabs);
+//   O^T      += V^T (16 dims x 32 keys) . P^T        : A = 16 bytes = 8 consecutive keys of one dim row of vT, the TRANSPOSED values
+//                                                      [row][kv head][D][Lkp] written once per encode by transpose_cross_v_kernel,
+//                                                      B = the lane's 8 probabilities -- with the key order of the A operand:
+//                                                      element i <-> key 8g + i of the 32-key step, so S^T is computed on keys
+//                                                      permuted accordingly (block b, row m = key 8 (m >> 2) + (m & 3) + 4 b ... see kperm).
+// All loads of a 3-step chunk (96 keys per wave) are issued before the first MFMA: one memory round trip per chunk. Replaces
+// cross_attn_split_kernel + cross_attn_merge_kernel (15 + 4.9 us per layer, profiles/r03_t_layout_table_kernel_stats.md) for bf16.
+template <int D>
+__global__ __launch_bounds__(512) void cross_attn_mfma_kernel(const float* __restrict__ qpart, int S, int M, const bf16_t* __restrict__ kv,
+                                                              const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
+                                                              const int* __restrict__ item_map, int nq, int nkv, int Lk, int Lkp, float scale) {
+    constexpr int NW = 8, NKS = D / 32, NDB = D / 16, CW = D + 4, STEPS = 3;
+    __shared__ __attribute__((aligned(16))) bf16_t qsh[16 * D];      // q heads of this kv head, rows >= G zero
+    __shared__ __attribute__((aligned(16))) float comb[NW * 8 * CW]; // per-wave (O[D], max, sum) of up to 8 heads
+    const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = nq / nkv, Hq = nq * D, row_w = 2 * nkv * D, img = item_map[b];
+    const int hn = lane & 15, g4 = lane >> 4;
+    for (int i = tid; i < 16 * D; i += 512) {
+        const int h = i / D, c = i % D;
+        float a = 0.f;
+        if (h < G) {
+            if (S == 0) a = bf2f(reinterpret_cast<const bf16_t*>(qpart)[(long)b * Hq + (kvh * G + h) * D + c]);
+            for (int s = 0; s < S; ++s) a += qpart[((long)s * M + b) * Hq + (kvh * G + h) * D + c];
+        }
+        qsh[i] = f2bf(a);
+    }
+    __syncthreads();
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qsh + hn * D + ks * 32 + g4 * 8);
+    // keys of this wave: [k_lo, k_hi), a multiple of 32 long except at the end of the sequence
+    const int kpw = ((Lk + NW - 1) / NW + 31) & ~31;
+    const int k_lo = wave * kpw, k_hi = min(Lk, k_lo + kpw);
+    const bf16_t* kbase = kv + (long)img * Lk * row_w + kvh * D;
+    const bf16_t* vbase = vT + ((long)img * nkv + kvh) * D * Lkp;
+    f32x4 oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+    // A-operand row m of S^T block kb (16 keys) of a 32-key step is key  8 (m >> 2) + 4 kb + (m & 3)  of the step, so that the lane's
+    // four scores of block kb (rows 4 g4 + i) are keys 8 g4 + 4 kb + i: its 8 probabilities [block 0 | block 1] are keys 8 g4 .. 8 g4 + 7,
+    // the k order of the V^T operand's 16 contiguous bytes.
+    const int krow = 8 * (hn >> 2) + (hn & 3);
+    for (int c0 = k_lo; c0 < k_hi; c0 += 32 * STEPS) {
+        u32x4 kf[STEPS][2][NKS], vf[STEPS][NDB];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int s0 = c0 + 32 * st;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int key = min(s0 + krow + 4 * kb, Lk - 1);                      // clamped: rows past the end are masked below
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    kf[st][kb][ks] = *reinterpret_cast<const u32x4*>(kbase + (long)key * row_w + ks * 32 + g4 * 8);
+            }
+            const int vk = min(s0, Lkp - 32) + g4 * 8;                                // vT rows are padded to whole 32-key steps with zeros
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vf[st][db] = *reinterpret_cast<const u32x4*>(vbase + (long)(db * 16 + hn) * Lkp + vk);
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int s0 = c0 + 32 * st;
+            if (s0 >= k_hi) break;                                                    // wave-uniform
+            f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[st][kb][ks]), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                                       sacc[kb], 0, 0, 0);
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = s0 + 8 * g4 + 4 * kb + i;
+                    const float sv = key < k_hi ? sacc[kb][i] * scale : -INFINITY;
+                    sacc[kb][i] = sv;
+                    bm = fmaxf(bm, sv);
+                }
+            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                                   // finite: key s0 < k_hi belongs to g4 = 0
+            const float mnew = fmaxf(mrun, bm), alpha = __expf(mrun - mnew);
+            mrun = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = __expf(sacc[kb][i] - mnew);
+                    sacc[kb][i] = pv;
+                    psum += pv;
+                }
+            lrun = lrun * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) oacc[db][i] *= alpha;
+            u32x4 pf;
+            pf[0] = pack2(sacc[0][0], sacc[0][1]); pf[1] = pack2(sacc[0][2], sacc[0][3]);
+            pf[2] = pack2(sacc[1][0], sacc[1][1]); pf[3] = pack2(sacc[1][2], sacc[1][3]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[st][db]), __builtin_bit_cast(bf16x8, pf), oacc[db], 0, 0, 0);
+        }
+    }
+    float ltot = lrun + __shfl_xor(lrun, 16, 64);
+    ltot += __shfl_xor(ltot, 32, 64);
+    if (hn < G) {
+        float* rec = comb + (wave * 8 + hn) * CW;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            *reinterpret_cast<float4*>(rec + db * 16 + g4 * 4) = make_float4(oacc[db][0], oacc[db][1], oacc[db][2], oacc[db][3]);
+        if (g4 == 0) { rec[D] = mrun; rec[D + 1] = ltot; }
+    }
+    __syncthreads();
+    if (tid < G * (D / 4)) {
+        const int oh = tid / (D / 4), od = (tid % (D / 4)) * 4;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, comb[(w * 8 + oh) * CW + D]);
+        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* rec = comb + (w * 8 + oh) * CW;
+            const float e = (rec[D] == -INFINITY) ? 0.f : __expf(rec[D] - mx);        // waves past the sequence hold (-inf, 0, 0)
+            const float4 o4 = *reinterpret_cast<const float4*>(rec + od);
+            num[0] += e * o4.x; num[1] += e * o4.y; num[2] += e * o4.z; num[3] += e * o4.w;
+            den += e * rec[D + 1];
+        }
+        const float inv = 1.0f / den;
+        store4(out + (long)b * Hq + (long)(kvh * G + oh) * D + od, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+    }
+}
+
+// vT[row][kv head][d][key] <- the v half of the fused k | v projection rows [row][key][2 * nkv * D]; keys >= Lk (padding to whole 32-key
+// steps) are zero. Once per encode and layer.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cross_v_kernel(const T* __restrict__ kv, T* __restrict__ vT, int Lk, int Lkp, int nkv, int D) {
+    const long n = (long)gridDim.y * nkv * D * Lkp;                  // gridDim.y = images
+    const int img = blockIdx.y;
+    const long per = (long)nkv * D * Lkp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int key = (int)(i % Lkp), d = (int)((i / Lkp) % D), h = (int)(i / ((long)Lkp * D));
+        T v = key < Lk ? kv[((long)img * Lk + key) * (2 * nkv * D) + (nkv + h) * D + d] : T(0);
+        vT[(long)img * per + i] = v;
+    }
+    (void)n;
+}
+
 // Launch-boundary reduce of a split-K projection of the ADETR decoder, fused with bias, the residual add and the NEXT
 // SuryaADETRDecoderRMSNorm (adetr_rmsnorm_kernel's arithmetic):
 //   x_out <- T(res + T(bias + sum_s part[s]))          (Linear output rounded, then the residual add, as the unsplit epilogue does)

@@ -54,6 +54,8 @@ struct LayoutModel : LayoutBase {
     std::vector<int*> perm;                      // [stage * 2 + (shift > 0)] device permutation tables (token -> window-order row)
     // decoder
     T *ckv;                                      // [layer][B][Lk][2 * kvd]
+    T *cvT = nullptr;                            // bf16: [layer][B][nkv][hd][Lkp] transposed cross-attention values (cross_attn_mfma_kernel)
+    int Lkp = 0;
     T *kcache, *vcache;                          // [layer][B][nkv][Tmax][hd]
     T *dx, *dh, *dq, *dattn, *dres, *dmlp;
     float* part;
@@ -97,6 +99,8 @@ struct LayoutModel : LayoutBase {
         const size_t o_qkv = take(rows0 * 3 * E * sizeof(T)), o_att = take(rows0 * E * sizeof(T)), o_mlp = take(rows0 * 4 * E * sizeof(T));
         enc_qkv_bytes = rows0 * 3 * E * sizeof(T); enc_mlp_bytes = rows0 * 4 * E * sizeof(T);
         const size_t o_ckv = take((size_t)c.dec_layers * B * Lk * 2 * kv * sizeof(T));
+        Lkp = (Lk + 31) & ~31;
+        const size_t o_cvt = take((size_t)c.dec_layers * B * kv * Lkp * sizeof(T));
         const size_t kv_elems = (size_t)c.dec_layers * B * c.dec_kv_heads * c.max_boxes * hd();
         const size_t o_k = take(kv_elems * sizeof(T)), o_v = take(kv_elems * sizeof(T));
         const size_t o_dx = take(B * Hd * sizeof(T)), o_dh = take(B * Hd * sizeof(T)), o_dq = take(B * qd * sizeof(T));
@@ -122,7 +126,7 @@ struct LayoutModel : LayoutBase {
         SA_HIP(hipMalloc((void**)&arena, off));
         char* b = arena;
         patch_rows = (T*)(b + o_patch); x = (T*)(b + o_x); hbuf = (T*)(b + o_h); qkv = (T*)(b + o_qkv); att = (T*)(b + o_att); mlp = (T*)(b + o_mlp);
-        ckv = (T*)(b + o_ckv); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
+        ckv = (T*)(b + o_ckv); cvT = (T*)(b + o_cvt); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
         dx = (T*)(b + o_dx); dh = (T*)(b + o_dh); dq = (T*)(b + o_dq); dattn = (T*)(b + o_da); dres = (T*)(b + o_dr); dmlp = (T*)(b + o_dm);
         part = (float*)(b + o_part); rope_cs = (float2*)(b + o_rope);
         cross_scratch = (float*)(b + o_cscr); cross_map_dev = (int*)(b + o_cmap);
@@ -252,6 +256,9 @@ struct LayoutModel : LayoutBase {
             const int lb = dec_base + l * SA_LD_COUNT;
             T* dst = ckv + (size_t)l * c.max_batch * Lk * kv2;
             if ((rc = gemm<EPI_BIAS>(x, dim, W(lb + SA_LD_CKV_W), dim, dst, kv2, nullptr, nullptr, 0, (int)rows, kv2, dim, s))) return rc;
+            if constexpr (std::is_same<T, bf16_t>::value)
+                hipLaunchKernelGGL(lay::transpose_cross_v_kernel<T>, dim3(64, B), dim3(256), 0, s, dst, cvT + (size_t)l * c.max_batch * kvd() * Lkp, Lk, Lkp,
+                                   c.dec_kv_heads, hd());
         }
         return (int)hipGetLastError();
     }
@@ -324,7 +331,13 @@ struct LayoutModel : LayoutBase {
                 const size_t lds = ((size_t)G * cross_chunk + (size_t)G * d + 1024) * sizeof(float);
                 dim3 grid(rows, nkv, cross_ranges);
                 const int mblocks = cdiv(rows * nq * (d / 4), 256);
-                if (d == 64) {
+                if constexpr (std::is_same<T, bf16_t>::value) {
+                    const T* vtp = cvT + (size_t)l * c.max_batch * kv * Lkp;
+                    if (d == 64) hipLaunchKernelGGL((lay::cross_attn_mfma_kernel<64>), dim3(rows, nkv), dim3(512), 0, s, reinterpret_cast<const float*>(pq), 0, rows,
+                                                    kvp, vtp, pat, pmap, nq, nkv, Lk, Lkp, scale);
+                    else hipLaunchKernelGGL((lay::cross_attn_mfma_kernel<32>), dim3(rows, nkv), dim3(512), 0, s, reinterpret_cast<const float*>(pq), 0, rows,
+                                            kvp, vtp, pat, pmap, nq, nkv, Lk, Lkp, scale);
+                } else if (d == 64) {
                     hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, reinterpret_cast<const float*>(pq), 0, rows, kvp, pscr,
                                        pmap, nq, nkv, Lk, cross_chunk, scale);
                     hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 64>), dim3(mblocks), dim3(256), 0, s, pscr, pat, rows * nq, cross_ranges);
@@ -413,7 +426,18 @@ struct LayoutModel : LayoutBase {
                 dim3 grid(B, nkv, cross_ranges);
                 if (G > 8 || G * (d / 4) > 256) return SA_ERR_UNSUPPORTED;
                 const int mblocks = cdiv(B * nq * (d / 4), 256);
-                if (d == 64) {
+                bool done = false;
+                if constexpr (std::is_same<T, bf16_t>::value) {          // matrix-core kernel on the transposed values (layout_kernels.h)
+                    const T* vtp = cvT + (size_t)l * c.max_batch * kv * Lkp;
+                    done = true;
+                    if (d == 64) hipLaunchKernelGGL((lay::cross_attn_mfma_kernel<64>), dim3(B, nkv), dim3(512), 0, s, part, S, B, kvp, vtp, dattn, cross_map_dev,
+                                                    nq, nkv, Lk, Lkp, scale);
+                    else if (d == 32) hipLaunchKernelGGL((lay::cross_attn_mfma_kernel<32>), dim3(B, nkv), dim3(512), 0, s, part, S, B, kvp, vtp, dattn,
+                                                         cross_map_dev, nq, nkv, Lk, Lkp, scale);
+                    else done = false;
+                }
+                if (done) {
+                } else if (d == 64) {
                     hipLaunchKernelGGL((lay::cross_attn_split_kernel<T, 64>), grid, dim3(256), lds, s, part, S, B, kvp, cross_scratch, cross_map_dev, nq, nkv, Lk,
                                        cross_chunk, scale);
                     hipLaunchKernelGGL((lay::cross_attn_merge_kernel<T, 64>), dim3(mblocks), dim3(256), 0, s, cross_scratch, dattn, B * nq, cross_ranges);
