@@ -573,11 +573,18 @@ __global__ __launch_bounds__(512) void cross_attn_mfma_kernel(const float* __res
     for (int i = tid; i < 16 * D; i += 512) {
         const int h = i / D, c = i % D;
         float a = 0.f;
-        if (h < G) {
-            if (S == 0) a = bf2f(reinterpret_cast<const bf16_t*>(qpart)[(long)b * Hq + (kvh * G + h) * D + c]);
-            for (int s = 0; s < S; ++s) a += qpart[((long)s * M + b) * Hq + (kvh * G + h) * D + c];
+        const int hc = min(h, G - 1);                                 // rows >= G: load a valid address, store zero
+        const long col = (long)(kvh * G + hc) * D + c;
+        if (S == 0) {
+            a = bf2f(reinterpret_cast<const bf16_t*>(qpart)[(long)b * Hq + col]);
+        } else {                                                      // all slab loads in flight together (a `for s < S` loop is one round trip per slab)
+            float p[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) p[s] = qpart[((long)min(s, S - 1) * M + b) * Hq + col];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a += (s < S) ? p[s] : 0.f;
         }
-        qsh[i] = f2bf(a);
+        qsh[i] = f2bf(h < G ? a : 0.f);
     }
     __syncthreads();
     u32x4 qf[NKS];
