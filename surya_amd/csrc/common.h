@@ -160,8 +160,16 @@ struct Tuning {
     int bigtile = 1;         // 256x256 tiles for large bf16 GEMMs
     int bigtile_min_k = 0;   // ... only when K >= this (short-K GEMMs are prologue / epilogue bound: two 128x128 workgroups per CU overlap those)
     int glds = 2;            // LDS stages of the 128x128 direct-to-LDS GEMM (2 or 3)
+    // round 4 (A/B knobs of the decode step's non-GEMM kernels and of the persistent big-tile GEMM; defaults = measured best)
+    int dattn = 4;           // bf16 decode attention: 4 = thread-local prologue (decode_attn_flash2_kernel), 3 = third version
+    int rnorm = 2;           // split-K reduce + residual + RMSNorm: 2 = slab loads sized by the slice count, 1 = round-3 kernel, 3 = one wave per row
+    int ghead = 2;           // greedy head: 2 = registers-only partial reduce + vector bbox head (+ next step's embedding when fused), 1 = round-3 kernel
+    int fuse_embed = 1;      // inner decode steps: the greedy head also writes the next step's embedding + first RMSNorm (no embed launch)
+    int lmhead = 1;          // lm_head (N >= 32768, M <= 256): 1 = one round of 256x320 tiles with the greedy partials taken from the accumulators, 0 = 128x128 tiles
+    int persist = 1;         // 256x256 bf16 GEMMs as a persistent tile loop (next tile's K-tiles in flight during the epilogue)
 };
 inline Tuning& tuning() { static Tuning t; return t; }
+inline int& tuning_epoch() { static int e = 0; return e; }   // bumped by surya_set_tuning whenever a knob changes value
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember, per device, the largest size
 // already granted, and raise it when a later launch of the same kernel needs more (kernels whose dynamic LDS depends on the

@@ -509,6 +509,302 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
     SA_DA_STAMP(8)
 }
 
+// Fourth version (bf16), round 4: the third version's phase timers at the bench's context (60-110 cached keys = ONE tile) showed a kernel
+// that is all prologue: 32 scalar 4-byte slab loads per thread, an fp32 round trip of the row through LDS (xrow) with its own barrier
+// before the rotary step, and a barrier in front of the combine records because they aliased the q operand. Here:
+//   * thread t < (G + 2) * D / 8 owns 4 consecutive dims i..i+3 of one head AND their rotate_half partners i + D/2..: two 16-byte loads
+//     per slab, the reduce, the rounding, the rotation and the q / K-new / V-new LDS writes are thread-local -- no xrow, no barrier
+//     between reduce and RoPE;
+//   * the K / V rows appended to the cache are stored to global memory AFTER the barrier that publishes the LDS tile (nothing in this
+//     launch reads them back, so no wave waits for their acknowledgement);
+//   * each wave drops its (max, sum, O) record into its OWN 32 key rows of the K tile (only that wave ever read them), so one barrier
+//     separates the per-wave flash pass from the final combine.
+// Arithmetic (slab order, rounding points, MFMA order, combine) is the third version's; outputs agree to the bit unless hipcc contracts
+// the rotation differently (pinned with explicit fma / mul below).
+template <int D, int MAXG>
+__global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __restrict__ qkv_part, int S, const bf16_t* __restrict__ qkv_bias,
+                                                                 bf16_t* __restrict__ out, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                                 const int* __restrict__ active_slots, const int* __restrict__ row_len,
+                                                                 const float2* __restrict__ rope_cs, int nq, int nkv, int Tmax,
+                                                                 float scale, uint8_t* __restrict__ out8 = nullptr,
+                                                                 uint8_t* __restrict__ sout = nullptr, int srows = 0) {
+    typedef bf16_t T;
+    constexpr int CPR = D / 8;                               // 16-byte chunks per K/V row
+    constexpr int ROWB = D * 2;                              // bytes per K/V row
+    constexpr int KT = 128;                                  // keys per LDS tile: 32 per wave
+    constexpr int RPI = 1024 / ROWB;                         // rows moved by one global_load_lds (64 lanes x 16 B)
+    constexpr int XM = CPR >= 16 ? 15 : CPR - 1;             // XOR mask of the K-tile chunk swizzle
+    constexpr int NKK = D / 16, NDB = (D + 31) / 32;
+    constexpr int CW = D + 4;                                // floats per head record of the final combine: O[D], max, sum
+    constexpr int IPH = D / 8;                               // prologue items (threads) per head: 4 dims + their 4 partners each
+    static_assert(D % 32 == 0 && D <= 128 && MAXG <= 32 && 1024 % ROWB == 0, "geometry");
+    static_assert((MAXG + 2) * IPH <= 256 && MAXG * CW * 4 <= 32 * ROWB, "one prologue pass; a wave's records fit its own K rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;                                // [KT][ROWB], chunk c of row r at c ^ (r & XM)
+    unsigned char* Vs = Ks + KT * ROWB;                      // [KT][ROWB], linear
+    unsigned char* qT = Vs + KT * ROWB;                      // [32][ROWB] q heads (rows >= G are zero), chunk-swizzled like K
+
+    SA_DA_STAMP(0)
+    const int G = nq / nkv;
+    const int a = blockIdx.x, kvh = blockIdx.y;
+    const int slot = active_slots[a];
+    const int len = row_len[a];                              // cached tokens; the new token sits at index len
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = len + 1;
+    const unsigned char* kb = reinterpret_cast<const unsigned char*>(kc + ((long)slot * nkv + kvh) * Tmax * D);
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vc + ((long)slot * nkv + kvh) * Tmax * D);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // Rows of tile `base` that a 16-key MFMA step can touch get finite data (cached rows, clamped duplicates past len) -- EXCEPT row
+    // `len` itself: the lanes that would fill it are masked off (LDS-DMA honours EXEC), so the new token's K / V rows, which this
+    // workgroup writes with ordinary LDS stores, never race with a late-landing duplicate and need no barrier of their own.
+    auto issue_tile = [&](int base) {
+        const int rows = min(KT, (total - base + 15) & ~15);
+        const int ngroups = (rows + RPI - 1) / RPI;
+        for (int g = wave; g < ngroups; g += 4) {
+            const int r = g * RPI + lane / CPR, pc = lane % CPR;
+            const long j = min(base + r, max(len - 1, 0));
+            if (base + r != len) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(kb + j * ROWB + ((pc ^ (r & XM)) << 4)), (lptr_t)(Ks + g * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(vb + j * ROWB + (pc << 4)), (lptr_t)(Vs + g * 1024), 16, 0, 0);
+            }
+        }
+    };
+    issue_tile(0);
+    SA_DA_STAMP(1)
+
+    // ---- prologue: this row's q / k / v = bias + sum of the split-K slabs, rounded; RoPE; all thread-local
+    const int qkv_dim = (nq + 2 * nkv) * D;
+    const int Mrows = gridDim.x;
+    constexpr int half = D / 2;
+    const int n_items = (G + 2) * IPH;
+    const int item = min(tid, n_items - 1);                   // idle threads shadow the last item (no stores)
+    const bool on = tid < n_items;
+    const int hh = item / IPH, i0 = (item % IPH) * 4;         // head (q heads, then k, then v) and first dim (< D/2)
+    const int col = (hh < G ? (kvh * G + hh) * D : (hh == G ? (nq + kvh) * D : (nq + nkv + kvh) * D)) + i0;
+    const float* prow = qkv_part + (long)a * qkv_dim + col;
+    const long sstride = (long)Mrows * qkv_dim;
+    f32x4 plo[8], phi[8];
+    // slab loads: unconditional, slab index clamped (duplicates hit L1); only as many as the launch can need
+    const int SL = S <= 2 ? 2 : (S <= 4 ? 4 : 8);
+    if (SL == 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            plo[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride);
+            phi[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride + half);
+        }
+#pragma unroll
+        for (int s = 2; s < 8; ++s) { plo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; phi[s] = plo[s]; }
+    } else if (SL == 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            plo[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride);
+            phi[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride + half);
+        }
+#pragma unroll
+        for (int s = 4; s < 8; ++s) { plo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; phi[s] = plo[s]; }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            plo[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride);
+            phi[s] = *reinterpret_cast<const f32x4*>(prow + min(s, S - 1) * sstride + half);
+        }
+    }
+    float blo[4], bhi[4];
+    load4(qkv_bias + col, blo);
+    load4(qkv_bias + col + half, bhi);
+    const float4 csA = *reinterpret_cast<const float4*>(rope_cs + (long)len * half + i0);        // (cos, sin) of dims i0, i0 + 1
+    const float4 csB = *reinterpret_cast<const float4*>(rope_cs + (long)len * half + i0 + 2);    // dims i0 + 2, i0 + 3
+    // zero the padding heads of the q operand: whole rows, 16 bytes per store
+    for (int i = tid; i < (32 - G) * CPR; i += 256)
+        *reinterpret_cast<u32x4*>(qT + G * ROWB + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    SA_DA_STAMP(2)
+    float xlo[4], xhi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float vl = blo[e], vh = bhi[e];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bool use = s < S;
+            vl += use ? plo[s][e] : 0.f;
+            vh += use ? phi[s][e] : 0.f;
+        }
+        xlo[e] = Ty<T>::rnd(vl); xhi[e] = Ty<T>::rnd(vh);
+    }
+    const float csn[4] = {csA.x, csA.z, csB.x, csB.z}, snn[4] = {csA.y, csA.w, csB.y, csB.w};
+    float ylo[4], yhi[4];                                     // what goes to the q operand / the cache rows (v: unrotated)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // decoder/__init__.py:60-84 with cos / sin rounded to the storage dtype (the table); one rounded product, one fused multiply-add
+        const float r1 = Ty<T>::rnd(__fmaf_rn(xlo[e], csn[e], -__fmul_rn(xhi[e], snn[e])));
+        const float r2 = Ty<T>::rnd(__fmaf_rn(xhi[e], csn[e], __fmul_rn(xlo[e], snn[e])));
+        ylo[e] = hh <= G ? r1 : xlo[e];
+        yhi[e] = hh <= G ? r2 : xhi[e];
+    }
+    const int new_tile = len / KT, new_row = len % KT;       // where the new token's row lives among the tiles
+    auto lds_put4 = [&](unsigned char* rowp, int swz, int e0, const float (&v)[4], float mul) {   // 4 consecutive elements from e0 (multiple of 4)
+        const int c = e0 / 8, w = e0 % 8;
+        store4(reinterpret_cast<T*>(rowp + ((c ^ swz) << 4)) + w, v[0] * mul, v[1] * mul, v[2] * mul, v[3] * mul);
+    };
+    auto put_new_rows = [&]() {                               // K-new (rotated) and V-new rows of the tile that holds index len
+        if (on && hh == G) {
+            lds_put4(Ks + new_row * ROWB, new_row & XM, i0, ylo, 1.f);
+            lds_put4(Ks + new_row * ROWB, new_row & XM, i0 + half, yhi, 1.f);
+        } else if (on && hh == G + 1) {
+            lds_put4(Vs + new_row * ROWB, 0, i0, ylo, 1.f);
+            lds_put4(Vs + new_row * ROWB, 0, i0 + half, yhi, 1.f);
+        }
+    };
+    if (on && hh < G) {
+        lds_put4(qT + hh * ROWB, hh & XM, i0, ylo, scale);
+        lds_put4(qT + hh * ROWB, hh & XM, i0 + half, yhi, scale);
+    }
+    if (new_tile == 0) put_new_rows();
+    SA_DA_STAMP(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA rows of tile 0 (not tracked by the compiler)
+    __syncthreads();
+    // append to the cache: after the barrier, so no wave's vmcnt(0) above waits for a store acknowledgement
+    if (on && hh >= G) {
+        T* dst = (hh == G ? kc : vc) + (((long)slot * nkv + kvh) * Tmax + len) * D;
+        store4(dst + i0, ylo[0], ylo[1], ylo[2], ylo[3]);
+        store4(dst + i0 + half, yhi[0], yhi[1], yhi[2], yhi[3]);
+    }
+    SA_DA_STAMP(4)
+
+    // ---- per-wave flash attention over keys [32 * wave, 32 * wave + 32) of every tile
+    const int hl = lane & 31, h = lane >> 5;                 // this lane's head (column of S^T) and K-half
+    u32x4 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+        qf[kk] = *reinterpret_cast<const u32x4*>(qT + hl * ROWB + (((kk * 2 + h) ^ (hl & XM)) << 4));
+    f32x16 oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int tr_off = (((lane & 15) >> 2) + h * 4) * D + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;   // elements, see attn_mfma.h
+    const int n_tiles = (total + KT - 1) / KT;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int base = t * KT, nk = min(KT, total - base);
+        if (t > 0) {
+            __syncthreads();                                 // every wave is done with the previous tile
+            issue_tile(base);
+            if (new_tile == t) put_new_rows();               // the new token's rows fall into this tile (the DMA above skips row `len`)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const int k0 = wave * 32;
+        if (k0 < nk) {                                       // wave-uniform
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const int krow = k0 + hl;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * ROWB + (((kk * 2 + h) ^ (krow & XM)) << 4));
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sacc, 0, 0, 0);
+            }
+            float bm = -INFINITY;                            // register 4g + r = key k0 + 8g + 4h + r
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = (k0 + g * 8 + h * 4 + r < nk) ? sacc[4 * g + r] : -INFINITY;
+                    sacc[4 * g + r] = sv;
+                    bm = fmaxf(bm, sv);
+                }
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));          // finite: key k0 is visible
+            const float mnew = fmaxf(mrun, bm);
+            const float alpha = __expf(mrun - mnew);         // exp(-inf) = 0 on the first tile
+            mrun = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(sacc[r] - mnew);
+                sacc[r] = pv;
+                psum += pv;
+            }
+            lrun = lrun * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (k0 + st * 16 < nk) {                     // wave-uniform; rows of a started 16-key step hold finite data
+                    u32x4 pf;
+                    pf[0] = pack2(sacc[8 * st + 0], sacc[8 * st + 1]);
+                    pf[1] = pack2(sacc[8 * st + 2], sacc[8 * st + 3]);
+                    pf[2] = pack2(sacc[8 * st + 4], sacc[8 * st + 5]);
+                    pf[3] = pack2(sacc[8 * st + 6], sacc[8 * st + 7]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vs) + (k0 + st * 16) * D + db * 32 + tr_off;
+                        typedef short s16x4_t __attribute__((ext_vector_type(4)));
+                        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * D));
+                        const s16x8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf),
+                                                                           oacc[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    SA_DA_STAMP(5)
+    // ---- split-KV combine of the four waves: records live in each wave's own K rows (rows 32w..32w+31: read by wave w only, and the
+    // last tile's LDS-DMA has landed), so no barrier is needed before they are written
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+    if (hl < G) {
+        float* rec = reinterpret_cast<float*>(Ks + wave * 32 * ROWB) + hl * CW;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(rec + db * 32 + g * 8 + h * 4) =
+                    make_float4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+        if (h == 0) { rec[D] = mrun; rec[D + 1] = ltot; }
+    }
+    __syncthreads();
+    SA_DA_STAMP(6)
+    if (tid < G * (D / 4)) {
+        const int oh = tid / (D / 4), od = (tid % (D / 4)) * 4;
+        const float* r0 = reinterpret_cast<const float*>(Ks) + oh * CW;
+        constexpr int WSTR = 32 * ROWB / 4;                  // floats between the records of consecutive waves
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mx = fmaxf(mx, r0[w * WSTR + D]);
+        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* rec = r0 + w * WSTR;
+            const float e = (rec[D] == -INFINITY) ? 0.f : __expf(rec[D] - mx);       // waves past the context hold (-inf, 0, 0)
+            const float4 o4 = *reinterpret_cast<const float4*>(rec + od);
+            num[0] += e * o4.x; num[1] += e * o4.y; num[2] += e * o4.z; num[3] += e * o4.w;
+            den += e * rec[D + 1];
+        }
+        const float inv = 1.0f / den;
+        const long o_off = (long)a * nq * D + (long)(kvh * G + oh) * D + od;
+        store4(out + o_off, num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv);
+        if (out8) {   // MXFP8 copy for the fp8 o-projection (gemm_mx.h): 8 adjacent threads own one 32-wide block of a head
+            const float q[4] = {Ty<T>::rnd(num[0] * inv), Ty<T>::rnd(num[1] * inv), Ty<T>::rnd(num[2] * inv), Ty<T>::rnd(num[3] * inv)};
+            int e8;
+            const uint32_t pk = mx_quant4_oct(q, e8);
+            *reinterpret_cast<uint32_t*>(out8 + o_off) = pk;
+            const int colo = (kvh * G + oh) * D + od;            // K-tile-major scales (gemm_mx.h): [col / 128][srows][4]
+            if ((tid & 7) == 0) sout[((long)(colo >> 7) * srows + a) * 4 + ((colo >> 5) & 3)] = (uint8_t)e8;
+        }
+    }
+    SA_DA_STAMP(7)
+    SA_DA_STAMP(8)
+}
+
+template <int D, int MAXG>
+static inline size_t decode_attn_flash2_lds() { return (size_t)2 * 128 * D * 2 + (size_t)32 * D * 2 + 64; }
+
 template <int D, int MAXG>
 static inline size_t decode_attn_flash_lds() {
     const size_t q_x = (size_t)32 * D * 2 + (size_t)(MAXG + 2) * D * 4, comb = (size_t)4 * MAXG * (D + 4) * 4;

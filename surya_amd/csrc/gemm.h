@@ -87,7 +87,7 @@ template <> struct Mfma<float> {
 };
 
 // BM x BN output tile per workgroup of WM x WN waves.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false, int WAUX = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> p) {
     static_assert(!CONV || (GLDS == 2 && !SPLIT), "the convolution gather exists for the 2-stage direct-to-LDS loop");
     constexpr int NT = 64 * WM * WN;
@@ -181,6 +181,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #ifndef SA_INTERLEAVE
 #define SA_INTERLEAVE 1
 #endif
+    // Accumulator-heavy tiles (the 256x320 lm_head tile: 160 accumulator registers per lane of 256) cannot afford two fragment sets:
+    // one set, hipcc schedules; the second wave of each SIMD covers the fragment-read latency.
+    constexpr bool LEAN = FM * FN * 16 > 128;
+#define SA_COMPUTE_LEAN(CURP)                              \
+    {                                                      \
+        const unsigned char* cur_ = (CURP);                \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) { \
+            u32x4 xf_[FM], wf_[FN];                        \
+            SA_FRAGS(xf_, wf_, kk_);                       \
+            __builtin_amdgcn_sched_barrier(0);             \
+            SA_MFMAS(xf_, wf_);                            \
+            __builtin_amdgcn_sched_barrier(0);             \
+        }                                                  \
+    }
 #if SA_INTERLEAVE
     // The LDS fragment reads of step kk+1 are placed BETWEEN the MFMAs of step kk (one read per MFMA) instead of in a burst
     // ahead of them: sched_group_barrier(mask, count, id), mask 0x100 = DS read, 0x8 = MFMA. +2-5 % on every shape over the
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     }                                                                                                   \
     if constexpr (FM * FN > FM + FN) __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - FM - FN, 0); \
     if constexpr (FM + FN > FM * FN) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN - FM * FN, 0);
-#define SA_COMPUTE(CURP)                                   \
+#define SA_COMPUTE_FULL(CURP)                              \
     {                                                      \
         const unsigned char* cur_ = (CURP);                \
         u32x4 xfa[FM], wfa[FN], xfb[FM], wfb[FN];          \
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0); \
     }
 #else
-#define SA_COMPUTE(CURP)                                   \
+#define SA_COMPUTE_FULL(CURP)                              \
     {                                                      \
         const unsigned char* cur_ = (CURP);                \
         u32x4 xfa[FM], wfa[FN], xfb[FM], wfb[FN];          \
@@ -231,6 +245,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         SA_MFMAS(xfb, wfb);                                \
     }
 #endif
+#define SA_COMPUTE(CURP)                                   \
+    {                                                      \
+        if constexpr (LEAN) SA_COMPUTE_LEAN(CURP)          \
+        else SA_COMPUTE_FULL(CURP)                         \
+    }
     if constexpr (GLDS > 0) {
         // Direct-to-LDS staging (global_load_lds_dwordx4): one instruction moves 64 lanes x 16 bytes = 8 consecutive
         // 128-byte tile rows from global memory into LDS at (wave-uniform M0 base) + lane * 16, with no staging VGPRs and
@@ -271,7 +290,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #ifndef SA_NT_W
 #define SA_NT_W 0
 #endif
-        constexpr int W_AUX = (SA_NT_W && (SPLIT || BM * BN <= 128 * 64)) ? 2 : 0;
+        // WAUX = 2 (template parameter): non-temporal weight stream for tiles whose W rows are read by exactly ONE workgroup (the
+        // 256x320 lm_head tile spans all rows of the batch, so nothing shares its weight slab through L2).
+        constexpr int W_AUX = WAUX ? WAUX : ((SA_NT_W && (SPLIT || BM * BN <= 128 * 64)) ? 2 : 0);
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
 #define SA_ISSUE(BUFOFF, KT)                                                                                            \
@@ -327,7 +348,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                 __builtin_amdgcn_sched_barrier(0);
                 SA_LANDED();
             }
-            if (nk & 1) SA_COMPUTE(smem);
+            if constexpr (!LEAN) {                      // (the accumulator-heavy tiles are launched for even K-tile counts only)
+                if (nk & 1) SA_COMPUTE(smem);
+            }
 #undef SA_LANDED
         } else {
         // GLDS-stage ring: tiles kt .. kt+GLDS-2 are in flight or resident while tile kt is multiplied. Per iteration:
@@ -431,6 +454,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #undef SA_STASH
     }
 #undef SA_COMPUTE
+#undef SA_COMPUTE_FULL
+#undef SA_COMPUTE_LEAN
 #undef SA_FRAGS
 #undef SA_MFMAS
 
@@ -444,12 +469,96 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     // loop-`continue` conditions: hipcc then branches around every load and waits vmcnt(0) behind each -- 32 dependent L2 round
     // trips for the bias of a 256x256 tile and 16 for its residual (r03 ISA), ~15-20 us of a ~50 us tile at K = 1280.
     __syncthreads();
+    // Greedy-head partials straight from the accumulators, for tiles whose fp32 image does not fit LDS (the 256x320 lm_head tile):
+    // a lane holds, for each of its FM rows, FN x 16 of the wave's columns in ascending order (the other FN x 16 sit in lane ^ 32),
+    // so the row's (max, first argmax, sum exp) over the wave's columns is a serial pass + one exchange; the WN waves of a row meet
+    // in 16 bytes of LDS each.
+    constexpr bool ARGMAX_DIRECT = (EPI == EPI_ARGMAX) && ((size_t)BM * BN * 4 > 160 * 1024);
+    if constexpr (ARGMAX_DIRECT) {
+        static_assert(!SPLIT && std::is_same<TO, float>::value && NT >= BM, "direct argmax epilogue");
+        const bool with_bias = p.bias != nullptr;                             // wave-uniform
+        float4* rec = reinterpret_cast<float4*>(smem);                        // [BM][WN] per-wave records of a row
+        float* bias_s = reinterpret_cast<float*>(smem + (size_t)BM * WN * 16);   // [BN] the tile's bias in fp32 (LDS: 20 float4 per lane would not fit beside the accumulators)
+        if (tid < BN / 4) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (with_bias) load4(p.bias + min(n0 + tid * 4, p.N - 4), b);
+            *reinterpret_cast<float4*>(bias_s + tid * 4) = make_float4(b[0], b[1], b[2], b[3]);
+        }
+        __syncthreads();
+        // columns of this lane: base + off with off = j * 32 + g * 8 + r a compile-time constant; off < lim are inside N
+        const int base = n0 + wn * WTN + (lane >> 5) * 4, lim = p.N - base;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + wn * WTN + j * 32 + g * 8 + (lane >> 5) * 4);
+                const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)          // masked once, here: every later pass sees -inf past N
+                        acc[j][i][4 * g + r] = (j * 32 + g * 8 + r < lim) ? acc[j][i][4 * g + r] + b[r] : -INFINITY;
+            }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);                                    // one row block at a time (register pressure)
+            float best = -INFINITY;
+            int bo = 0;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[j][i][4 * g + r];
+                        if (v > best) { best = v; bo = j * 32 + g * 8 + r; }       // strict >: first maximum wins (offsets ascend)
+                    }
+            int bi = (best == -INFINITY) ? 0x7fffffff : base + bo;
+            {
+                const float ob = __shfl_xor(best, 32, 64);
+                const int oi = __shfl_xor(bi, 32, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const float bsafe = (best == -INFINITY) ? 0.f : best;                 // exp(-inf - 0) = 0 for a row block wholly past N
+            float se = 0.f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (std::is_same<TI, float>::value) se += expf(acc[j][i][4 * g + r] - bsafe);      // reference mode
+                        else se += __expf(acc[j][i][4 * g + r] - bsafe);
+                    }
+            se += __shfl_xor(se, 32, 64);
+            if (lane < 32) rec[(wm * WTM + i * 32 + lane) * WN + wn] = make_float4(best, __int_as_float(bi), se, 0.f);
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                const float4 r4 = rec[tid * WN + w];
+                const int ri = __float_as_int(r4.y);
+                if (r4.x > best || (r4.x == best && ri < bi)) { best = r4.x; bi = ri; }
+            }
+            float se = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                const float4 r4 = rec[tid * WN + w];
+                se += r4.z * expf(r4.x - best);                                      // a wave past N holds (-inf, -, 0): contributes 0
+            }
+            p.amax[(long)(m0 + tid) * tiles_n + tile_n] = make_float4(best, __int_as_float(bi), se, 0.f);
+        }
+        return;
+    }
     constexpr bool GLU = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT;     // gated epilogues halve the output width
     constexpr int OW = GLU ? BN / 2 : BN;                                    // output columns of this tile
     using TS = typename std::conditional<SPLIT, float, TO>::type;            // staged / stored element type
     constexpr int ROWB = OW * (int)sizeof(TS), CPR = ROWB / 16;              // bytes and 16-byte chunks per tile row
     constexpr int XM = CPR >= 8 ? 7 : CPR - 1;                               // chunk XOR mask (conflict-free b128 writes)
-    static_assert(BM * ROWB <= 160 * 1024 && CPR >= 1, "output tile must fit LDS (launcher sizes it)");
+    static_assert(ARGMAX_DIRECT || (BM * ROWB <= 160 * 1024 && CPR >= 1), "output tile must fit LDS (launcher sizes it)");
     const bool has_bias = !SPLIT && p.bias != nullptr;                       // wave-uniform
     // the lane's 4 bias columns of (j, g), the same for every i; kept as loaded (packed bf16: 2 registers) until they are used
     using BiasRaw = typename std::conditional<std::is_same<TI, float>::value, float4, uint2>::type;
@@ -637,7 +746,7 @@ inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 // profiler buckets: 0 = 128x128 (large GEMMs), 1 = tall 256-row tiles (decode regime), 2 = small tiles
 inline int gemm_cfg_id(int BM, int BN) { return (BM >= 128 && BN >= 128) ? 0 : (BM == 256 ? 1 : 2); }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int EPI, bool SPLIT = false, int GLDS = 0, bool CONV = false, int WAUX = 0>
 static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     int tiles = SPLIT ? cdiv(cdiv(a.N, BN) * a.splitk, 8) * 8 * cdiv(a.M, BM) : cdiv(a.M, BM) * cdiv(a.N, BN);
     a.bn_used = BN;
@@ -654,8 +763,9 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr size_t out_w = ((EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT) ? BN / 2 : BN;
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
-    constexpr size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;     // staging buffers are reused for the output tile
-    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS, CONV>;
+    constexpr bool argmax_direct = (EPI == EPI_ARGMAX) && ((size_t)BM * BN * 4 > 160 * 1024);     // partials straight from the accumulators
+    constexpr size_t lds = (argmax_direct || stage_bytes > out_bytes) ? stage_bytes : out_bytes;   // staging buffers are reused for the output tile
+    auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS, CONV, WAUX>;
     static AttrOnce attr;           // >64 KiB dynamic LDS needs the opt-in attribute; harmless below
     attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
@@ -691,6 +801,15 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         if constexpr (EPI == EPI_ARGMAX) {
             // the fused lm_head hands per-column-block (max, sum-exp) partials to greedy_head: keep the block width a function
             // of N alone so a line's score is summed in the same groups whatever the number of active rows
+            // Round 4: lm_head-sized N runs as ONE round of 256-row x 320-column tiles (81920 = 256 x 320: a tile per CU). The 128x128
+            // tiling asked L2 for 839 MB to stream 210 MB of weights (each X row block re-read by 640 column tiles, each W tile by 2 row
+            // tiles) -- 110 us in situ at the ~15 TB/s L2->LDS ceiling plus cold HBM; this tile asks for 378 MB. Fewer active rows
+            // still take the tile (clamped rows): the column grouping, and with it a line's score bits, must not depend on M.
+            if (a.N >= 64 * 512 && tuning().lmhead && (a.K / Ty<TI>::KE) % 2 == 0 && a.N % 4 == 0) {
+                if constexpr (sizeof(TI) == 2)
+                    if (tuning().lmhead == 2) return launch_gemm_cfg<TI, TO, 256, 320, 4, 2, EPI, false, 2, false, 2>(a, s);   // non-temporal W
+                return launch_gemm_cfg<TI, TO, 256, 320, 4, 2, EPI, false, 2>(a, s);
+            }
             if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
             return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
         }

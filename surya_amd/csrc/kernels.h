@@ -287,7 +287,7 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 // loads are in flight together and the normalised row is written from registers. (The first version ran 256 threads over
 // H = 1280 -- a second serial trip for the first wave -- and re-read its own stores for the norm: 4.9 us per launch, 1504
 // launches per recognition step.)
-template <typename T>
+template <typename T, int SL = 8>      // SL: slabs requested per thread (>= S; the round-3 kernel always asked for 8, clamped duplicates included)
 __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float* __restrict__ part, int S, int M, T* __restrict__ x,
                                                                     const T* __restrict__ bias, const T* __restrict__ w,
                                                                     T* __restrict__ y, int H, float eps,
@@ -307,12 +307,12 @@ __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float*
         load4(bias + cc, b);
         v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
     }
-    f32x4 p4[8];                                   // slabs in flight
+    f32x4 p4[SL];                                  // slabs in flight
 #pragma unroll
-    for (int s = 0; s < 8; ++s)                    // clamped slab index: unconditional loads, masked below
+    for (int s = 0; s < SL; ++s)                   // clamped slab index: unconditional loads, masked below
         p4[s] = *reinterpret_cast<const f32x4*>(part + ((long)min(s, S - 1) * M + row) * H + cc);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < SL; ++s) {
         const float on = (s < S) ? 1.f : 0.f;
         v[0] += on * p4[s][0]; v[1] += on * p4[s][1]; v[2] += on * p4[s][2]; v[3] += on * p4[s][3];
     }
@@ -471,5 +471,171 @@ __global__ __launch_bounds__(256) void greedy_head_kernel(const float* __restric
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the decode step's two small per-row kernels, rebuilt around "every load in flight before the first wait".
+//
+// embed_norm_row: x = table row, y = w * T(x * rsqrt(mean(x^2) + eps)) for ONE row by a whole workgroup of NT threads, each owning
+// up to two 4-element chunks. Used by the standalone embedding kernel (first step of a decode call) AND by the greedy head's fused
+// tail (inner steps), so both produce the same bits: the sum of squares is reduced in the same tree in both places.
+template <typename T, int NT>
+__device__ __forceinline__ void embed_norm_row(const T* __restrict__ src, T* __restrict__ xr, const T* __restrict__ w, T* __restrict__ yr,
+                                               int H, float eps, float* red, uint8_t* __restrict__ y8, uint8_t* __restrict__ sy, int srows,
+                                               int row) {
+    const int tid = threadIdx.x;
+    float v[2][4], g[2][4];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = (u * NT + tid) * 4;
+        ok[u] = c < H;
+        const int cc = ok[u] ? c : 0;
+        load4(src + cc, v[u]);
+        load4(w + cc, g[u]);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (ok[u]) store4(xr + (u * NT + tid) * 4, v[u][0], v[u][1], v[u][2], v[u][3]);
+        ss += ok[u] ? (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]) : 0.f;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) tot += red[i];
+    const float rstd = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = (u * NT + tid) * 4;
+        const float o[4] = {g[u][0] * Ty<T>::rnd(v[u][0] * rstd), g[u][1] * Ty<T>::rnd(v[u][1] * rstd), g[u][2] * Ty<T>::rnd(v[u][2] * rstd),
+                            g[u][3] * Ty<T>::rnd(v[u][3] * rstd)};
+        if (ok[u]) store4(yr + c, o[0], o[1], o[2], o[3]);
+        if (y8) {   // MXFP8 copy (H % 32 == 0: an aligned group of 8 lanes is inside the row or outside it)
+            const float q[4] = {Ty<T>::rnd(o[0]), Ty<T>::rnd(o[1]), Ty<T>::rnd(o[2]), Ty<T>::rnd(o[3])};
+            int e8;
+            const uint32_t pk = mx_quant4_oct(q, e8);
+            if (ok[u]) {
+                *reinterpret_cast<uint32_t*>(y8 + (long)row * H + c) = pk;
+                if ((tid & 7) == 0) sy[((long)(c >> 7) * srows + row) * 4 + ((c >> 5) & 3)] = (uint8_t)e8;
+            }
+        }
+    }
+}
+
+constexpr int SA_HEAD_THREADS = 384;      // 6 waves: one per bbox output; 2 x 384 x 4 >= H for the fused embedding
+
+// First step of a decode call: x[a] = table[next_token[slot]], y[a] = norm(x[a]), row_len[a] = context length of the step.
+template <typename T>
+__global__ __launch_bounds__(SA_HEAD_THREADS) void embed_slots_norm2_kernel(const T* __restrict__ table, const int* __restrict__ next_token,
+                                                                            const int* __restrict__ active_slots, const int* __restrict__ kv_len,
+                                                                            int Tmax, int* __restrict__ row_len, T* __restrict__ x,
+                                                                            const T* __restrict__ w, T* __restrict__ y, int H, float eps,
+                                                                            uint8_t* __restrict__ y8, uint8_t* __restrict__ sy, int srows) {
+    __shared__ float red[SA_HEAD_THREADS / 64];
+    const int a = blockIdx.x;
+    const int slot = active_slots[a];
+    if (threadIdx.x == 0) row_len[a] = min(kv_len[slot], Tmax - 1);
+    embed_norm_row<T, SA_HEAD_THREADS>(table + (long)next_token[slot] * H, x + (long)a * H, w, y + (long)a * H, H, eps, red, y8, sy, srows, a);
+}
+
+// Greedy head on the lm_head GEMM's per-tile partials (greedy_head_kernel<T, true> above states the reduction). Differences:
+//   * a row's partials (<= 4 per thread) and the operands of the six bbox dot products (one wave each, 16-byte loads) are requested
+//     before anything is waited for, and the partials stay in registers for the second pass (the first version walked the partial
+//     row twice and the hidden row 2 bytes at a time in two serial rounds: 19.5 us per launch for ~25 KB of operands);
+//   * with `table` set, the workgroup continues with the NEXT step's embedding + first RMSNorm of the token it just chose (the
+//     embed launch of every inner decode step disappears; row r of x / y is this row's slot because row_slot == the active list).
+template <typename T>
+__global__ __launch_bounds__(SA_HEAD_THREADS) void greedy_head2_kernel(const float4* __restrict__ part, int tiles_n, const T* __restrict__ hidden,
+                                                                       int H, const T* __restrict__ wb, const T* __restrict__ bb,
+                                                                       const int* __restrict__ row_slot, int eos_id, int pad_id, float bbox_size,
+                                                                       int* __restrict__ out_token, float* __restrict__ out_score,
+                                                                       int* __restrict__ out_bbox, int* __restrict__ next_token,
+                                                                       int* __restrict__ kv_len, int len_inc,
+                                                                       const T* __restrict__ table, const T* __restrict__ wnorm, T* __restrict__ x,
+                                                                       T* __restrict__ y, int* __restrict__ row_len, int Tmax, float eps,
+                                                                       uint8_t* __restrict__ y8, uint8_t* __restrict__ sy, int srows) {
+    constexpr int NT = SA_HEAD_THREADS, NW = NT / 64, NP = 4, V = Ty<T>::V16, NB = 32 / V;   // NB x 64 x V = 2048 >= H
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float smax[NW], ssum[NW], red[NW];
+    __shared__ int sidx[NW];
+    const float4* lr = part + (long)r * tiles_n;
+    float4 pv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) pv[k] = lr[min(tid + k * NT, tiles_n - 1)];
+    // bbox head operands of output `wave`: NB x 16 bytes of the hidden row and of the weight row per lane (H <= 64 * V * NB)
+    uint4 hv[NB], wv[NB];
+    const T* hr = hidden + (long)r * H;
+    const T* wr = wb + (long)wave * H;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int c = (u * 64 + lane) * V, cc = c < H ? c : 0;
+        hv[u] = *reinterpret_cast<const uint4*>(hr + cc);
+        wv[u] = *reinterpret_cast<const uint4*>(wr + cc);
+    }
+    const int slot = row_slot[r];
+    const int klen = kv_len[slot];
+    const float bias_o = Ty<T>::ld(bb + wave);
+
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int vi = __float_as_int(pv[k].y);
+        if (tid + k * NT < tiles_n && (pv[k].x > best || (pv[k].x == best && vi < bi))) { best = pv[k].x; bi = vi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { smax[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    best = smax[0]; bi = sidx[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+        if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+        if (tid + k * NT < tiles_n) se += pv[k].z * expf(pv[k].x - best);
+    se = wave_sum(se);
+    if (lane == 0) ssum[wave] = se;
+    // bbox dot product of this wave's output while the sums settle
+    float d = 0.f;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        float hf[V], wf[V];
+        unpack16(hv[u], hf, (T*)nullptr);
+        unpack16(wv[u], wf, (T*)nullptr);
+        float du = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) du += hf[i] * wf[i];
+        d += ((u * 64 + lane) * V < H) ? du : 0.f;
+    }
+    d = wave_sum(d);
+    __syncthreads();
+    const bool done = (bi == eos_id) || (bi == pad_id);
+    const int tok_next = done ? pad_id : bi;
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += ssum[w];
+        out_token[slot] = bi;
+        out_score[slot] = done ? 0.f : 1.0f / tot;
+        next_token[slot] = tok_next;
+        kv_len[slot] = klen + len_inc;
+        if (table) row_len[r] = min(klen + len_inc, Tmax - 1);
+    }
+    if (lane == 0 && wave < 6) {
+        const float lin = Ty<T>::rnd(d + bias_o);
+        const float sg = Ty<T>::rnd(1.0f / (1.0f + expf(-lin)));
+        out_bbox[slot * 6 + wave] = (int)(sg * bbox_size);
+    }
+    if (table) embed_norm_row<T, NT>(table + (long)tok_next * H, x + (long)r * H, wnorm, y + (long)r * H, H, eps, red, y8, sy, srows, r);
+}
+
 
 }  // namespace sa

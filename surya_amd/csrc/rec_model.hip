@@ -199,6 +199,7 @@ struct RecModel : RecBase {
     std::map<long, hipGraphExec_t> graphs;
     std::set<long> seen_keys;
     bool use_graph = true;
+    int graph_epoch = 0;                                 // tuning_epoch() the cached graphs were captured under
     // MXFP8 decode weights (surya_rec_set_mx_weights; gemm_mx.h): e4m3 copies + e8m0 block scales of the decoder projections
     // and lm_head, used by the decode steps only (prefill keeps the bf16 weights), and MXFP8 twins of the four decode-step
     // activation buffers, written by the kernels that produce the bf16 ones.
@@ -556,8 +557,13 @@ struct RecModel : RecBase {
                              uint8_t* sy = nullptr) {
         const int threads = cdiv(c.dec_hidden / 4, 64) * 64;         // one 4-element chunk per thread
         if (threads > 1024 || c.dec_hidden % 4) return SA_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(splitk_residual_norm_kernel<T>, dim3(M), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr,
-                           wnorm, y, c.dec_hidden, c.dec_eps, y8, sy, c.max_slots);
+#define SA_RNORM(SL) hipLaunchKernelGGL((splitk_residual_norm_kernel<T, SL>), dim3(M), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr, \
+                                        wnorm, y, c.dec_hidden, c.dec_eps, y8, sy, c.max_slots)
+        // only as many slab loads per thread as the slice count needs (the sums are the same: the extra slabs were masked duplicates)
+        if (tuning().rnorm == 1 || S > 4) SA_RNORM(8);
+        else if (S > 2) SA_RNORM(4);
+        else SA_RNORM(2);
+#undef SA_RNORM
         return (int)hipGetLastError();
     }
     // Activation scale tensors are K-tile-major with max_slots rows per K-tile ([K / 128][max_slots][4]); a row range of the
@@ -573,8 +579,15 @@ struct RecModel : RecBase {
 
     // FP8 KV cache for the decode steps (bf16 model only). Takes effect for lines prefilled AFTER the call: switch while no line
     // is in flight.
+    // Captured decode steps hold launch arguments AND kernel choices: any mode change (fp8 KV cache, MXFP8 weights, a tuning knob)
+    // must drop them, or a replay would run the other attention kernel on a cache the new shapes no longer append to.
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear(); seen_keys.clear();
+    }
     int set_kv_fp8(int on) override {
         if constexpr (!std::is_same<T, bf16_t>::value) return on ? SA_ERR_UNSUPPORTED : SA_OK;
+        if ((on != 0) != kv8) drop_graphs();
         if (!on) { kv8 = false; return SA_OK; }
         const int d = c.dec_head_dim;
         if (d != 128 && d != 64 && d != 32) return SA_ERR_UNSUPPORTED;
@@ -597,7 +610,7 @@ struct RecModel : RecBase {
     // MXFP8 weight table of the decode steps: per layer SA_MX_COUNT pointers, then SA_MX_LM_W, SA_MX_LM_S. bf16 model only.
     int set_mx_weights(const void* const* tbl, int n) override {
         if constexpr (!std::is_same<T, bf16_t>::value) return SA_ERR_UNSUPPORTED;
-        if (!tbl) { mxw.clear(); return SA_OK; }                     // back to the bf16 decode weights
+        if (!tbl) { if (!mxw.empty()) drop_graphs(); mxw.clear(); return SA_OK; }     // back to the bf16 decode weights
         if (n != SA_MX_TOTAL(c.dec_layers)) return SA_ERR_ARG;
         for (int i = 0; i < n; ++i)
             if (!tbl[i]) return SA_ERR_ARG;
@@ -616,8 +629,7 @@ struct RecModel : RecBase {
         }
         mxw.resize(n);
         for (int i = 0; i < n; ++i) mxw[i] = reinterpret_cast<const uint8_t*>(tbl[i]);
-        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);   // captured steps hold the old launch arguments
-        graphs.clear(); seen_keys.clear();
+        drop_graphs();                                                  // captured steps hold the old launch arguments
         return SA_OK;
     }
 
@@ -625,8 +637,20 @@ struct RecModel : RecBase {
     // (r02 ran two halves of the batch on two streams: no gain -- a 128-row launch takes as long as a 256-row one -- removed.)
     struct Half { int r0, M; float* part; hipStream_t s; };
 
+    // The round-4 head / embedding kernels (kernels.h) hold a row's operands in registers: partial tiles, hidden size and the fused
+    // embedding are bounded by their thread geometry; anything larger keeps the round-3 kernels.
+    bool head2_ok() const {
+        return tuning().ghead == 2 && c.dec_hidden <= 2048 && c.dec_hidden % 8 == 0 && (!mx() || c.dec_hidden % 32 == 0);
+    }
     int decode_embed(const Half& h) {
         const int Hd = c.dec_hidden;
+        if (head2_ok()) {
+            hipLaunchKernelGGL(embed_slots_norm2_kernel<T>, dim3(h.M), dim3(SA_HEAD_THREADS), 0, h.s, W(SA_RW_TOK_EMBED), next_token,
+                               active_dev + h.r0, kv_len, c.max_kv_len, row_len + h.r0, dx + (size_t)h.r0 * Hd, WD(0, SA_RD_LN1),
+                               dh + (size_t)h.r0 * Hd, Hd, c.dec_eps, mx() ? dh8 + (size_t)h.r0 * Hd : nullptr,
+                               mx() ? sdh + (size_t)h.r0 * 4 : nullptr, c.max_slots);
+            return (int)hipGetLastError();
+        }
         hipLaunchKernelGGL(embed_slots_norm_kernel<T>, dim3(h.M), dim3(64), 0, h.s, W(SA_RW_TOK_EMBED), next_token, active_dev + h.r0,
                            kv_len, c.max_kv_len, row_len + h.r0, dx + (size_t)h.r0 * Hd, WD(0, SA_RD_LN1), dh + (size_t)h.r0 * Hd, Hd,
                            c.dec_eps, mx() ? dh8 + (size_t)h.r0 * Hd : nullptr, mx() ? sdh + (size_t)h.r0 * 4 : nullptr, c.max_slots);
@@ -673,7 +697,9 @@ struct RecModel : RecBase {
                            c.max_kv_len, scale, ##__VA_ARGS__);                                                             \
     }
 #define SA_DEC_MFMA(DD, GG) SA_DEC_LAUNCH((decode_attn_mfma_kernel<T, DD, GG>), (decode_attn_mfma_lds<T, DD, GG>()))
-#define SA_DEC_FLASH(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), at8, sat, c.max_slots)
+#define SA_DEC_FLASH3(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), at8, sat, c.max_slots)
+#define SA_DEC_FLASH4(DD, GG) SA_DEC_LAUNCH((decode_attn_flash2_kernel<DD, GG>), (decode_attn_flash2_lds<DD, GG>()), at8, sat, c.max_slots)
+#define SA_DEC_FLASH(DD, GG) { if (tuning().dattn == 3) SA_DEC_FLASH3(DD, GG) else SA_DEC_FLASH4(DD, GG) }
         bool launched = false;
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (kv8) {                                       // FP8 KV cache (decode_attn_kv8.h)
@@ -717,6 +743,8 @@ struct RecModel : RecBase {
             else return SA_ERR_UNSUPPORTED;
         }
 #undef SA_DEC_FLASH
+#undef SA_DEC_FLASH3
+#undef SA_DEC_FLASH4
 #undef SA_DEC_MFMA
 #undef SA_DEC_LAUNCH
         if ((rc = (int)hipGetLastError())) return rc;
@@ -741,7 +769,9 @@ struct RecModel : RecBase {
         return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s);
     }
 
-    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s) {
+    // fuse_next: the rows are the active list of a decode call and another step follows -- the head also writes that step's
+    // embedding, first RMSNorm and row_len (decode_eager skips the embed launch).
+    int heads(int rows, const int* d_last_row, const int* d_row_slot, int step, int len_inc, bool normed, hipStream_t s, bool fuse_next = false) {
         const int Hd = c.dec_hidden;
         int rc;
         T* last = dlast;
@@ -765,6 +795,18 @@ struct RecModel : RecBase {
         }
         const int tiles_n = cdiv(c.vocab, bn_used);
         const size_t so = (size_t)step * c.max_slots;
+        last_rows = rows;
+        last_heads_mx = mx() && normed;
+        if (head2_ok() && tiles_n <= 4 * SA_HEAD_THREADS) {
+            const bool fz = fuse_next;
+            hipLaunchKernelGGL((greedy_head2_kernel<T>), dim3(rows), dim3(SA_HEAD_THREADS), 0, s, reinterpret_cast<const float4*>(am), tiles_n,
+                               last, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id, c.pad_token_id, (float)c.bbox_size,
+                               out_token + so, out_score + so, out_bbox + so * 6, next_token, kv_len, len_inc,
+                               fz ? W(SA_RW_TOK_EMBED) : (const T*)nullptr, WD(0, SA_RD_LN1), dx, dh, row_len, c.max_kv_len, c.dec_eps,
+                               (fz && mx()) ? dh8 : (uint8_t*)nullptr, (fz && mx()) ? sdh : (uint8_t*)nullptr, c.max_slots);
+            return (int)hipGetLastError();
+        }
+        if (fuse_next) return SA_ERR_STATE;                  // the caller checks can_fuse_embed() first
         hipLaunchKernelGGL((greedy_head_kernel<T, true>), dim3(rows), dim3(256), 0, s, reinterpret_cast<const float*>(am),
                            (long)tiles_n, tiles_n, last, Hd, W(SA_RW_BBOX_W), W(SA_RW_BBOX_B), d_row_slot, c.eos_token_id,
                            c.pad_token_id, (float)c.bbox_size, out_token + so, out_score + so, out_bbox + so * 6, next_token,
@@ -861,14 +903,19 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
+    bool can_fuse_embed() const {       // greedy_head2_kernel's fused tail: two 4-element chunks per thread, lm_head partials in registers
+        return tuning().fuse_embed && head2_ok() && c.dec_hidden <= 2 * 4 * SA_HEAD_THREADS && cdiv(c.vocab, 320) <= 4 * SA_HEAD_THREADS &&
+               cdiv(c.vocab, 64) <= 4 * SA_HEAD_THREADS;
+    }
     int decode_eager(int M, int n_steps, int step0, hipStream_t s) {
         int rc;
         const Half h{0, M, part, s};
+        const bool fuse = can_fuse_embed();
         for (int step = 0; step < n_steps; ++step) {
-            if ((rc = decode_embed(h))) return rc;
+            if ((step == 0 || !fuse) && (rc = decode_embed(h))) return rc;
             for (int l = 0; l < c.dec_layers; ++l)
                 if ((rc = decode_layer(l, h))) return rc;
-            if ((rc = heads(M, nullptr, active_dev, step0 + step, 1, true, s))) return rc;
+            if ((rc = heads(M, nullptr, active_dev, step0 + step, 1, true, s, fuse && step + 1 < n_steps))) return rc;
         }
         return SA_OK;
     }
@@ -910,6 +957,7 @@ struct RecModel : RecBase {
         const int M = n_active;
         if (M == 0 || n_steps == 0) return SA_OK;
         if (!use_graph || !tuning().graph || gemm_profiler().enabled) return decode_eager(M, n_steps, step0, s);
+        if (graph_epoch != tuning_epoch()) { drop_graphs(); graph_epoch = tuning_epoch(); }   // a knob changed since the captures
         const long key = ((long)M * 64 + n_steps) * 64 + step0;
         auto it = graphs.find(key);
         if (it == graphs.end()) {
@@ -1225,7 +1273,9 @@ int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_s
         hipLaunchKernelGGL(kern, grid, block, LDS, s, qkv_part, n_slabs, (const TT*)qkv_bias, (TT*)out, (TT*)kcache, (TT*)vcache, \
                            active_slots, row_len, cs, heads, kv_heads, max_kv_len, scale, ##__VA_ARGS__);                       \
     }
-#define SA_OPD_FLASH(DD, GG) SA_OPD((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+#define SA_OPD_FLASH3(DD, GG) SA_OPD((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+#define SA_OPD_FLASH4(DD, GG) SA_OPD((decode_attn_flash2_kernel<DD, GG>), (decode_attn_flash2_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+#define SA_OPD_FLASH(DD, GG) { if (tuning().dattn == 3) SA_OPD_FLASH3(DD, GG) else SA_OPD_FLASH4(DD, GG) }
 #define SA_OPD_MFMA(DD, GG) SA_OPD((decode_attn_mfma_kernel<float, DD, GG>), (decode_attn_mfma_lds<float, DD, GG>()), float)
     if (dtype == SA_DTYPE_BF16) {          // the dispatch of RecModel::decode_layer
         if (d == 128 && G <= 5) SA_OPD_FLASH(128, 5)
@@ -1243,6 +1293,8 @@ int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_s
         return SA_ERR_UNSUPPORTED;
     }
 #undef SA_OPD_FLASH
+#undef SA_OPD_FLASH3
+#undef SA_OPD_FLASH4
 #undef SA_OPD_MFMA
 #undef SA_OPD
     return (int)hipGetLastError();
@@ -1355,9 +1407,14 @@ int surya_set_tuning(const char* key, int value) {
     Tuning& t = tuning();
     struct { const char* k; int* v; } tab[] = {
         {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
-        {"bigtile", &t.bigtile}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}};
+        {"bigtile", &t.bigtile}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}, {"dattn", &t.dattn}, {"rnorm", &t.rnorm},
+        {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}};
     for (auto& e : tab)
-        if (!strcmp(e.k, key)) { *e.v = value; return SA_OK; }
+        if (!strcmp(e.k, key)) {
+            if (*e.v != value) ++tuning_epoch();        // captured decode graphs are stale (RecModel::decode_steps drops them)
+            *e.v = value;
+            return SA_OK;
+        }
     return SA_ERR_ARG;
 }
 

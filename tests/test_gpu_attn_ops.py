@@ -151,7 +151,7 @@ def _rope_table(Tmax, d, dtype, theta=10000.0):
     return cs.contiguous()
 
 
-def _decode_case(lib, dtype, d, nq, nkv, lens, S, Tmax, seed):
+def _decode_case(lib, dtype, d, nq, nkv, lens, S, Tmax, seed, ret_raw=False):
     G = nq // nkv
     M = len(lens)
     n_slots = M + 3
@@ -172,6 +172,8 @@ def _decode_case(lib, dtype, d, nq, nkv, lens, S, Tmax, seed):
                                   L.ptr(kc), L.ptr(vc), L.ptr(act), L.ptr(rl), L.ptr(cs), M, nq, nkv, Tmax, C.c_float(scale), _stream())
     assert rc == 0, rc
     torch.cuda.synchronize()
+    if ret_raw:
+        return out, kc, vc
     # fp32 PyTorch restatement on the same rounded inputs
     x = (part.sum(0) + bias.float()).to(dtype).float()                        # projection output rounded to the storage dtype
     qh = x[:, :nq * d].view(M, nq, d)
@@ -208,17 +210,41 @@ def _decode_case(lib, dtype, d, nq, nkv, lens, S, Tmax, seed):
 DECODE_LENS = [0, 1, 15, 16, 51, 63, 64, 110, 127, 128, 129, 255, 256, 300, 460, 700, 969]
 
 
-@pytest.mark.parametrize("S", [1, 2, 3, 8])
-def test_decode_attn_flash_d128_g5_vs_fp32(hip_lib, S):
+@pytest.fixture(params=[4, 3], ids=["flash2", "flash"])
+def dattn(request, hip_lib):
+    """Both bf16 decode-attention kernels behind surya_op_decode_attn: 4 = decode_attn_flash2_kernel (round 4, the default), 3 = the
+    third version it replaces (kept as the A/B arm of tools/microbench/decode_sweep.py)."""
+    L.check(hip_lib.surya_set_tuning(b"dattn", C.c_int(request.param)), "surya_set_tuning")
+    yield request.param
+    L.check(hip_lib.surya_set_tuning(b"dattn", C.c_int(4)), "surya_set_tuning")
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 5, 8])
+def test_decode_attn_flash_d128_g5_vs_fp32(hip_lib, dattn, S):
     worst, ref_max, worst_kv = _decode_case(hip_lib, torch.bfloat16, 128, 10, 2, DECODE_LENS, S, 1024, seed=S)
     assert worst <= 2e-2 * ref_max, f"max err {worst} vs max|ref| {ref_max}"
     assert worst_kv <= 4e-2, f"appended K/V rows differ by {worst_kv}"      # at most one bf16 ulp of |k| < 8 (fp32 contraction order)
 
 
 @pytest.mark.parametrize("d,nq,nkv", [(128, 16, 2), (64, 8, 2), (32, 4, 2)])
-def test_decode_attn_flash_other_shapes_vs_fp32(hip_lib, d, nq, nkv):
-    worst, ref_max, worst_kv = _decode_case(hip_lib, torch.bfloat16, d, nq, nkv, [0, 7, 64, 130, 257], 2, 512, seed=d)
+def test_decode_attn_flash_other_shapes_vs_fp32(hip_lib, dattn, d, nq, nkv):
+    worst, ref_max, worst_kv = _decode_case(hip_lib, torch.bfloat16, d, nq, nkv, [0, 7, 64, 127, 128, 130, 257], 2, 512, seed=d)
     assert worst <= 2e-2 * ref_max, f"max err {worst} vs max|ref| {ref_max}"
+    assert worst_kv <= 4e-2
+
+
+def test_decode_attn_flash2_agrees_with_flash(hip_lib):
+    """Same slab order, rounding points, MFMA order and combine: the round-4 kernel's outputs and appended K / V rows equal the third
+    version's to one bf16 ulp (the rotation's products are pinned with explicit fma / mul in the new kernel only)."""
+    outs = {}
+    for ver in (3, 4):
+        L.check(hip_lib.surya_set_tuning(b"dattn", C.c_int(ver)), "surya_set_tuning")
+        outs[ver] = _decode_case(hip_lib, torch.bfloat16, 128, 10, 2, DECODE_LENS, 3, 1024, seed=5, ret_raw=True)
+    L.check(hip_lib.surya_set_tuning(b"dattn", C.c_int(4)), "surya_set_tuning")
+    (o3, k3, v3), (o4, k4, v4) = outs[3], outs[4]
+    assert torch.equal(v3, v4)                                   # V rows are not rotated: bit-identical
+    assert (k3.float() - k4.float()).abs().max().item() <= 4e-2  # one bf16 ulp of |k| < 8
+    assert (o3.float() - o4.float()).abs().max().item() <= 2e-2 * max(1.0, o3.float().abs().max().item())
 
 
 def test_decode_attn_fp32_mode_vs_fp32(hip_lib):

@@ -57,12 +57,15 @@ def main():
         for k, v in kw.items():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
-    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8)
+    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8, dattn=4, rnorm=2, ghead=2, fuse_embed=1, lmhead=1)
     if args.configs == "base":
         variants = [dict()]
     elif args.configs == "fewer":        # fewer, longer split-K slices for the bf16 path
         variants = [dict(), dict(split_min_kt=6), dict(split_min_kt=8), dict(split_min_kt=10), dict(split_max=2), dict(split_target=192),
                     dict(split_target=128), dict(split_max=1)]
+    elif args.configs == "r4":           # round 4: every new decode-step kernel against the round-3 kernel it replaces, one at a time
+        variants = [dict(), dict(dattn=3), dict(rnorm=1), dict(ghead=1, fuse_embed=0), dict(fuse_embed=0), dict(lmhead=0), dict(lmhead=2),
+                    dict(dattn=3, rnorm=1, ghead=1, fuse_embed=0, lmhead=0), dict(graph=1), dict()]
     elif args.configs == "fp8only":
         variants = [dict(fp8=1)]
     elif args.configs == "fp8":
