@@ -406,10 +406,13 @@ int surya_layout_encoder_states(surya_layout* h, void* out, int batch, void* str
  * ---------------------------------------------------------------------------------------------------------- */
 int surya_prof_enable(int on);
 /* Launch-policy knob for A/B measurements inside one process (tools/microbench/decode_sweep.py; keys = the fields of
- * sa::Tuning in csrc/common.h: "graph", "dual", "split_tile", "gu_tile", ...). Process-wide; results never depend on it
+ * sa::Tuning in csrc/common.h: "graph", "split_target", "bigtile", "persist", "lmhead", "dattn", ...). Process-wide; results never depend on it
  * beyond fp rounding order. Returns SA_ERR_ARG for an unknown key. */
 int surya_set_tuning(const char* key, int value);
 int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes);
+/* surya_prof_read + slab_bytes[]: the fp32 partial slabs split-K launches wrote (a by-product of the kernel's own decomposition,
+ * NOT part of `bytes`: `bytes` counts the result once in the storage type, as an unsplit GEMM would write it). slab_bytes may be NULL. */
+int surya_prof_read2(int max_cfg, int* launches, double* ms, double* flops, double* bytes, double* slab_bytes);
 /* Median event-pair time (ms) around an empty kernel on `stream`: the fixed cost inside every per-launch figure above. */
 int surya_prof_event_overhead(void* stream, double* ms);
 

@@ -91,7 +91,7 @@ def sharded_over_ranks(images, run_local, model_device, group=None, chunk: int =
     import numpy as np
     from .. import dist as sdist
     rank, world = sdist.world_info(group)
-    if world <= 1:
+    if not sdist.collectives_on(group):
         return None
     dev = sdist.collective_device(model_device, group)
     sizes = np.asarray([im.size for im in images], np.int64).reshape(-1, 2)

@@ -285,6 +285,7 @@ static inline int launch_conv_cfg(const ConvArgs<T>& a, hipStream_t s) {
         pf.cfg_of[pf.n] = 3;       // profiler bucket 3 = implicit-GEMM convolutions
         pf.flops_of[pf.n] = 2.0 * M * a.Cout * a.KH * a.KW * a.Cin;
         pf.bytes_of[pf.n] = ((double)a.B * a.H * a.W * a.Cin + (double)a.Cout * a.Kpad + (double)M * a.Cout * (a.res ? 2 : 1)) * sizeof(T);
+        pf.slab_of[pf.n] = 0.0;
         ++pf.n;
     }
     return (int)hipGetLastError();

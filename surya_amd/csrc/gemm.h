@@ -453,11 +453,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #undef SA_FETCH
 #undef SA_STASH
     }
-#undef SA_COMPUTE
-#undef SA_COMPUTE_FULL
-#undef SA_COMPUTE_LEAN
-#undef SA_FRAGS
-#undef SA_MFMAS
 
     // Epilogue through LDS. 32x32 result D[n][m]: a lane owns row m = .. + (lane & 31) and, per register group g, four
     // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
@@ -724,6 +719,257 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Persistent 256x256 tile loop (round 4). The one-tile-per-workgroup kernel above spends 7-15 us of a 42-50 us K = 1280 tile
+// outside its main loop: the first K-tile's round trip (every CU starts together and asks for 64 KB at once) and an epilogue that
+// needs the staging LDS back, so nothing of the next tile can be in flight while it runs. Here one workgroup per CU walks the
+// XCD-swizzled tile order (virtual block id = blockIdx.x + round * gridDim.x through the same super-tile map, so an XCD still works
+// on a compact patch of the output) and keeps the operand pipeline alive across tiles:
+//   * the next tile's K-tile 0 is issued into buffer 0 in place of "K-tile nk" during the current tile's last pair;
+//   * the epilogue stages the output through buffer 1 only, in two passes of 128 rows (64 KB), so buffer 0 keeps receiving;
+//   * as soon as the second pass has read its rows back, the next tile's K-tile 1 goes into buffer 1 (its global stores drain behind
+//     the first MFMAs of the next tile).
+// K order, MFMA order and every epilogue formula are the one-tile kernel's: results are bit-identical (tests/test_gpu_ops.py).
+// Requires an even K-tile count (buffer roles stay fixed) and a 2-byte output type (a 128-row pass must fit 64 KB).
+template <typename TI, typename TO, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmArgs<TI, TO> p) {
+    constexpr int BM = 256, BN = 256, WM = 4, WN = 2, NT = 512, GRP = 32;
+    constexpr int KE = Ty<TI>::KE;
+    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
+    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
+    constexpr bool LEAN = false;
+    static_assert(sizeof(TO) == 2 && EPI != EPI_ARGMAX && FM == 2 && FN == 4, "persistent tile loop: 2-byte outputs, 256x256 tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, total = tiles_m * tiles_n;
+    const int padded = ((total + 8 * GRP - 1) / (8 * GRP)) * (8 * GRP);
+    const int nk = p.K / KE, last = nk - 1, pairs = nk >> 1;
+    const int frow = lane & 31, fch = lane >> 5;
+    constexpr int NW = WM * WN, XI = BM / 8 / NW, WI = BN / 8 / NW;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // virtual block id -> output tile (the one-tile kernel's super-tile order)
+    auto map_tile = [&](int vb, int& tile_m, int& tile_n) -> bool {
+        const int x = vb & 7, j = vb >> 3;
+        const int idx = ((j / GRP) * 8 + x) * GRP + (j % GRP);
+        if (idx >= total) return false;
+        const int per_row = p.swz_m * tiles_n;
+        const int sr = idx / per_row, rem = idx - sr * per_row;
+        const int h = min(p.swz_m, tiles_m - sr * p.swz_m);
+        const int sc = rem / (h * p.swz_n), rem2 = rem - sc * h * p.swz_n;
+        const int w = min(p.swz_n, tiles_n - sc * p.swz_n);
+        tile_m = sr * p.swz_m + rem2 / w;
+        tile_n = sc * p.swz_n + rem2 % w;
+        return true;
+    };
+    int vb_next = (int)blockIdx.x;
+    auto next_tile = [&](int& tile_m, int& tile_n) -> bool {      // wave-uniform
+        while (vb_next < padded) {
+            const int vb = vb_next;
+            vb_next += (int)gridDim.x;
+            if (map_tile(vb, tile_m, tile_n)) return true;
+        }
+        return false;
+    };
+    const unsigned char* xg[XI];
+    const unsigned char* wg[WI];
+    auto set_ptrs = [&](int tile_m, int tile_n) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            xg[i] = reinterpret_cast<const unsigned char*>(p.X + (long)min(tile_m * BM + row, p.M - 1) * p.ldx) + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            wg[i] = reinterpret_cast<const unsigned char*>(p.W + (long)min(tile_n * BN + row, p.N - 1) * p.ldw) + c * 16;
+        }
+    };
+#define SA_PISSUE(BUFOFF, KT)                                                                                           \
+    {                                                                                                                   \
+        const long koff_ = (long)(KT) * 128;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                                \
+            (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                     \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
+            (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, 0);            \
+    }
+#define SA_PLANDED()                                     \
+    {                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __syncthreads();                                 \
+    }
+    int tile_m = 0, tile_n = 0;
+    if (!next_tile(tile_m, tile_n)) return;
+    set_ptrs(tile_m, tile_n);
+    SA_PISSUE(0, 0);
+    SA_PLANDED();
+    SA_PISSUE(BUF, 1);                                  // nk >= 2
+    for (;;) {
+        // here: K-tile 0 of (tile_m, tile_n) has landed in buffer 0 and every wave has passed a barrier behind it; K-tile 1 is on
+        // its way into buffer 1
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        int nt_m = 0, nt_n = 0;
+        const bool have_next = next_tile(nt_m, nt_n);
+        f32x16 acc[FN][FM];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+        for (int pi = 0; pi < pairs; ++pi) {
+            const int kt = 2 * pi;
+            __builtin_amdgcn_sched_barrier(0);
+            SA_COMPUTE(smem);
+            __builtin_amdgcn_sched_barrier(0);
+            SA_PLANDED();                               // K-tile kt + 1 is in buffer 1; buffer 0 is free
+            if (kt + 2 <= last) {
+                SA_PISSUE(0, kt + 2);
+            } else if (have_next) {                     // last pair: buffer 0 takes the NEXT tile's first K-tile
+                set_ptrs(nt_m, nt_n);
+                SA_PISSUE(0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            SA_COMPUTE(smem + BUF);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 3 <= last) {
+                SA_PLANDED();                           // K-tile kt + 2 is in buffer 0; buffer 1 is free
+                SA_PISSUE(BUF, kt + 3);
+            }
+        }
+
+        // ---- epilogue: two passes of 128 rows (the i-th 32-row block of every wave row) through buffer 1
+        // The epilogue's addresses are functions of the lane and thread ids only; left visible, hipcc hoists all of them out of the
+        // tile loop and keeps them in scratch beside the 128 accumulator registers -- and every scratch reload in the store loop waits
+        // vmcnt(0), i.e. for the previous store's acknowledgement (r04 ISA). The ids are made opaque once per tile instead.
+        int lane_e = lane, tid_e = tid;
+        asm volatile("" : "+v"(lane_e), "+v"(tid_e));
+        constexpr bool GLU = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU);
+        constexpr int OW = GLU ? BN / 2 : BN;
+        constexpr int ROWB = OW * (int)sizeof(TO), CPR = ROWB / 16, XM = 7;
+        constexpr int PITERS = 128 * CPR / NT;                                // 16-byte chunks per thread per pass (8, or 4 for gated outputs)
+        constexpr int EPC = 16 / (int)sizeof(TO);
+        unsigned char* stage = smem + BUF;
+        const bool has_bias = p.bias != nullptr;
+        float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF);             // [BN] this tile's bias in fp32, beside the two operand buffers
+        if (tid_e < BN / 4) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) load4(p.bias + min(n0 + tid_e * 4, p.N - 4), b);
+            *reinterpret_cast<float4*>(bias_s + tid_e * 4) = make_float4(b[0], b[1], b[2], b[3]);
+        }
+        const int n_out = GLU ? p.N / 2 : p.N, n0_out = GLU ? n0 / 2 : n0;
+        // every wave: its own loads (the next tile's K-tile 0 among them) have landed; all waves: done reading buffer 1
+        SA_PLANDED();
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int srow = wm * 32 + (lane_e & 31);                           // staged row of this lane in pass i
+            constexpr int JG = 2;                                             // rotary entries are fetched for JG column blocks at a time (8 x 16 bytes)
+            [[maybe_unused]] float4 rope_v[JG][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (EPI == EPI_ROPE) {
+                    if (j % JG == 0) {
+                        const int m = min(m0 + wm * WTM + i * 32 + (lane_e & 31), p.M - 1), half = p.rope_D >> 1;
+#pragma unroll
+                        for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int n = min(min(n0 + wn * WTN + (j + jj) * 32 + g * 8 + (lane_e >> 5) * 4, p.N - 4), p.rope_cols - 4);
+                                rope_v[jj][g] = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((n % p.rope_D) >> 1));
+                            }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ncol = wn * WTN + j * 32 + g * 8 + (lane_e >> 5) * 4;
+                    float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                    if (has_bias) {                                           // (adding the staged zeros of a null bias would turn -0 into +0)
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_s + ncol);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    }
+                    if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                    } else if constexpr (EPI == EPI_HARDSWISH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
+                    } else if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (EPI == EPI_ROPE) {
+                        const int n = min(n0 + ncol, p.N - 4);
+                        if (n < p.rope_cols) {
+                            const float4 cs = rope_v[j % JG][g];
+                            const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
+                            v[0] = __fmaf_rn(x0, cs.x, -__fmul_rn(x1, cs.y)); v[1] = __fmaf_rn(x1, cs.x, __fmul_rn(x0, cs.y));
+                            v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
+                        }
+                    }
+                    if constexpr (GLU) {
+                        const int boff = (ncol >> 1) * (int)sizeof(TO);
+                        TO* dst = reinterpret_cast<TO*>(stage + srow * ROWB + ((((boff >> 4) ^ (srow & XM)) << 4) | (boff & 15)));
+                        if constexpr (EPI == EPI_GEGLU) {
+                            const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
+                            store2(dst, g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
+                        } else {
+                            store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                        }
+                    } else {
+                        const int boff = ncol * (int)sizeof(TO);
+                        TO* dst = reinterpret_cast<TO*>(stage + srow * ROWB + ((((boff >> 4) ^ (srow & XM)) << 4) | (boff & 15)));
+                        store4(dst, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+            // This pass's residual rows: one batch of loads, issued once the pass's accumulators are staged and dead (at the top of
+            // the pass the 32 registers do not fit beside 128 accumulators: r04 ISA, 45 spills with reloads between the stores).
+            [[maybe_unused]] u32x4 res[PITERS];
+            if constexpr (EPI == EPI_RESIDUAL) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < PITERS; ++it) {
+                    const int id = tid_e + it * NT, sr = id / CPR, c = id % CPR;
+                    const int m = min(m0 + (sr >> 5) * WTM + i * 32 + (sr & 31), p.M - 1), n = min(n0_out + c * EPC, n_out - EPC);
+                    res[it] = *reinterpret_cast<const u32x4*>(p.R + (long)m * p.ldr + n);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < PITERS; ++it) {
+                const int id = tid_e + it * NT, sr = id / CPR, c = id % CPR;
+                const int m = m0 + (sr >> 5) * WTM + i * 32 + (sr & 31), n = n0_out + c * EPC;
+                if (m >= p.M || n >= n_out) continue;                         // stores only: nothing below waits on memory
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(stage + sr * ROWB + ((c ^ (sr & XM)) << 4));
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    float a[EPC], r[EPC];
+                    unpack16(make_uint4(raw[0], raw[1], raw[2], raw[3]), a, (TO*)nullptr);
+                    unpack16(make_uint4(res[it][0], res[it][1], res[it][2], res[it][3]), r, (TO*)nullptr);
+                    TO* dst = p.C + (long)m * p.ldc + n;
+#pragma unroll
+                    for (int e = 0; e < EPC; e += 4) store4(dst + e, a[e] + r[e], a[e + 1] + r[e + 1], a[e + 2] + r[e + 2], a[e + 3] + r[e + 3]);
+                    __builtin_amdgcn_sched_barrier(0);                        // one chunk at a time: interleaved, the 8 unpacked chunks spill
+                } else {
+                    *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = raw;
+                }
+            }
+            __syncthreads();                                                  // the staged rows have been read: buffer 1 is free again
+        }
+        if (have_next) SA_PISSUE(BUF, 1);                                     // the next tile's K-tile 1 (set_ptrs ran in the last pair)
+        if (!have_next) return;
+        tile_m = nt_m; tile_n = nt_n;
+    }
+#undef SA_PISSUE
+#undef SA_PLANDED
+}
+#undef SA_COMPUTE
+#undef SA_COMPUTE_FULL
+#undef SA_COMPUTE_LEAN
+#undef SA_FRAGS
+#undef SA_MFMAS
+
 // Optional per-launch timing with HIP events on the launch stream (bench.py's `roofline` object): one record per
 // tile configuration, accumulating launches, algorithmic FLOPs / bytes and event-measured milliseconds.
 struct GemmProfiler {
@@ -733,7 +979,7 @@ struct GemmProfiler {
     bool have_events = false;
     int n = 0;
     int cfg_of[POOL];
-    double flops_of[POOL], bytes_of[POOL];
+    double flops_of[POOL], bytes_of[POOL], slab_of[POOL];   // bytes_of: operands + the result once; slab_of: fp32 split-K partial slabs (a by-product of the decomposition)
     void start() {
         if (!have_events) {
             for (int i = 0; i < 2 * POOL; ++i) (void)hipEventCreate(&ev[i]);
@@ -778,9 +1024,51 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
         pf.flops_of[pf.n] = CONV ? 2.0 * a.M * a.N * a.cTaps * a.cCin : 2.0 * a.M * a.N * a.K;
         const double outn = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : (EPI == EPI_ARGMAX ? 4.0 * cdiv(a.N, BN) : a.N);
         const double xelems = CONV ? (double)a.M / std::max(1, a.cHo * a.cWo) * a.cH * a.cW * a.cCin : (double)a.M * a.K;   // the input tensor once
-        pf.bytes_of[pf.n] = SPLIT ? (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.splitk * a.M * a.N * 4.0
-                                  : (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
-                                        (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
+        // algorithmic bytes: X + W + the result ONCE in the storage type (what an unsplit GEMM of this shape would move). The fp32
+        // partial slabs a split-K launch actually writes are the kernel's own decomposition, not the problem's: counted apart
+        // (the bucket's frac 0.148 came from counting them as algorithmic; 0.126 without).
+        pf.bytes_of[pf.n] = (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * (SPLIT ? sizeof(TI) : sizeof(TO)) +
+                            (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
+        pf.slab_of[pf.n] = SPLIT ? (double)a.splitk * a.M * a.N * 4.0 : 0.0;
+        ++pf.n;
+    }
+    return (int)hipGetLastError();
+}
+
+// Launch of the persistent 256x256 tile loop: one workgroup per CU (128 KB of LDS each), XCD-aware super-tiles as in launch_gemm_cfg.
+template <typename TI, typename TO, int EPI>
+static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) {
+    constexpr int BM = 256, BN = 256, GRP = 32;
+    const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
+    GemmArgs<TI, TO> aa = a;
+    a.bn_used = BN;
+    aa.swz_n = cdiv(tn, cdiv(tn, 8));
+    aa.swz_m = std::max(1, GRP / aa.swz_n);
+    const int padded = cdiv(tm * tn, 8 * GRP) * 8 * GRP;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        n_cu = (n_cu / 8) * 8;                              // whole XCD rounds: virtual block b stays on XCD b % 8 in every round
+    }
+    const int grid = std::min(padded, n_cu);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 128 + BN * sizeof(float);
+    auto kern = gemm_nt_persist_kernel<TI, TO, EPI>;
+    static AttrOnce attr;
+    attr.ensure(kern, lds);
+    GemmProfiler& pf = gemm_profiler();
+    const bool prof = pf.enabled && pf.n < GemmProfiler::POOL;
+    if (prof) (void)hipEventRecord(pf.ev[2 * pf.n], s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, aa);
+    if (prof) {
+        (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
+        pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
+        pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
+        const double outn = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : a.N;
+        pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
+                            (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
+        pf.slab_of[pf.n] = 0.0;
         ++pf.n;
     }
     return (int)hipGetLastError();
@@ -842,7 +1130,13 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         // (r03: 256 x 128 tiles with a 3-stage ring -- 144 KB, deeper prefetch, 1.37x the L2 bytes per flop -- lost 5-15 % on every
         // encoder / prefill shape and on 8k^3 (1212 -> 1026 TF/s, profiles/r03_sweeps.txt): the big-tile loop is bound by L2 -> LDS bytes
         // per flop, not by prefetch depth.)
-        if (bigtile && a.K >= tuning().bigtile_min_k && t256 >= 256 && cost256 <= cost128) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
+        if (bigtile && a.K >= tuning().bigtile_min_k && t256 >= 256 && cost256 <= cost128) {
+            if constexpr (EPI != EPI_ARGMAX) {
+                const int nk = a.K / Ty<TI>::KE;
+                if (tuning().persist && nk >= 2 && nk % 2 == 0) return launch_gemm_persist<TI, TO, EPI>(a, s);
+            }
+            return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
+        }
     }
     if (big >= 256) {
         if (glds == 2) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);

@@ -303,9 +303,10 @@ static inline int launch_gemm_mx_cfg(const MxArgs& a, hipStream_t s) {
         pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
         pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
         const double in = ((double)a.M + a.N) * a.K * (1.0 + 1.0 / 32);
-        pf.bytes_of[pf.n] = in + (SPLIT ? (double)a.splitk * a.M * a.N * 4.0
+        pf.bytes_of[pf.n] = in + (SPLIT ? (double)a.M * a.N * 2.0          // the result once (bf16); the fp32 slabs are counted apart
                                         : EPI == MX_EPI_SWIGLU ? a.M * (a.N / 2) * (1.0 + 1.0 / 32)
                                         : EPI == MX_EPI_ARGMAX ? 16.0 * a.M * cdiv(a.N, BN) : 4.0 * a.M * a.N);
+        pf.slab_of[pf.n] = SPLIT ? (double)a.splitk * a.M * a.N * 4.0 : 0.0;
         ++pf.n;
     }
     return (int)hipGetLastError();

@@ -1450,19 +1450,24 @@ int surya_prof_event_overhead(void* stream, double* ms) {
     return SA_OK;
 }
 
-int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes) {
+int surya_prof_read2(int max_cfg, int* launches, double* ms, double* flops, double* bytes, double* slab_bytes) {
     GemmProfiler& pf = gemm_profiler();
     if (!launches || !ms || !flops || !bytes || max_cfg < GemmProfiler::NCFG) return SA_ERR_ARG;
     SA_HIP(hipDeviceSynchronize());
-    for (int c = 0; c < GemmProfiler::NCFG; ++c) { launches[c] = 0; ms[c] = flops[c] = bytes[c] = 0.0; }
+    for (int c = 0; c < GemmProfiler::NCFG; ++c) { launches[c] = 0; ms[c] = flops[c] = bytes[c] = 0.0; if (slab_bytes) slab_bytes[c] = 0.0; }
     for (int i = 0; i < pf.n; ++i) {
         float t = 0.f;
         SA_HIP(hipEventElapsedTime(&t, pf.ev[2 * i], pf.ev[2 * i + 1]));
         const int c = pf.cfg_of[i];
         launches[c]++; ms[c] += t; flops[c] += pf.flops_of[i]; bytes[c] += pf.bytes_of[i];
+        if (slab_bytes) slab_bytes[c] += pf.slab_of[i];
     }
     pf.n = 0;
     return SA_OK;
+}
+
+int surya_prof_read(int max_cfg, int* launches, double* ms, double* flops, double* bytes) {
+    return surya_prof_read2(max_cfg, launches, ms, flops, bytes, nullptr);
 }
 
 int surya_op_rmsnorm(int dtype, const void* x, long ldx, const void* w, void* y, long ldy, int rows, int C, float eps,

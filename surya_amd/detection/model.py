@@ -33,7 +33,7 @@ class HipDetModel:
         self.weights = [w.to(device=self.device, dtype=dtype).contiguous() for w in plan.weights]
         if broadcast_weights:             # every rank planned the op list (shapes); the folded weights used are rank 0's
             from .. import dist as sdist
-            if sdist.world_info(process_group)[1] > 1:
+            if sdist.collectives_on(process_group):
                 cdev = sdist.collective_device(self.device, process_group)
                 tmp = [w.to(cdev) for w in self.weights]
                 sdist.broadcast_tensors(tmp, src=0, group=process_group)

@@ -117,7 +117,7 @@ class DetectionModelLoader(ModelLoader):
         bw = False
         if settings.SURYA_AMD_BROADCAST_WEIGHTS:
             from .. import dist as sdist
-            bw = sdist.world_info()[1] > 1
+            bw = sdist.collectives_on()
         return HipDetModel(self._cfg, self._sd, height=self._size, width=self._size, dtype=dtype, device=device, max_batch=mb,
                            broadcast_weights=bw)
 

@@ -19,6 +19,26 @@ import numpy as np
 import torch
 
 
+# A world of ONE rank normally short-circuits every function below (no process group needed). `force_collectives(True)` (bench.py
+# --force-dist, SURYA_AMD_FORCE_COLLECTIVES=1) makes an initialised 1-rank group run the real collectives instead -- communicator
+# set-up, device buffers, all_gather_into_tensor, broadcast -- so the RCCL path executes on a 1-GPU box exactly as rank 0 of an
+# N-GPU job would run it.
+_FORCE = [False]
+
+
+def force_collectives(on: bool = True):
+    _FORCE[0] = bool(on)
+
+
+def collectives_on(group=None) -> bool:
+    """True when the functions below go through torch.distributed: more than one rank, or a forced 1-rank group."""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _FORCE[0] or os.environ.get("SURYA_AMD_FORCE_COLLECTIVES") == "1"
+
+
 def world_info(group=None) -> Tuple[int, int]:
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -39,7 +59,7 @@ def assert_same_inputs(fingerprint: Sequence[int], group=None, device="cpu"):
     lines of different pages."""
     import torch.distributed as dist
     _, world = world_info(group)
-    if world == 1:
+    if not collectives_on(group):
         return
     mine = torch.tensor(list(fingerprint), dtype=torch.int64, device=device)
     allf = [torch.empty_like(mine) for _ in range(world)]
@@ -81,7 +101,7 @@ def gather_line_outputs(tokens: Sequence[Sequence[int]], scores: Sequence[Sequen
         body[..., 1][mask] = flat_s.view(np.int32)                         # bit-cast, lossless
         bb = np.ascontiguousarray(bboxes[:, :T]).astype(np.int32)
         body[..., 2:8] = np.where(mask[..., None], bb, 0)
-    if world == 1:
+    if not collectives_on(group):
         allr = rec[None]
     else:
         mine = torch.from_numpy(rec).to(device)
@@ -109,7 +129,7 @@ def gather_objects(local: list, local_idx: Sequence[int], n_total: int, group=No
     """Small picklable per-item results (detection boxes of a page): every rank gets all n_total back in global order."""
     import torch.distributed as dist
     _, world = world_info(group)
-    if world == 1:
+    if not collectives_on(group):
         return list(local)
     parts = [None] * world
     dist.all_gather_object(parts, (list(local_idx), list(local)), group=group)
@@ -125,7 +145,7 @@ def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, bucket_byte
     point-to-point, ~153 GB/s each, so bandwidth comes from message size, not from message count)."""
     import torch.distributed as dist
     _, world = world_info(group)
-    if world == 1:
+    if not collectives_on(group):
         return
     by_dtype = {}
     for t in tensors:
@@ -160,7 +180,7 @@ def share_weights(weights, device, src: int = 0, group=None, bucket_bytes: int =
     One checkpoint read + one repack per node instead of one per GPU; REC-FULL is ~1.35 GB in 6 buckets."""
     import torch.distributed as dist
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_on(group):
         return list(weights)
     manifest = [[(tuple(t.shape), t.dtype) for t in weights] if rank == src else None]
     dist.broadcast_object_list(manifest, src=src, group=group)

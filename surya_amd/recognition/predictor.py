@@ -200,7 +200,7 @@ class RecognitionModelLoader(ModelLoader):
         caps.setdefault("max_kv_len", 1536 + 32)
         if settings.SURYA_AMD_BROADCAST_WEIGHTS:
             from .. import dist as sdist
-            caps.setdefault("broadcast_weights", sdist.world_info()[1] > 1)
+            caps.setdefault("broadcast_weights", sdist.collectives_on())
         return HipRecModel(self._cfg, self._sd, image_token_id=sysm["<IMAGE>"], pad_token_id=sysm["<PAD>"],
                            eos_token_id=sysm["</S>"], dtype=dtype, device=device, **caps)
 
@@ -587,7 +587,7 @@ class RecognitionPredictor(BasePredictor):
         group = self.process_group
         rank, world = sdist.world_info(group)
         n = len(flat["slices"])
-        if world == 1:
+        if not sdist.collectives_on(group):                  # one rank (unless a forced 1-rank group, dist.force_collectives)
             return self.prediction_loop(flat, recognition_batch_size, math_mode)
         dev = sdist.collective_device(self.model.device, group)
         shapes = np.asarray([s.shape[:2] for s in flat["slices"]], np.int64).reshape(-1, 2)

@@ -23,7 +23,7 @@ from util import make_prompts
 pytestmark = pytest.mark.gpu
 
 GRIDS = [(6, 38), (10, 18), (8, 24), (6, 10), (12, 12), (2, 30)]
-DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=1)
+DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1)
 
 
 def tune(**kw):
@@ -133,3 +133,66 @@ def test_graph_cache_is_dropped_when_a_mode_changes(hip_lib):
         for k in plain:
             for x, y in zip(plain[k], g[k]):
                 assert np.array_equal(x, y), (rep, k)
+
+
+# ------------------------------------------------------------------------------------------------- persistent 256x256 GEMM
+def _op_gemm(lib, x, w, bias, epi, res=None):
+    M, K = x.shape
+    N = w.shape[0]
+    No = N // 2 if epi == L.EPI_SWIGLU else N
+    c = torch.full((M, No), float("nan"), dtype=torch.bfloat16, device=x.device)
+    rc = lib.surya_op_gemm(L.DTYPE_BF16, 0, epi, L.ptr(x), C.c_long(x.stride(0)), L.ptr(w), C.c_long(w.stride(0)), L.ptr(c), C.c_long(No),
+                           L.ptr(bias), L.ptr(res), C.c_long(No if res is not None else 0), M, N, K,
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return c
+
+
+# (M, N, K): encoder / prefill shapes of the bench (ragged M, N = 5 / 15 / 27 / 40 tile columns, 20 and 54 K-tiles), and a ragged N
+PERSIST_SHAPES = [(46460, 1280, 1280), (46460, 3840, 1280), (15360, 10240, 1280), (46460, 1280, 3456), (33000, 2064, 256), (16700, 4096, 128)]
+
+
+@pytest.mark.parametrize("epi", [L.EPI_BIAS, L.EPI_RESIDUAL, L.EPI_GELU, L.EPI_SWIGLU])
+@pytest.mark.parametrize("M,N,K", PERSIST_SHAPES)
+def test_persistent_tile_loop_is_bit_identical_to_one_tile_per_workgroup(hip_lib, epi, M, N, K):
+    """Same K order, MFMA order and epilogue arithmetic: the persistent 256x256 loop must reproduce the one-tile kernel's bits
+    (which tests/test_gpu_ops.py pins to fp32 PyTorch), including ragged last tile rows / columns and the in-place residual."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if epi != L.EPI_RESIDUAL else None
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if epi == L.EPI_RESIDUAL else None
+    tune(persist=0)
+    ref = _op_gemm(hip_lib, x, w, b, epi, res)
+    tune(persist=1)
+    got = _op_gemm(hip_lib, x, w, b, epi, res)
+    assert not torch.isnan(got.float()).any()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (got.float() - ref.float()).abs().max().item()
+    if epi == L.EPI_RESIDUAL:                       # in place, as the encoder calls it (C aliases R)
+        c = res.clone()
+        rc = hip_lib.surya_op_gemm(L.DTYPE_BF16, 0, epi, L.ptr(x), C.c_long(K), L.ptr(w), C.c_long(K), L.ptr(c), C.c_long(N), None, L.ptr(c),
+                                   C.c_long(N), M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(c.view(torch.int16), ref.view(torch.int16))
+
+
+def test_encoder_features_do_not_depend_on_the_persistent_loop(hip_lib):
+    """The vision qkv projection's rotary epilogue (EPI_ROPE) is reachable through the encoder only: REC-FULL bf16 image features of 96
+    bench-sized lines, persistent loop on vs off, bit for bit."""
+    from surya_amd.recognition.model import HipRecModel
+    from util import crop_grid
+    cfg = rec_config("REC-FULL")
+    sd = make_rec_weights(cfg, 0)
+    m = HipRecModel(cfg, sd, image_token_id=cfg.image_token_id, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    dtype=torch.bfloat16, max_slots=8, max_kv_len=128, max_patches=65536, max_prefill_tokens=96 * 72)
+    rng = np.random.default_rng(7)
+    grids = [crop_grid(64, int(w)) for w in sorted(rng.integers(128, 513, size=96), reverse=True)]
+    tiles, _ = make_prompts(cfg, grids, seed=5)
+    tiles = tiles.cuda().contiguous()
+    tune(persist=0)
+    a = m.encode_only(tiles, grids).clone()
+    tune(persist=1)
+    b = m.encode_only(tiles, grids)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))

@@ -38,9 +38,9 @@ def run(reps=4):
     return e0.elapsed_time(e1) / reps
 
 
-variants = [dict(), dict(bigtile=0), dict(bigtile_min_k=1300), dict(bigtile_min_k=3500)] + [dict(**{k: int(v)}) for k, v in
+variants = [dict(), dict(persist=1), dict(bigtile=0), dict()] + [dict(**{k: int(v)}) for k, v in
                                                                                              (a.split("=") for a in sys.argv[1:])]
-base = dict(bigtile=1, glds=2, bigtile_min_k=0)
+base = dict(bigtile=1, glds=2, bigtile_min_k=0, persist=0)
 for v in variants:
     for k, val in {**base, **v}.items():
         L.check(lib.surya_set_tuning(k.encode(), C.c_int(val)), k)
