@@ -287,12 +287,44 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, const int* __restrict
 // loads are in flight together and the normalised row is written from registers. (The first version ran 256 threads over
 // H = 1280 -- a second serial trip for the first wave -- and re-read its own stores for the norm: 4.9 us per launch, 1504
 // launches per recognition step.)
+// Round 4: the launch may carry M extra workgroups (blockIdx.x >= M) that do nothing but request the K (or V) rows the NEXT layer's
+// decode attention will read for row blockIdx.x - M (KvPrefetch). That kernel is the only one of the decode step that waits on cold HBM:
+// 22 MB per layer that were last touched a whole step (1.1 GB of traffic) ago -- 11.2 us per launch against 7.5 us on a warm cache
+// (profiles/r04_a_decode_attn_phases.txt). The reduce kernels move ~5 MB and leave HBM idle; with M a multiple of 8, workgroup M + r
+// runs on XCD r % 8 like the attention workgroups of row r, so the lines arrive in the L2 that will be asked for them. The extra
+// workgroups write nothing and share no barrier with the working ones (a prefetch WAVE inside the row's workgroup would hold the
+// row's barrier until its loads return: s_endpgm drains the wave's memory queue first).
+struct KvPrefetch {
+    const unsigned char* base = nullptr;   // cache of the layer to warm ([slot][kv head][T_max][D]); nullptr = no prefetch wave
+    const int* slots = nullptr;            // [rows] slot of each row (the active list)
+    const int* lens = nullptr;             // [rows] cached tokens of each row
+    long slot_stride = 0, head_stride = 0; // bytes
+    int heads = 0, row_bytes = 0, max_rows = 0;
+};
+
 template <typename T, int SL = 8>      // SL: slabs requested per thread (>= S; the round-3 kernel always asked for 8, clamped duplicates included)
 __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float* __restrict__ part, int S, int M, T* __restrict__ x,
                                                                     const T* __restrict__ bias, const T* __restrict__ w,
                                                                     T* __restrict__ y, int H, float eps,
                                                                     uint8_t* __restrict__ y8 = nullptr, uint8_t* __restrict__ sy = nullptr,
-                                                                    int srows = 0) {
+                                                                    int srows = 0, KvPrefetch pf = KvPrefetch()) {
+    if ((int)blockIdx.x >= M) {
+        if (pf.base) {
+            const int r = (int)blockIdx.x - M, t16 = (int)threadIdx.x * 16, step = (int)blockDim.x * 16;
+            const int bytes = min(pf.lens[r] + 1, pf.max_rows) * pf.row_bytes;
+            const unsigned char* p0 = pf.base + (long)pf.slots[r] * pf.slot_stride + t16;
+            u32x4 sink;
+            for (int h = 0; h < pf.heads; ++h) {
+                const unsigned char* p = p0 + (long)h * pf.head_stride;
+                for (int off = 0; off + t16 < bytes; off += step)
+                    // an asm load: the compiler sees no memory operation, so nothing ever waits for it; the one destination quad is
+                    // only ever overwritten by the next request (s_endpgm drains the queue)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(p + off) : "memory");
+            }
+            asm volatile("" ::"v"(sink));
+        }
+        return;
+    }
     const int row = blockIdx.x, tid = threadIdx.x;       // one workgroup per row: M workgroups keep the chip busy at M = 256
     __shared__ float red[16];
     T* xr = x + (long)row * H;

@@ -547,18 +547,33 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
+    // The rows of a decode step and their workspaces: every per-row buffer is row-major, so a row range is a pointer offset.
+    // (r02 ran two halves of the batch on two streams: no gain -- a 128-row launch takes as long as a 256-row one -- removed.)
+    struct Half { int r0, M; float* part; hipStream_t s; };
+
     int splitk_gemm(const T* X, long ldx, const T* Wt, long ldw, int M, int N, int K, float* part_, int* S, hipStream_t s) {
         GemmArgs<T, T> a{X, ldx, Wt, ldw, nullptr, 0, nullptr, nullptr, 0, M, N, K, 1, part_};
         int rc = launch_gemm_splitk<T>(a, s);
         *S = a.splitk;
         return rc;
     }
+    // pf_cache: the K or V cache of the layer whose decode attention comes next -- M extra workgroups request this step's rows of it
+    // while the reduce runs (KvPrefetch, kernels.h). bf16 cache only; nullptr = plain reduce.
     int reduce_residual_norm(int S, int M, const float* part_, T* x, const T* wnorm, T* y, hipStream_t s, uint8_t* y8 = nullptr,
-                             uint8_t* sy = nullptr) {
+                             uint8_t* sy = nullptr, const T* pf_cache = nullptr, const Half* h = nullptr) {
         const int threads = cdiv(c.dec_hidden / 4, 64) * 64;         // one 4-element chunk per thread
         if (threads > 1024 || c.dec_hidden % 4) return SA_ERR_UNSUPPORTED;
-#define SA_RNORM(SL) hipLaunchKernelGGL((splitk_residual_norm_kernel<T, SL>), dim3(M), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr, \
-                                        wnorm, y, c.dec_hidden, c.dec_eps, y8, sy, c.max_slots)
+        KvPrefetch pf;
+        if (pf_cache && h && tuning().kvprefetch && (c.dec_head_dim * sizeof(T)) % 16 == 0) {
+            pf.base = reinterpret_cast<const unsigned char*>(pf_cache);
+            pf.slots = active_dev + h->r0; pf.lens = row_len + h->r0;
+            pf.head_stride = (long)c.max_kv_len * c.dec_head_dim * sizeof(T);
+            pf.slot_stride = pf.head_stride * c.dec_kv_heads;
+            pf.heads = c.dec_kv_heads; pf.row_bytes = c.dec_head_dim * (int)sizeof(T); pf.max_rows = c.max_kv_len;
+        }
+        const int grid = pf.base ? 2 * M : M;
+#define SA_RNORM(SL) hipLaunchKernelGGL((splitk_residual_norm_kernel<T, SL>), dim3(grid), dim3(threads), 0, s, part_, S, M, x, (const T*)nullptr, \
+                                        wnorm, y, c.dec_hidden, c.dec_eps, y8, sy, c.max_slots, pf)
         // only as many slab loads per thread as the slice count needs (the sums are the same: the extra slabs were masked duplicates)
         if (tuning().rnorm == 1 || S > 4) SA_RNORM(8);
         else if (S > 2) SA_RNORM(4);
@@ -633,9 +648,6 @@ struct RecModel : RecBase {
         return SA_OK;
     }
 
-    // The rows of a decode step and their workspaces: every per-row buffer is row-major, so a row range is a pointer offset.
-    // (r02 ran two halves of the batch on two streams: no gain -- a 128-row launch takes as long as a 256-row one -- removed.)
-    struct Half { int r0, M; float* part; hipStream_t s; };
 
     // The round-4 head / embedding kernels (kernels.h) hold a row's operands in registers: partial tiles, hidden size and the fused
     // embedding are bounded by their thread geometry; anything larger keeps the round-3 kernels.
@@ -762,11 +774,16 @@ struct RecModel : RecBase {
             return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s, last ? dlast8 + (size_t)h.r0 * Hd : hh8,
                                         last ? slast + (size_t)h.r0 * 4 : shh);
         }
+        // the next layer's cache rows of this step's slots are requested while the two reduce kernels run: V first (it is needed
+        // second and may fall back to the infinity cache behind gate|up's 26 MB), K right before the attention launch
+        const bool warm = !last && !kv8;
+        const T* v_next = warm ? vcache + (size_t)(l + 1) * layer_kv : nullptr;
+        const T* k_next = warm ? kcache + (size_t)(l + 1) * layer_kv : nullptr;
         if ((rc = splitk_gemm(at, (long)nq * d, WD(l, SA_RD_O_W), (long)nq * d, M, Hd, nq * d, h.part, &S, s))) return rc;
-        if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s))) return rc;
+        if ((rc = reduce_residual_norm(S, M, h.part, x, WD(l, SA_RD_LN2), hh, s, nullptr, nullptr, v_next, &h))) return rc;
         if ((rc = gemm<EPI_SWIGLU>(hh, Hd, WD(l, SA_RD_GU_W), Hd, ml, I, nullptr, nullptr, 0, M, 2 * I, Hd, s))) return rc;
         if ((rc = splitk_gemm(ml, I, WD(l, SA_RD_DOWN_W), I, M, Hd, I, h.part, &S, s))) return rc;
-        return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s);
+        return reduce_residual_norm(S, M, h.part, x, wnext, ynext, s, nullptr, nullptr, k_next, &h);
     }
 
     // fuse_next: the rows are the active list of a decode call and another step follows -- the head also writes that step's
@@ -1408,7 +1425,7 @@ int surya_set_tuning(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
         {"bigtile", &t.bigtile}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}, {"dattn", &t.dattn}, {"rnorm", &t.rnorm},
-        {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}};
+        {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}, {"kvprefetch", &t.kvprefetch}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) {
             if (*e.v != value) ++tuning_epoch();        // captured decode graphs are stale (RecModel::decode_steps drops them)

@@ -220,3 +220,41 @@ def test_sharded_table_predictor_two_ranks_equal_one():
     assert len(results) == 2 and all(r[1] == single for r in results)       # every rank holds all 5 tables, equal to the 1-rank run
     assert len(single) == 5 and sum(len(t["rows"]) for t in single) > 0
     assert len(errors) == 2 and all(e[1].startswith("raised") for e in errors), errors
+
+
+def _forced_worker(port, q):
+    """One rank, gloo, dist.force_collectives(True): the helpers must take the collective branch (bench.py --force-dist rehearses the
+    N > 1 path this way on a 1-GPU box) and still return this rank's own data."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    assert not sd.collectives_on()
+    sd.force_collectives(True)
+    assert sd.collectives_on()
+    max_tokens = 9
+    lines = [_fake_line(i, max_tokens) for i in range(6)]
+    tok, sc, bb = sd.gather_line_outputs([l[0] for l in lines], [l[1] for l in lines], np.stack([l[2] for l in lines]), list(range(6)), 6, max_tokens)
+    assert tok == [l[0] for l in lines] and np.array_equal(bb, np.stack([l[2] for l in lines]))
+    assert all(a == b for a, b in zip(sc, [l[1] for l in lines]))
+    w = [torch.arange(6, dtype=torch.float32)]
+    sd.broadcast_tensors(w, src=0)
+    shared = sd.share_weights([torch.ones(3)], "cpu")
+    assert shared[0].tolist() == [1.0, 1.0, 1.0] and w[0].tolist() == list(range(6))
+    assert sd.gather_objects(["a", "b"], [0, 1], 2) == ["a", "b"]
+    sd.assert_same_inputs([1, 2, 3])
+    sd.force_collectives(False)
+    q.put("ok")
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_takes_the_collective_branch():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=120) == "ok"
+    p.join(timeout=60)
+    assert p.exitcode == 0

@@ -116,7 +116,17 @@ def _free_run_fp32(cfg, m, g, tiles, grids, seqs, steps, topk):
     return worst, flips, int(alive.sum())
 
 
+DEV_CAP = 0.05      # a bf16 tolerance built on the reference's own bf16 deviation means something only while that deviation is small
+
+
 def _teacher_forced_bf16(cfg, m, g, tiles, grids, seqs, steps, dev_per_step):
+    """Teacher-forced bf16 logits within 2 x (the reference's own bf16 deviation) + 1e-2 x max|logit|. VERDICT r03: on the default
+    synthetic weights that deviation is 12-21 % of max|logit| -- a tolerance of ~35 % accepts almost anything. The fixture, not the
+    kernel, is then unfit for a parity claim: where the recorded deviation exceeds DEV_CAP x max|logit| the check degrades to an
+    ENVELOPE (stated as such in the printed result: finite logits, inside the reference's own rounding envelope) and the test is
+    reported as SKIPPED with that reason; the bf16 parity claim lives in tests/test_gpu_bf16_parity.py (conditioned weights, same shapes,
+    deviation <= 1.8 %, enforced there with the same cap)."""
+    unfit = float(max(float(dev_per_step[s_]) / float(g["logits_absmax"][s_].max()) for s_ in range(steps)))
     n = len(seqs)
     slots = list(range(n))
     m.prefill(tiles.cuda().contiguous(), grids, seqs, slots)
@@ -142,6 +152,9 @@ def _teacher_forced_bf16(cfg, m, g, tiles, grids, seqs, steps, dev_per_step):
             m.set_next_tokens(slots, g["tokens"][step].tolist())
             m.decode(1)
     assert mism == 0, (mism, checked)
+    if unfit > DEV_CAP:
+        pytest.skip(f"envelope only, no parity claim: the reference's own bf16 run deviates {unfit:.1%} of max|logit| on this weight set "
+                    f"(cap {DEV_CAP:.0%}); HIP bf16 worst {worst:.4f} stayed inside 2 x that + 1 %. Parity of the bf16 path: tests/test_gpu_bf16_parity.py")
     return worst, worst_ref, checked
 
 

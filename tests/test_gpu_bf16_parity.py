@@ -60,6 +60,9 @@ def bench_inputs():
 def _tols(g, dev):
     """Per-step tolerance 2 x (reference's own bf16 deviation, worst line of the step) + 5e-3 x max|logit| of the step."""
     scale = g["logits_absmax"].amax(-1)
+    # the cap of tests/test_gpu_baseline_parity.py (VERDICT r03): a tolerance built on the reference's own bf16 deviation is a parity
+    # bar only while that deviation is small -- a fixture above it is unfit, whatever the kernel does
+    assert float((dev / scale).max()) <= 0.05, f"fixture unfit: the reference's own bf16 run deviates {float((dev / scale).max()):.1%} of max|logit|"
     return 2 * dev + 5e-3 * scale, scale
 
 

@@ -1,0 +1,129 @@
+"""GPU: the collectives of surya_amd.dist on RCCL ("nccl" IS RCCL on ROCm) with device buffers.
+
+  * test_forced_one_rank_group_runs_real_collectives: ONE rank (runs on the 1-GPU box). dist.force_collectives makes a one-rank nccl
+    group take the same code path as rank 0 of an N-GPU job: communicator set-up, broadcast of bucketed device tensors,
+    all_gather_into_tensor of the per-line records on the GPU, all_gather / all_gather_object -- then the PRODUCT:
+    HipRecModel(broadcast_weights=True) and RecognitionPredictor.sharded_prediction_loop on REC-TINY == the plain loop.
+  * test_two_ranks_nccl_equal_one_rank: TWO ranks, one GPU each (skipped below 2 GPUs; the driver's 8-GPU node runs it): the helpers
+    and the product's sharded loop with rank 0's weights broadcast over xGMI == the 1-rank result.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_line(i, max_tokens):
+    rng = np.random.default_rng(1000 + i)
+    L = int(rng.integers(0, max_tokens + 1))
+    toks = rng.integers(0, 70000, size=L).tolist()
+    scores = rng.random(L).astype(np.float32).tolist()
+    bb = np.zeros((max_tokens, 6), np.float32)
+    bb[:L] = rng.integers(0, 1025, size=(L, 6))
+    return toks, scores, bb
+
+
+def _crops(n, seed=5):
+    rng = np.random.default_rng(seed)
+    return [(rng.random((28 * int(rng.integers(1, 3)), 28 * int(rng.integers(4, 12)), 3)) * 255).astype(np.float32) for _ in range(n)]
+
+
+def _worker(rank, world, port, q, force):
+    import torch.distributed as dist
+    from surya_amd import dist as sd
+    from surya_amd.config import rec_config
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    from surya_amd.recognition.schema import TaskNames
+    from surya_amd.settings import settings
+    from surya_amd.synth import make_rec_weights
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if force:
+        sd.force_collectives(True)
+    assert sd.collectives_on()
+    max_tokens = 12
+    gathered = []
+    for n in (7, 16, 1):
+        idx = sd.shard_indices(n, world, rank)
+        lines = [_fake_line(i, max_tokens) for i in idx]
+        bbs = np.stack([l[2] for l in lines]) if lines else np.zeros((0, max_tokens, 6), np.float32)
+        gathered.append(sd.gather_line_outputs([l[0] for l in lines], [l[1] for l in lines], bbs, idx, n, max_tokens, device=dev))
+    w = [torch.full((5, 3), float(rank + 1), device=dev), (torch.arange(7, dtype=torch.int32) * (rank + 1)).to(dev),
+         torch.full((2,), 9.0 * (rank + 1), device=dev)]
+    sd.broadcast_tensors(w, src=0, bucket_bytes=32)
+    mine = [torch.arange(12, dtype=torch.float32, device=dev).reshape(3, 4), torch.ones(5, dtype=torch.bfloat16, device=dev) * 3] if rank == 0 else None
+    shared = sd.share_weights(mine, dev, src=0, bucket_bytes=16)
+    assert shared[0].flatten().tolist() == list(range(12)) and shared[1].float().tolist() == [3.0] * 5 and shared[0].device == dev
+    objs = sd.gather_objects([{"page": i} for i in sd.shard_indices(5, world, rank)], sd.shard_indices(5, world, rank), 5)
+    assert objs == [{"page": i} for i in range(5)]
+    sd.assert_same_inputs([7, 1234, 0], device=dev)
+    # ---- the product: rank 0 holds the state dict, the others receive the kernel-layout tensors; sharded loop == plain loop
+    cfg = rec_config("REC-TINY")
+    settings.SURYA_AMD_BROADCAST_WEIGHTS = True
+    os.environ["RECOGNITION_MAX_TOKENS"] = "10"
+    settings.reload()
+    settings.SURYA_AMD_BROADCAST_WEIGHTS = True
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype=None, **caps):
+            return super().model(f"cuda:{rank}", torch.float32, max_slots=8, max_kv_len=128, max_patches=4096, max_prefill_tokens=1024)
+
+    RecognitionPredictor.model_loader_cls = Loader
+    pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": make_rec_weights(cfg, 0) if rank == 0 else None})
+    crops = _crops(11)
+    flat = {"slices": crops, "input_text": [None] * len(crops), "task_names": [TaskNames.ocr_with_boxes] * len(crops)}
+    toks_s, boxes_s, sc_s = pred.sharded_prediction_loop(flat, 8, True)
+    toks_p, boxes_p, sc_p = pred.prediction_loop(flat, 8, True)            # every rank: all lines locally
+    assert [list(t) for t in toks_s] == [list(t) for t in toks_p]
+    n = min(boxes_s.shape[1], boxes_p.shape[1])
+    assert torch.equal(boxes_s[:, :n].float(), boxes_p[:, :n].float())
+    q.put((rank, gathered, [t.cpu().tolist() for t in w], [list(t) for t in toks_s]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, force):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, force)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    max_tokens = 12
+    tok0 = None
+    for rank, gathered, w, toks in results:
+        for n, (tok, sc, bb) in zip((7, 16, 1), gathered):
+            ref = [_fake_line(i, max_tokens) for i in range(n)]
+            assert tok == [r[0] for r in ref]
+            assert all(a == b for a, b in zip(sc, [r[1] for r in ref]))
+            assert np.array_equal(bb, np.stack([r[2] for r in ref]))
+        assert w[0] == [[1.0] * 3] * 5 and w[1] == list(range(7)) and w[2] == [9.0, 9.0]      # rank 0's values everywhere
+        tok0 = tok0 or toks
+        assert toks == tok0
+
+
+def test_forced_one_rank_group_runs_real_collectives(hip_lib):
+    _run(1, True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL over xGMI)")
+def test_two_ranks_nccl_equal_one_rank(hip_lib):
+    _run(2, False)
