@@ -389,6 +389,29 @@ int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, i
  * continue at position n_tokens. Equivalent to n_tokens decode steps (a causal prefill is the same arithmetic); SA_ERR_ARG when the prompt
  * does not fit the borrowed encoder workspaces -- callers then take the step-by-step route. Synchronises the stream. */
 int surya_layout_prefill(surya_layout* h, const int32_t* boxes, int batch, int n_tokens, float* class_logits, float* bbox, void* stream);
+/* Device-fed decode steps (round 4). The reference's box loop moves every step's outputs to the host, forms the next token there and sends
+ * it back (surya/layout/__init__.py:110-177; surya/table_rec/__init__.py:57-129). Here the heads kernel forms that token itself --
+ *   layout: (trunc(bbox * bbox_size) x 6, argmax class), a PageHeader / PageFooter whose polygon (surya/layout/util.py:4-40, float64)
+ *           lies in the middle of its page takes the next-best class (__init__.py:158-169);
+ *   table:  (trunc(clamp(bbox * bbox_size, 0, bbox_size)) x 6, argmax category, argmax merges, round(max(colspan, 1)), argmax is_header)
+ *           = LabelShaper.dict_to_labels of the step's predictions (table_rec/shaper.py:12-51) --
+ * embeds it and runs on; the host reads n_steps steps of records at a time and re-derives the tokens as a check.
+ *   surya_layout_set_feedback: the constants of the rule (per model) and, for the layout family, the (width, height) of every row's page
+ *     slice (host int32 [batch][2]; NULL = rule off). Call after surya_layout_encode / surya_layout_select, before the first run.
+ *   surya_layout_decode_steps: enqueue n_steps (<= 16) steps at cache positions position .. position + n_steps - 1 into record ring
+ *     `ring` (0 / 1). boxes = host int32 [batch][token width] feeds the first step from the host; NULL continues from the token the
+ *     previous run left on the device (its position must be this run's `position`, else SA_ERR_STATE). Enqueue only.
+ *   surya_layout_wait_steps: wait for ring `ring` and copy its records: class_logits fp32 [n_steps][batch][label_count], bbox fp32
+ *     [n_steps][batch][6], fed_tokens int32 [n_steps][batch][token width] (the token each step fed to the one after it). */
+typedef struct surya_layout_feedback {
+    int32_t skew_scaler;              /* layout: decoder.skew_scaler (512) */
+    int32_t relabel_ids[2];           /* layout: class ids (with the special-token offset) of PageHeader / PageFooter; -1 = none */
+    int32_t head_widths[4];           /* table: rows of the category | merges | colspan | is_header heads (their sum = label_count) */
+    const int32_t* page_sizes;        /* layout: host [batch][2] = (width, height) of each slice, NULL = no header / footer rule */
+} surya_layout_feedback;
+int surya_layout_set_feedback(surya_layout* h, const surya_layout_feedback* fb, int batch, void* stream);
+int surya_layout_decode_steps(surya_layout* h, const int32_t* boxes, int batch, int position, int n_steps, int ring, void* stream);
+int surya_layout_wait_steps(surya_layout* h, int ring, int batch, int n_steps, float* class_logits, float* bbox, int32_t* fed_tokens);
 /* Re-batch the decoder after surya_layout_encode: the following decode steps run n rows (n <= max_batch), row i cross-attending the
  * encoder states of image src_index[i] (host array, values < the encoded batch). Table recognition decodes the cells of every detected
  * ROW against its table image (surya/table_rec/__init__.py:196-230: row_encoder_hidden_states = stacked copies); here the copies are an

@@ -165,7 +165,8 @@ struct Tuning {
     int rnorm = 2;           // split-K reduce + residual + RMSNorm: 2 = slab loads sized by the slice count, 1 = round-3 kernel, 3 = one wave per row
     int ghead = 2;           // greedy head: 2 = registers-only partial reduce + vector bbox head (+ next step's embedding when fused), 1 = round-3 kernel
     int fuse_embed = 1;      // inner decode steps: the greedy head also writes the next step's embedding + first RMSNorm (no embed launch)
-    int kvprefetch = 1;      // the two reduce kernels of a decode layer request the next layer's V / K cache rows (extra workgroups, kernels.h KvPrefetch)
+    int kvprefetch = 0;      // 1: the two reduce kernels of a decode layer request the next layer's V / K cache rows (extra workgroups, kernels.h KvPrefetch).
+                             // Measured slower (gpurun r04d, 256 slots: 1165 us per step on vs 1100 off): the extra workgroups delay the reduce rows more than the warm L2 saves
     int lmhead = 1;          // lm_head (N >= 32768, M <= 256): 1 = one round of 256x320 tiles with the greedy partials taken from the accumulators, 0 = 128x128 tiles
     int persist = 0;         // 256x256 bf16 GEMMs as a persistent tile loop (next tile's K-tiles in flight during the epilogue): 1 = on. Measured
                              // bit-identical and NOT faster (r04b: -1.5 ... +1.5 % per encoder / prefill shape, prefill of 256 lines 33.8 vs 33.4 ms):

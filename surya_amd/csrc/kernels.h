@@ -313,15 +313,22 @@ __global__ __launch_bounds__(1024) void splitk_residual_norm_kernel(const float*
             const int r = (int)blockIdx.x - M, t16 = (int)threadIdx.x * 16, step = (int)blockDim.x * 16;
             const int bytes = min(pf.lens[r] + 1, pf.max_rows) * pf.row_bytes;
             const unsigned char* p0 = pf.base + (long)pf.slots[r] * pf.slot_stride + t16;
-            u32x4 sink;
-            for (int h = 0; h < pf.heads; ++h) {
-                const unsigned char* p = p0 + (long)h * pf.head_stride;
-                for (int off = 0; off + t16 < bytes; off += step)
-                    // an asm load: the compiler sees no memory operation, so nothing ever waits for it; the one destination quad is
-                    // only ever overwritten by the next request (s_endpgm drains the queue)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(p + off) : "memory");
+            // Ordinary loads folded into a value that an empty asm "uses": the compiler knows every destination register, keeps eight
+            // requests in flight (unroll) and waits for them before the wave ends. (The first version was an asm load the compiler knew
+            // nothing about: it re-used the destination quad for the next address while the load was still in flight and the late
+            // write-back turned the address into garbage -- MEMORY_APERTURE_VIOLATION on the box, gpurun r04c. A volatile load is
+            // compiled to a system-scope flat_load (sc0 sc1) with a full wait after each: it would bypass the L2 it is meant to fill.)
+            const int per_head = bytes > t16 ? (bytes - t16 + step - 1) / step : 0;
+            const int total = per_head * pf.heads;
+            u32x4 acc = {0u, 0u, 0u, 0u};
+            int k = 0;
+            const unsigned char* p = p0;
+#pragma unroll 8
+            for (int i = 0; i < total; ++i) {
+                acc ^= *reinterpret_cast<const u32x4*>(p + (long)k * step);
+                if (++k == per_head) { k = 0; p += pf.head_stride; }
             }
-            asm volatile("" ::"v"(sink));
+            asm volatile("" ::"v"(acc));
         }
         return;
     }

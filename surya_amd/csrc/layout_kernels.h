@@ -322,11 +322,11 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const T* __restrict__ x, 
 // BboxEmbedding (surya/layout/model/decoder.py:14-60): 15 table rows per token, summed in the reference's order and rounded to the
 // storage dtype after every addition (each `+` of the reference is a tensor op in the model dtype).
 //   tables: [w, h, cx, cy, xskew, yskew, x1, y1, x2, y2, x3, y3, x4, y4] each [vocab][Hd], then label [label_count][Hd]
-template <typename T>
-__global__ __launch_bounds__(256) void box_embed_kernel(const int* __restrict__ boxes, const T* const* __restrict__ tabs, T* __restrict__ x,
-                                                        int Hd, int bbox_size, int vocab, int label_count) {
-    const int b = blockIdx.x;
-    const int* bx = boxes + b * 7;
+// `emit(c, e)` receives column c of the row's embedding (already rounded to the storage dtype): the stand-alone kernel stores it, the
+// fused heads kernel also keeps it in LDS for the next layer's norm.
+template <typename T, typename Emit>
+__device__ __forceinline__ void box_embed_row(const int* __restrict__ bx, const T* const* __restrict__ tabs, int Hd, int bbox_size, int vocab,
+                                              int label_count, Emit emit) {
     auto clampv = [&](int v) { return min(max(v, 0), vocab - 1); };
     const int cx = clampv(bx[0]), cy = clampv(bx[1]), w = clampv(bx[2]), h = clampv(bx[3]), xs = clampv(bx[4]), ys = clampv(bx[5]);
     const int label = min(max(bx[6], 0), label_count - 1);
@@ -342,9 +342,15 @@ __global__ __launch_bounds__(256) void box_embed_kernel(const int* __restrict__ 
         float corner = R(E(6, x1) + E(7, y1));
         corner = R(corner + E(8, x2)); corner = R(corner + E(9, y2)); corner = R(corner + E(10, x3)); corner = R(corner + E(11, y3));
         corner = R(corner + E(12, x4)); corner = R(corner + E(13, y4));
-        const float e = R(R(R(E(14, label) + size_e) + skew_e) + corner);
-        Ty<T>::st(x + (long)b * Hd + c, e);
+        emit(c, R(R(R(E(14, label) + size_e) + skew_e) + corner));
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void box_embed_kernel(const int* __restrict__ boxes, const T* const* __restrict__ tabs, T* __restrict__ x,
+                                                        int Hd, int bbox_size, int vocab, int label_count) {
+    const int b = blockIdx.x;
+    box_embed_row<T>(boxes + b * 7, tabs, Hd, bbox_size, vocab, label_count, [&](int c, float e) { Ty<T>::st(x + (long)b * Hd + c, e); });
 }
 
 // LabelEmbedding of the table-recognition decoder (surya/table_rec/model/decoder.py:12-73): 10-number tokens (cx, cy, w, h, xskew, yskew,
@@ -352,11 +358,9 @@ __global__ __launch_bounds__(256) void box_embed_kernel(const int* __restrict__ 
 // tables of width BE, columns [BE, Hd) = category + merge + colspan from tables of width Hd - BE; is_header is not embedded. Rounded to
 // the storage dtype after every addition, in the reference's order. tables: the 14 box tables (x2 / y2 / x4 / y4 exist but are not read,
 // :25-30 vs :63), then category, merge, colspan.
-template <typename T>
-__global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict__ boxes, const T* const* __restrict__ tabs, T* __restrict__ x,
-                                                          int Hd, int BE, int bbox_size, int vocab, int category_count, int merge_count) {
-    const int b = blockIdx.x;
-    const int* bx = boxes + b * 10;
+template <typename T, typename Emit>
+__device__ __forceinline__ void table_embed_row(const int* __restrict__ bx, const T* const* __restrict__ tabs, int Hd, int BE, int bbox_size,
+                                                int vocab, int category_count, int merge_count, Emit emit) {
     auto clampv = [&](int v) { return min(max(v, 0), vocab - 1); };          // boxes.clamp(0, vocab_size) (:48); index vocab would be out of range
     const int cx = clampv(bx[0]), cy = clampv(bx[1]), w = clampv(bx[2]), h = clampv(bx[3]), xs = clampv(bx[4]), ys = clampv(bx[5]);
     const int cat = min(clampv(bx[6]), category_count - 1), mer = min(clampv(bx[7]), merge_count - 1), col = clampv(bx[8]);
@@ -378,8 +382,16 @@ __global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict_
             auto E = [&](int t, int idx) { return Ty<T>::ld(tabs[t] + (long)idx * P + pc); };
             e = R(R(E(14, cat) + E(15, mer)) + E(16, col));
         }
-        Ty<T>::st(x + (long)b * Hd + c, e);
+        emit(c, e);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict__ boxes, const T* const* __restrict__ tabs, T* __restrict__ x,
+                                                          int Hd, int BE, int bbox_size, int vocab, int category_count, int merge_count) {
+    const int b = blockIdx.x;
+    table_embed_row<T>(boxes + b * 10, tabs, Hd, BE, bbox_size, vocab, category_count, merge_count,
+                       [&](int c, float e) { Ty<T>::st(x + (long)b * Hd + c, e); });
 }
 
 // SuryaADETRDecoderRMSNorm (adetr/decoder.py:23-47): variance CLAMPED at eps (not added), scale (1 + weight), clamp to the storage
@@ -837,14 +849,62 @@ __global__ void expand_map_kernel(const int* __restrict__ src, int* __restrict__
 // Output heads of SuryaLayoutDecoder.forward (layout/model/decoder.py:119-131): final ADETR RMSNorm -> LayerNorm -> class logits
 // (label_count rows, no bias) and sigmoid(bbox_head). One workgroup per image; every intermediate is rounded to the storage dtype
 // where the reference materialises a tensor. class_logits fp32 [B][label_count], bbox fp32 [B][6].
-template <typename T>
+// Round 4: with FB the workgroup goes on to what the reference's host loop does with these outputs (surya/layout/__init__.py:110-131,
+// 158-169; surya/table_rec/__init__.py:80-118, shaper.py:12-51) -- it forms the token that is fed back, embeds it and applies the first
+// layer's cross_pre_norm -- so the next decode step starts at its first GEMM with no host round trip:
+//   layout: token = (trunc(box * bbox_size) x 6, argmax class); a PageHeader / PageFooter whose polygon lies in the middle of its page
+//           takes the next-best class (logit of the first choice set to 0, then argmax), the polygon in float64 exactly as
+//           prediction_to_polygon computes it (IEEE double operations, no contraction);
+//   table:  token = (trunc(clamp(box * bbox_size, 0, bbox_size)) x 6, argmax category, argmax merges, round-half-even(max(colspan, 1)),
+//           argmax is_header), the classification values with their special-token offset = the raw argmax.
+// The host receives every step's class logits / boxes / fed token from rings and re-derives the token itself: a mismatch is an error.
+struct LayoutFeedback {
+    int* boxes = nullptr;              // [B][tokw] token of the next step (also read by a host-fed first step)
+    int* len = nullptr;                // [B] cache position, incremented once per step
+    const int* page_sizes = nullptr;   // layout: [B][2] (width, height) of every slice; nullptr = no header / footer rule
+    int* tok_ring = nullptr;           // this step's fed tokens [B][tokw]
+    int family = 0, tokw = 7, bbox_size = 1024, vocab = 0, skew_scaler = 512, relabel_a = -1, relabel_b = -1;
+    int wcat = 0, wmer = 0, whdr = 0;  // table: widths of the category / merges / is_header heads (colspan has one row between merges and is_header)
+    int box_embed = 0, category_count = 0, merge_count = 0, embed_labels = 0;
+};
+
+__device__ __forceinline__ int argmax_first(const float* v, int n, int zeroed = -1) {
+    int best = 0;
+    float bv = zeroed == 0 ? 0.f : v[0];
+    for (int i = 1; i < n; ++i) {
+        const float x = i == zeroed ? 0.f : v[i];
+        if (x > bv) { bv = x; best = i; }
+    }
+    return best;
+}
+
+// the reference's prediction_to_polygon corners 0 and 2 against the page box (surya/layout/util.py:4-40, __init__.py:158-164)
+__device__ inline bool header_footer_in_page_middle(const float* bp, int pw, int ph, int bbox_size, int skew_scaler) {
+#pragma clang fp contract(off)
+    const double bs = (double)bbox_size;
+    const double w_scale = (double)pw / bs, h_scale = (double)ph / bs;
+    const double cx = (double)bp[0], cy = (double)bp[1], wd = (double)bp[2], ht = (double)bp[3];
+    const double x1 = cx - wd / 2.0, y1 = cy - ht / 2.0, x2 = cx + wd / 2.0, y2 = cy + ht / 2.0;
+    double sx = floor(((double)bp[4] - (double)skew_scaler) / 2.0), sy = floor(((double)bp[5] - (double)skew_scaler) / 2.0);
+    if (fabs(sx) < 0.001) sx = 0.0;
+    if (fabs(sy) < 0.001) sy = 0.0;
+    const double p0x = (x1 - sx) * w_scale, p0y = (y1 - sy) * h_scale, p2x = (x2 + sx) * w_scale, p2y = (y2 + sy) * h_scale;
+    return p0y < (double)ph * .8 && p2y > (double)ph * .2 && p0x < (double)pw * .8 && p2x > (double)pw * .2;
+}
+
+template <typename T, bool FB = false>
 __global__ __launch_bounds__(256) void layout_heads_kernel(const T* __restrict__ x, const T* __restrict__ fnorm_w, const T* __restrict__ ln_w,
                                                            const T* __restrict__ ln_b, const T* __restrict__ lm_w, const T* __restrict__ bb_w,
                                                            const T* __restrict__ bb_b, float* __restrict__ cls, float* __restrict__ box, int Hd,
-                                                           int label_count, float rms_eps, float ln_eps, long ldx) {
+                                                           int label_count, float rms_eps, float ln_eps, long ldx,
+                                                           LayoutFeedback fb = LayoutFeedback(), const T* const* __restrict__ tabs = nullptr,
+                                                           T* __restrict__ xn = nullptr, const T* __restrict__ cnorm_w = nullptr,
+                                                           T* __restrict__ yn = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* h = reinterpret_cast<float*>(smem_raw);                  // [Hd]
     __shared__ float red[4];
+    __shared__ float outs[FB ? 64 : 1];                             // FB: this row's class logits then its 6 box values
+    __shared__ int tok_s[10];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const T* xr = x + (long)b * ldx;
     auto block_sum = [&](float v) {
@@ -883,10 +943,64 @@ __global__ __launch_bounds__(256) void layout_heads_kernel(const T* __restrict__
         }
         d = wave_sum(d);
         if (lane == 0) {
-            if (o < label_count) cls[(long)b * label_count + o] = Ty<T>::rnd(d);
+            float r;
+            if (o < label_count) cls[(long)b * label_count + o] = r = Ty<T>::rnd(d);
             else {
                 const float z = Ty<T>::rnd(d + Ty<T>::ld(bb_b + o - label_count));
-                box[(long)b * 6 + o - label_count] = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));
+                box[(long)b * 6 + o - label_count] = r = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));
+            }
+            if constexpr (FB) outs[o] = r;
+        }
+    }
+    if constexpr (FB) {
+        __syncthreads();
+        if (tid == 0) {
+            const float* cl = outs;
+            const float* bx = outs + label_count;
+            int tok[10];
+            float bp[6];
+            for (int i = 0; i < 6; ++i) bp[i] = __fmul_rn(bx[i], (float)fb.bbox_size);
+            if (fb.family == 0) {
+                for (int i = 0; i < 6; ++i) tok[i] = (int)bp[i];                    // .astype(int64): truncation
+                int label = argmax_first(cl, label_count);
+                if (fb.page_sizes && (label == fb.relabel_a || label == fb.relabel_b) &&
+                    header_footer_in_page_middle(bp, fb.page_sizes[2 * b], fb.page_sizes[2 * b + 1], fb.bbox_size, fb.skew_scaler))
+                    label = argmax_first(cl, label_count, label);
+                tok[6] = label;
+            } else {
+                for (int i = 0; i < 6; ++i) tok[i] = (int)fminf(fmaxf(bp[i], 0.f), (float)fb.bbox_size);
+                tok[6] = argmax_first(cl, fb.wcat);
+                tok[7] = argmax_first(cl + fb.wcat, fb.wmer);
+                tok[8] = (int)rintf(fmaxf(cl[fb.wcat + fb.wmer], 1.0f));
+                tok[9] = argmax_first(cl + fb.wcat + fb.wmer + 1, fb.whdr);
+            }
+            for (int i = 0; i < fb.tokw; ++i) {
+                tok_s[i] = tok[i];
+                fb.boxes[b * fb.tokw + i] = tok[i];
+                fb.tok_ring[b * fb.tokw + i] = tok[i];
+            }
+            fb.len[b] += 1;
+        }
+        __syncthreads();
+        // the fed token's embedding: this row of the residual stream for the next step (h is free: the heads are done with it)
+        auto emit = [&](int c, float e) { h[c] = e; Ty<T>::st(xn + (long)b * Hd + c, e); };
+        if (fb.family == 0) box_embed_row<T>(tok_s, tabs, Hd, fb.bbox_size, fb.vocab, fb.embed_labels, emit);
+        else table_embed_row<T>(tok_s, tabs, Hd, fb.box_embed, fb.bbox_size, fb.vocab, fb.category_count, fb.merge_count, emit);
+        __syncthreads();
+        if (wave == 0) {                                            // adetr_rmsnorm_kernel's arithmetic and summation order, one wave per row
+            float q2 = 0.f;
+            for (int c = lane * 4; c < Hd; c += 256) q2 += h[c] * h[c] + h[c + 1] * h[c + 1] + h[c + 2] * h[c + 2] + h[c + 3] * h[c + 3];
+            const float r2 = rsqrtf(fmaxf(wave_sum(q2) / (float)Hd, rms_eps));
+            for (int c = lane * 4; c < Hd; c += 256) {
+                float wv[4], o[4];
+                load4(cnorm_w + c, wv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = h[c + i] * r2 * (1.0f + wv[i]);
+                    t = fminf(fmaxf(t, -lim), lim);
+                    o[i] = (t != t) ? 0.f : t;
+                }
+                store4(yn + (long)b * Hd + c, o[0], o[1], o[2], o[3]);
             }
         }
     }

@@ -15,7 +15,9 @@
 //   * every dense layer runs on gemm.h's MFMA tiles (patch embedding = GEMM over patch rows, merge reduction, GeGLU MLP).
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "../../include/surya_amd.h"
@@ -33,6 +35,9 @@ struct LayoutBase {
     virtual int encoder_states(void* out, int B, hipStream_t s) = 0;
     virtual int select(const int32_t* src, int n) = 0;
     virtual int prefill(const int32_t* boxes, int B, int Tn, float* cls, float* box, hipStream_t s) = 0;
+    virtual int set_feedback(const surya_layout_feedback* fb, int B, hipStream_t s) = 0;
+    virtual int decode_steps(const int32_t* boxes, int B, int pos0, int n_steps, int ring, hipStream_t s) = 0;
+    virtual int wait_steps(int ring, int B, int n_steps, float* cls, float* box, int32_t* tok) = 0;
 };
 
 static size_t lalign(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -168,10 +173,13 @@ struct LayoutModel : LayoutBase {
             SA_HIP(hipGetLastError());
         }
         SA_HIP(hipHostMalloc((void**)&pinned, B * (MAX_PROMPT * 10 * sizeof(int) + (c.label_count + 6) * sizeof(float)) + 256, hipHostMallocDefault));
+        int rrc = init_rings();
+        if (rrc) return rrc;
         SA_HIP(hipDeviceSynchronize());
         return SA_OK;
     }
     ~LayoutModel() override {
+        free_rings();
         if (arena) (void)hipFree(arena);
         if (pinned) (void)hipHostFree(pinned);
     }
@@ -249,6 +257,7 @@ struct LayoutModel : LayoutBase {
         }
         enc_rows_final = (int)rows;
         batch_encoded = batch_active = B;
+        fed_ready = false;
         SA_HIP(hipMemcpyAsync(cross_map_dev, slots_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));     // identity
         // cross-attention keys / values of every decoder layer (adetr/decoder.py:167-173: projected once, then cached)
         const int kv2 = 2 * kvd();
@@ -278,6 +287,7 @@ struct LayoutModel : LayoutBase {
         SA_HIP(hipDeviceSynchronize());
         SA_HIP(hipMemcpy(cross_map_dev, src, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         batch_active = n;
+        fed_ready = false;
         return SA_OK;
     }
 
@@ -288,6 +298,7 @@ struct LayoutModel : LayoutBase {
     int prefill(const int32_t* boxes, int B, int Tn, float* cls, float* box, hipStream_t s) override {
         if (B != batch_active) return SA_ERR_STATE;
         if (Tn < 1 || Tn > MAX_PROMPT || Tn > c.max_boxes) return SA_ERR_ARG;
+        fed_ready = false;
         const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
         const int qkv_d = Hd + 2 * kv, rows = B * Tn, G = nq / nkv;
         if (G > 8 || (d != 64 && d != 32)) return SA_ERR_UNSUPPORTED;
@@ -366,7 +377,7 @@ struct LayoutModel : LayoutBase {
             if ((rc = gemm<EPI_GEGLU>(ph, Hd, W(lb + SA_LD_GU_W), Hd, pml, I, nullptr, nullptr, 0, rows, 2 * I, Hd, s))) return rc;
             if ((rc = gemm<EPI_RESIDUAL>(pml, I, W(lb + SA_LD_DOWN_W), I, px, Hd, nullptr, prs, Hd, rows, Hd, I, s))) return rc;
         }
-        hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, px + (size_t)(Tn - 1) * Hd, W(SA_LW_DEC_FNORM),
+        hipLaunchKernelGGL((lay::layout_heads_kernel<T, false>), dim3(B), dim3(256), (size_t)Hd * 4, s, px + (size_t)(Tn - 1) * Hd, W(SA_LW_DEC_FNORM),
                            W(SA_LW_DEC_LN_W), W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd,
                            c.label_count, c.rms_eps, c.ln_eps, (long)Tn * Hd);
         if ((rc = (int)hipGetLastError())) return rc;
@@ -380,12 +391,11 @@ struct LayoutModel : LayoutBase {
         return SA_OK;
     }
 
-    int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) override {
-        if (B != batch_active) return SA_ERR_STATE;
-        if (pos < 0 || pos >= c.max_boxes) return SA_ERR_ARG;
-        const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
-        const int qkv_d = Hd + 2 * kv, He = c.embed_dim << (c.n_stages - 1);
-        int rc;
+    // Host-fed start of a decode step: the token rows go to the device, are embedded, and the first layer's cross_pre_norm is applied
+    // (dx = embedding, dh = its norm). The fused heads kernel (lay::layout_heads_kernel<T, true>) leaves the same state for the
+    // step after it, so only the FIRST step of a device-fed run comes through here.
+    int start_step(const int32_t* boxes, int B, int pos, hipStream_t s) {
+        const int Hd = c.dec_hidden;
         int* hb = reinterpret_cast<int*>(pinned);
         memcpy(hb, boxes, (size_t)B * tokw() * sizeof(int));
         SA_HIP(hipMemcpyAsync(boxes_dev, hb, (size_t)B * tokw() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -395,6 +405,16 @@ struct LayoutModel : LayoutBase {
                                c.category_count, c.merge_count);
         else
             hipLaunchKernelGGL(lay::box_embed_kernel<T>, dim3(B), dim3(256), 0, s, boxes_dev, tabs_dev, dx, Hd, c.bbox_size, c.vocab, c.label_count);
+        hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dx, W(dec_base + SA_LD_CNORM), dh, B, Hd, c.rms_eps);
+        return (int)hipGetLastError();
+    }
+
+    // The decoder layers of one step for B rows: dx = the token embeddings, dh = cross_pre_norm(dx) of layer 0, len_dev = the cache
+    // position of every row on entry; dx = the final layer's output on exit.
+    int decode_layers(int B, hipStream_t s) {
+        const int Hd = c.dec_hidden, I = c.dec_inter, nq = c.dec_heads, nkv = c.dec_kv_heads, d = hd(), kv = kvd();
+        const int qkv_d = Hd + 2 * kv;
+        int rc;
         const float scale = 1.0f / sqrtf((float)d);
         const size_t layer_kv = (size_t)c.max_batch * nkv * c.max_boxes * d;
         // Every M = B projection runs split-K (64 x 64 tiles over ~128-256 workgroups instead of 32) and hands its slabs to the
@@ -413,7 +433,6 @@ struct LayoutModel : LayoutBase {
                                c.rms_eps);
         };
         if (Hd % 4 || Hd > 4096) return SA_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(lay::adetr_rmsnorm_kernel<T>, dim3(cdiv(B, 4)), dim3(256), 0, s, dx, W(dec_base + SA_LD_CNORM), dh, B, Hd, c.rms_eps);
         for (int l = 0; l < c.dec_layers; ++l) {
             const int lb = dec_base + l * SA_LD_COUNT;
             int S = 1;
@@ -487,7 +506,18 @@ struct LayoutModel : LayoutBase {
             if ((rc = splitk(dmlp, I, W(lb + SA_LD_DOWN_W), Hd, I, S))) return rc;
             reduce_norm(S, dres, nullptr, dx, l + 1 < c.dec_layers ? W(lb + SA_LD_COUNT + SA_LD_CNORM) : nullptr);
         }
-        hipLaunchKernelGGL(lay::layout_heads_kernel<T>, dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
+        return (int)hipGetLastError();
+    }
+
+    int decode_step(const int32_t* boxes, int B, int pos, float* cls, float* box, hipStream_t s) override {
+        if (B != batch_active) return SA_ERR_STATE;
+        if (pos < 0 || pos >= c.max_boxes) return SA_ERR_ARG;
+        const int Hd = c.dec_hidden;
+        int rc;
+        fed_ready = false;
+        if ((rc = start_step(boxes, B, pos, s))) return rc;
+        if ((rc = decode_layers(B, s))) return rc;
+        hipLaunchKernelGGL((lay::layout_heads_kernel<T, false>), dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
                            W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B), cls_dev, box_dev, Hd, c.label_count,
                            c.rms_eps, c.ln_eps, (long)Hd);
         if ((rc = (int)hipGetLastError())) return rc;
@@ -498,6 +528,167 @@ struct LayoutModel : LayoutBase {
         SA_HIP(hipStreamSynchronize(s));
         memcpy(cls, hc, (size_t)B * c.label_count * sizeof(float));
         memcpy(box, hbx, (size_t)B * 6 * sizeof(float));
+        return SA_OK;
+    }
+
+    // ------------------------------------------------------------------------------------------------ device-fed decode steps (round 4)
+    // n_steps decode steps whose fed-back tokens never leave the device (lay::layout_heads_kernel<T, true>), recorded in ring `ring`
+    // ([step][row] class logits / boxes / fed tokens); one D2H copy + event at the end, no host synchronisation: the caller enqueues
+    // the next run before it waits for this one. A run is replayed as a hipGraph once its (rows, steps) shape has been seen twice;
+    // the cache position lives in len_dev, so the position is not part of the shape.
+    static constexpr int RING_STEPS = 16;
+    float *cls_ring = nullptr, *box_ring = nullptr;
+    int *tok_ring = nullptr, *page_sizes_dev = nullptr;
+    char* ring_host = nullptr;                   // pinned: [2] x (cls | box | tok) of RING_STEPS steps
+    size_t ring_cls = 0, ring_box = 0, ring_tok = 0;     // elements per ring
+    hipEvent_t ev_ring[2] = {nullptr, nullptr}, gev_in = nullptr, gev_out = nullptr;
+    hipStream_t gstream = nullptr;
+    std::map<long, hipGraphExec_t> graphs;
+    std::set<long> seen_keys;
+    bool use_graph = true, fed_ready = false;
+    int fed_rows = 0, fed_pos = 0;
+    surya_layout_feedback fbcfg{};
+    bool have_sizes = false, fb_set = false;
+    int graph_epoch = 0;
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear(); seen_keys.clear();
+    }
+
+    int init_rings() {
+        const size_t B = c.max_batch;
+        ring_cls = (size_t)RING_STEPS * B * c.label_count; ring_box = (size_t)RING_STEPS * B * 6; ring_tok = (size_t)RING_STEPS * B * 10;
+        SA_HIP(hipMalloc((void**)&cls_ring, 2 * ring_cls * sizeof(float)));
+        SA_HIP(hipMalloc((void**)&box_ring, 2 * ring_box * sizeof(float)));
+        SA_HIP(hipMalloc((void**)&tok_ring, 2 * ring_tok * sizeof(int)));
+        SA_HIP(hipMalloc((void**)&page_sizes_dev, B * 2 * sizeof(int)));
+        SA_HIP(hipHostMalloc((void**)&ring_host, 2 * (ring_cls + ring_box + ring_tok) * 4 + B * 2 * sizeof(int), hipHostMallocDefault));
+        for (auto& e : ev_ring) SA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SA_HIP(hipEventCreateWithFlags(&gev_in, hipEventDisableTiming));
+        SA_HIP(hipEventCreateWithFlags(&gev_out, hipEventDisableTiming));
+        SA_HIP(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
+        return SA_OK;
+    }
+    void free_rings() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+        if (cls_ring) (void)hipFree(cls_ring);
+        if (box_ring) (void)hipFree(box_ring);
+        if (tok_ring) (void)hipFree(tok_ring);
+        if (page_sizes_dev) (void)hipFree(page_sizes_dev);
+        if (ring_host) (void)hipHostFree(ring_host);
+        for (auto& e : ev_ring) if (e) (void)hipEventDestroy(e);
+        if (gev_in) (void)hipEventDestroy(gev_in);
+        if (gev_out) (void)hipEventDestroy(gev_out);
+        if (gstream) (void)hipStreamDestroy(gstream);
+    }
+
+    int set_feedback(const surya_layout_feedback* fb, int B, hipStream_t s) override {
+        if (!fb) return SA_ERR_ARG;
+        if (B <= 0 || B > c.max_batch) return SA_ERR_ARG;
+        if (c.label_count + 6 > 64) return SA_ERR_UNSUPPORTED;
+        if (c.family == SA_FAMILY_TABLE && fb->head_widths[0] + fb->head_widths[1] + fb->head_widths[2] + fb->head_widths[3] != c.label_count) return SA_ERR_SHAPE;
+        if (c.family == SA_FAMILY_TABLE && (fb->head_widths[2] != 1 || fb->head_widths[0] < 1 || fb->head_widths[1] < 1 || fb->head_widths[3] < 1)) return SA_ERR_SHAPE;
+        const bool changed = memcmp(&fbcfg, fb, sizeof(int32_t) * 7) != 0 || have_sizes != (fb->page_sizes != nullptr);
+        fbcfg = *fb;
+        have_sizes = fb->page_sizes != nullptr;
+        fbcfg.page_sizes = nullptr;
+        if (changed) drop_graphs();                              // captured runs hold the old rule's constants
+        fb_set = true;
+        if (have_sizes) {
+            int* hs = reinterpret_cast<int*>(ring_host + 2 * (ring_cls + ring_box + ring_tok) * 4);
+            SA_HIP(hipStreamSynchronize(s));                     // an earlier upload from this staging area may still be in flight
+            memcpy(hs, fb->page_sizes, (size_t)B * 2 * sizeof(int));
+            SA_HIP(hipMemcpyAsync(page_sizes_dev, hs, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+        }
+        return SA_OK;
+    }
+
+    int fed_steps_eager(int B, int n_steps, int ring, hipStream_t s) {
+        const int Hd = c.dec_hidden;
+        int rc;
+        lay::LayoutFeedback fb;
+        fb.boxes = boxes_dev; fb.len = len_dev; fb.page_sizes = have_sizes ? page_sizes_dev : nullptr;
+        fb.family = c.family; fb.tokw = tokw(); fb.bbox_size = c.bbox_size; fb.vocab = c.vocab; fb.skew_scaler = fbcfg.skew_scaler;
+        fb.relabel_a = fbcfg.relabel_ids[0]; fb.relabel_b = fbcfg.relabel_ids[1];
+        fb.wcat = fbcfg.head_widths[0]; fb.wmer = fbcfg.head_widths[1]; fb.whdr = fbcfg.head_widths[3];
+        fb.box_embed = c.box_embed; fb.category_count = c.category_count; fb.merge_count = c.merge_count; fb.embed_labels = c.label_count;
+        for (int k = 0; k < n_steps; ++k) {
+            if ((rc = decode_layers(B, s))) return rc;
+            const size_t slot = (size_t)ring * RING_STEPS + k;
+            fb.tok_ring = tok_ring + slot * c.max_batch * 10;
+            hipLaunchKernelGGL((lay::layout_heads_kernel<T, true>), dim3(B), dim3(256), (size_t)Hd * 4, s, dx, W(SA_LW_DEC_FNORM), W(SA_LW_DEC_LN_W),
+                               W(SA_LW_DEC_LN_B), W(SA_LW_DEC_LM_W), W(SA_LW_DEC_BB_W), W(SA_LW_DEC_BB_B),
+                               cls_ring + slot * c.max_batch * c.label_count, box_ring + slot * c.max_batch * 6, Hd, c.label_count, c.rms_eps,
+                               c.ln_eps, (long)Hd, fb, tabs_dev, dx, W(dec_base + SA_LD_CNORM), dh);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        return SA_OK;
+    }
+
+    int decode_steps(const int32_t* boxes, int B, int pos0, int n_steps, int ring, hipStream_t s) override {
+        if (B != batch_active) return SA_ERR_STATE;
+        if (n_steps < 1 || n_steps > RING_STEPS || ring < 0 || ring > 1 || pos0 < 0 || pos0 + n_steps > c.max_boxes) return SA_ERR_ARG;
+        if (!fb_set) return SA_ERR_STATE;                       // surya_layout_set_feedback first
+        if (graph_epoch != tuning_epoch()) { drop_graphs(); graph_epoch = tuning_epoch(); }      // split-K shapes follow the tuning knobs
+        int rc;
+        if (boxes) {
+            if ((rc = start_step(boxes, B, pos0, s))) return rc;
+        } else if (!fed_ready || fed_rows != B || fed_pos != pos0) {
+            return SA_ERR_STATE;                                 // nothing on the device to continue from at this position
+        }
+        fed_ready = false;
+        const long key = (long)B * 64 + n_steps + (long)ring * (1L << 40);
+        bool replayed = false;
+        if (use_graph && tuning().graph != 2 && !gemm_profiler().enabled) {                 // surya_set_tuning("graph", 2): plain launches for the layout runs too
+            auto it = graphs.find(key);
+            if (it == graphs.end() && seen_keys.count(key)) {
+                hipGraph_t g = nullptr;
+                SA_HIP(hipStreamBeginCapture(gstream, hipStreamCaptureModeThreadLocal));
+                rc = fed_steps_eager(B, n_steps, ring, gstream);
+                hipError_t e = hipStreamEndCapture(gstream, &g);
+                hipGraphExec_t ex = nullptr;
+                if (!rc && e == hipSuccess && g) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+                if (rc || e != hipSuccess || !ex) { (void)hipGetLastError(); use_graph = false; }
+                else it = graphs.emplace(key, ex).first;
+            }
+            seen_keys.insert(key);                               // the first run of a shape is eager: one-time attribute calls happen there
+            if (it != graphs.end()) {
+                SA_HIP(hipEventRecord(gev_in, s));
+                SA_HIP(hipStreamWaitEvent(gstream, gev_in, 0));
+                SA_HIP(hipGraphLaunch(it->second, gstream));
+                SA_HIP(hipEventRecord(gev_out, gstream));
+                SA_HIP(hipStreamWaitEvent(s, gev_out, 0));
+                replayed = true;
+            }
+        }
+        if (!replayed && (rc = fed_steps_eager(B, n_steps, ring, s))) return rc;
+        const size_t mb = c.max_batch, off = (size_t)ring * RING_STEPS;
+        float* hc = reinterpret_cast<float*>(ring_host) + (size_t)ring * (ring_cls + ring_box + ring_tok);
+        float* hb = hc + ring_cls;
+        int* ht = reinterpret_cast<int*>(hb + ring_box);
+        SA_HIP(hipMemcpyAsync(hc, cls_ring + off * mb * c.label_count, (size_t)n_steps * mb * c.label_count * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(hb, box_ring + off * mb * 6, (size_t)n_steps * mb * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipMemcpyAsync(ht, tok_ring + off * mb * 10, (size_t)n_steps * mb * 10 * sizeof(int), hipMemcpyDeviceToHost, s));
+        SA_HIP(hipEventRecord(ev_ring[ring], s));
+        fed_ready = true; fed_rows = B; fed_pos = pos0 + n_steps;
+        return SA_OK;
+    }
+
+    int wait_steps(int ring, int B, int n_steps, float* cls, float* box, int32_t* tok) override {
+        if (ring < 0 || ring > 1 || n_steps < 1 || n_steps > RING_STEPS || B < 1 || B > c.max_batch) return SA_ERR_ARG;
+        SA_HIP(hipEventSynchronize(ev_ring[ring]));
+        const size_t mb = c.max_batch;
+        const float* hc = reinterpret_cast<const float*>(ring_host) + (size_t)ring * (ring_cls + ring_box + ring_tok);
+        const float* hb = hc + ring_cls;
+        const int* ht = reinterpret_cast<const int*>(hb + ring_box);
+        const int tw = tokw();
+        for (int k = 0; k < n_steps; ++k) {                      // device rings are [step][max_batch]; the caller's arrays [step][B]
+            memcpy(cls + (size_t)k * B * c.label_count, hc + (size_t)k * mb * c.label_count, (size_t)B * c.label_count * sizeof(float));
+            memcpy(box + (size_t)k * B * 6, hb + (size_t)k * mb * 6, (size_t)B * 6 * sizeof(float));
+            memcpy(tok + (size_t)k * B * tw, ht + (size_t)k * mb * 10, (size_t)B * tw * sizeof(int));          // rows packed at the token width
+        }
         return SA_OK;
     }
 };
@@ -515,6 +706,7 @@ int surya_layout_create(const surya_layout_config* cfg, const void* const* weigh
     if (cfg->img_h % cfg->patch || cfg->img_w % cfg->patch || cfg->dec_hidden % 64 || cfg->dec_inter % 64 || cfg->dec_heads % cfg->dec_kv_heads)
         return SA_ERR_SHAPE;
     if (cfg->max_batch <= 0 || cfg->max_boxes <= 0 || cfg->label_count <= 0) return SA_ERR_ARG;
+    if (cfg->vocab <= cfg->bbox_size) return SA_ERR_SHAPE;       // box_embed / table_embed clamp corners to [0, bbox_size] and index [vocab]-row tables
     if (cfg->family != SA_FAMILY_LAYOUT && cfg->family != SA_FAMILY_TABLE) return SA_ERR_ARG;
     if (cfg->family == SA_FAMILY_TABLE &&
         (cfg->box_embed <= 0 || cfg->box_embed >= cfg->dec_hidden || cfg->category_count <= 0 || cfg->merge_count <= 0)) return SA_ERR_ARG;
@@ -558,6 +750,21 @@ int surya_layout_decode_step(surya_layout* h, const int32_t* boxes, int batch, i
 int surya_layout_prefill(surya_layout* h, const int32_t* boxes, int batch, int n_tokens, float* class_logits, float* bbox, void* stream) {
     if (!h || !boxes || !class_logits || !bbox) return SA_ERR_ARG;
     return h->impl->prefill(boxes, batch, n_tokens, class_logits, bbox, (hipStream_t)stream);
+}
+
+int surya_layout_set_feedback(surya_layout* h, const surya_layout_feedback* fb, int batch, void* stream) {
+    if (!h || !fb) return SA_ERR_ARG;
+    return h->impl->set_feedback(fb, batch, (hipStream_t)stream);
+}
+
+int surya_layout_decode_steps(surya_layout* h, const int32_t* boxes, int batch, int position, int n_steps, int ring, void* stream) {
+    if (!h) return SA_ERR_ARG;
+    return h->impl->decode_steps(boxes, batch, position, n_steps, ring, (hipStream_t)stream);
+}
+
+int surya_layout_wait_steps(surya_layout* h, int ring, int batch, int n_steps, float* class_logits, float* bbox, int32_t* fed_tokens) {
+    if (!h || !class_logits || !bbox || !fed_tokens) return SA_ERR_ARG;
+    return h->impl->wait_steps(ring, batch, n_steps, class_logits, bbox, fed_tokens);
 }
 
 int surya_layout_select(surya_layout* h, const int32_t* src_index, int n) {

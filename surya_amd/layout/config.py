@@ -58,6 +58,7 @@ class LayoutDecoderConfig:
     bos_token_id: int = 1
     pause_token_id: int = 2
     pause_token_count: int = 0
+    ASSUMED_EXTRA = {"double_residual_flow": True}      # (class attribute, not a field) surya/layout/model/config.py:221
 
     @property
     def head_dim(self) -> int:
@@ -89,11 +90,49 @@ def layout_config(name: str) -> LayoutConfig:
     raise KeyError(name)
 
 
+# Architecture switches of the reference's config classes that the HIP engine does NOT read because it implements exactly one
+# setting of each (csrc/layout_model.hip: every decoder layer has cross + self attention, all of it global and causal; GELU(tanh)
+# gated MLP; bias-free attention projections; Swin with qkv bias, exact GELU, no absolute position embedding). A checkpoint that says
+# otherwise would load and silently compute something else -- so a key that is present must carry the assumed value.
+_ASSUMED_ENCODER = {"qkv_bias": True, "hidden_act": "gelu", "use_absolute_embeddings": False, "hidden_dropout_prob": 0.0,
+                    "attention_probs_dropout_prob": 0.0, "drop_path_rate": 0}
+_ASSUMED_DECODER = {"hidden_activation": "gelu_pytorch_tanh", "attention_bias": False, "causal": True, "block_types": ("attention",),
+                    "attention_dropout": 0.0, "aux_heads": 0, "tie_word_embeddings": False, "max_pause_tokens": 0}
+_ALL_LAYERS = ("cross_attn_layers", "encoder_cross_attn_layers", "self_attn_layers", "global_attn_layers")
+
+
+def _norm(v):
+    return tuple(_norm(x) for x in v) if isinstance(v, (list, tuple)) else v
+
+
+def check_assumed(raw: dict, assumed: dict, what: str, n_layers: int | None = None, extra: dict | None = None):
+    """Raise a clear ValueError when a config.json key the engine ignores carries a value other than the one it implements."""
+    bad = []
+    for k, want in {**assumed, **(extra or {})}.items():
+        if k in raw and raw[k] is not None and _norm(raw[k]) != _norm(want) and not (isinstance(want, (int, float)) and float(raw[k]) == float(want)):
+            bad.append(f"{k} = {raw[k]!r} (the HIP engine implements {want!r})")
+    if n_layers is not None:
+        for k in _ALL_LAYERS:
+            if k in raw and raw[k] is not None and not set(range(n_layers)) <= {int(x) for x in raw[k]}:
+                bad.append(f"{k} = {list(raw[k])!r} (the HIP engine runs this in every one of the {n_layers} layers)")
+    if bad:
+        raise ValueError(f"{what}: unsupported architecture switches in config.json: " + "; ".join(bad))
+
+
 def _pick(cls, raw: dict, **extra):
-    """Keep the keys of a reference sub-config dict that are fields of our dataclass (lists -> tuples)."""
+    """Keep the keys of a reference sub-config dict that are fields of our dataclass (lists -> tuples). Keys that change the
+    architecture are not dropped silently: see check_assumed."""
+    if cls is SwinConfig:
+        check_assumed(raw, _ASSUMED_ENCODER, "Swin encoder")
+    elif "num_hidden_layers" in raw or "hidden_activation" in raw:
+        check_assumed(raw, _ASSUMED_DECODER, cls.__name__, n_layers=int(raw.get("num_hidden_layers", cls.__dataclass_fields__["num_hidden_layers"].default)),
+                      extra=getattr(cls, "ASSUMED_EXTRA", None))
     kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items() if k in cls.__dataclass_fields__}
     kw.update(extra)
-    return cls(**kw)
+    cfg = cls(**kw)
+    if cls is SwinConfig and "encoder_length" not in raw:
+        raise ValueError("Swin encoder: config.json has no encoder_length (the position-embedding length of the encoder output)")
+    return cfg
 
 
 def layout_config_from_reference_json(raw: dict) -> LayoutConfig:

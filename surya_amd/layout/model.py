@@ -90,13 +90,24 @@ def repack_layout_weights(cfg, sd, dtype: torch.dtype, device) -> List[torch.Ten
     hd = d.head_dim
     put(1.0 / (d.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd)), torch.float32)
     put(torch.zeros((d.num_attention_heads + 2 * d.num_key_value_heads) * hd))
+    # The embedding kernels index these tables with clamped corner values in [0, bbox_size] and with class ids below the counts of
+    # the config; the pointer table carries no sizes, so the row counts are checked HERE (the reference would raise an index error).
+    def rows(key, need, what):
+        t = f(key)
+        if t.shape[0] < need:
+            raise ValueError(f"{key}: {t.shape[0]} rows, but {what} needs {need} (config / checkpoint mismatch)")
+        return t
+
+    if d.vocab_size <= d.bbox_size:
+        raise ValueError(f"decoder.vocab_size {d.vocab_size} must exceed bbox_size {d.bbox_size}: box corners take values 0..bbox_size")
     for nm in EMB_ORDER[:14]:
-        put(f(f"decoder.model.embed_tokens.{nm}_embed.weight"))
+        put(rows(f"decoder.model.embed_tokens.{nm}_embed.weight", d.bbox_size + 1, "bbox_size + 1 corner values"))
     if table:
-        for nm in ("category", "merge", "colspan"):
-            put(f(f"decoder.model.embed_tokens.{nm}_embed.weight"))
+        put(rows("decoder.model.embed_tokens.category_embed.weight", d.category_count, "category_count"))
+        put(rows("decoder.model.embed_tokens.merge_embed.weight", d.merge_count, "merge_count"))
+        put(rows("decoder.model.embed_tokens.colspan_embed.weight", d.bbox_size + 1, "bbox_size + 1 colspan values"))
     else:
-        put(f("decoder.model.embed_tokens.label_embed.weight")); put(torch.zeros(4)); put(torch.zeros(4))
+        put(rows("decoder.model.embed_tokens.label_embed.weight", d.label_count, "label_count")); put(torch.zeros(4)); put(torch.zeros(4))
     assert len(out) == LW_GLOBALS
     gh, gw = e.grid
     ws = e.window_size

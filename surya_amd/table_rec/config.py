@@ -46,6 +46,7 @@ class TableDecoderConfig:
     pause_token_id: int = 2
     query_end_token_id: int = 4
     special_token_count: int = SPECIAL_TOKENS
+    ASSUMED_EXTRA = {"double_residual_flow": False}     # (class attribute, not a field) surya/table_rec/model/config.py:224
 
     @property
     def head_dim(self) -> int:

@@ -23,7 +23,7 @@ from util import make_prompts
 pytestmark = pytest.mark.gpu
 
 GRIDS = [(6, 38), (10, 18), (8, 24), (6, 10), (12, 12), (2, 30)]
-DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1)
+DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1, kvprefetch=0)
 
 
 def tune(**kw):
@@ -196,3 +196,13 @@ def test_encoder_features_do_not_depend_on_the_persistent_loop(hip_lib):
     tune(persist=1)
     b = m.encode_only(tiles, grids)
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_kv_prefetch_workgroups_change_nothing(hip_lib):
+    """The extra workgroups of the reduce kernels only request cache lines: tokens, scores and boxes with kvprefetch on == off."""
+    cfg, m = build("REC-SMALL", torch.bfloat16)
+    tune(kvprefetch=0)
+    a = run_steps(m, cfg, [4, 4, 3])
+    tune(kvprefetch=1)
+    b = run_steps(m, cfg, [4, 4, 3])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
