@@ -676,23 +676,59 @@ def bench_layout(args, local_rank):
     m = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=f"cuda:{local_rank}", max_batch=B, max_boxes=steps + 4)
     px = torch.randn(B, 3, *cfg.encoder.image_size, generator=torch.Generator().manual_seed(5)).to(f"cuda:{local_rank}").contiguous()
 
-    def run():
+    from surya_amd.layout.config import ID_TO_LABEL
+    from surya_amd.layout.model import FedRuns
+    from surya_amd.layout.predictor import polygons_of_predictions
+    sizes = np.tile(np.array([[612, 792]], np.int64), (B, 1))              # letter pages: the header / footer rule is live
+    hf = [k + d.special_token_count for k, v in ID_TO_LABEL.items() if v in ("PageHeader", "PageFooter")]
+
+    def host_token(cls, box):
+        """The predictor's own rule (surya_amd/layout/predictor.py _detect_chunk, surya/layout/__init__.py:117-169) on one step's records."""
+        cp = cls.argmax(-1)
+        nxt = np.concatenate([box * d.bbox_size, cp[:, None].astype(np.float32)], -1)
+        cand = np.isin(cp, hf)
+        if cand.any():
+            r = np.nonzero(cand)[0]
+            po = polygons_of_predictions(nxt[r], sizes[r], d.bbox_size, d.skew_scaler, dtype="bfloat16")
+            w, h = sizes[r, 0], sizes[r, 1]
+            mid = (po[:, 0, 1] < h * .8) & (po[:, 2, 1] > h * .2) & (po[:, 0, 0] < w * .8) & (po[:, 2, 0] > w * .2)
+            if mid.any():
+                lg = cls[r[mid]].copy()
+                lg[np.arange(lg.shape[0]), cp[r[mid]]] = 0
+                nxt[r[mid], 6] = lg.argmax(-1)
+        return nxt.astype(np.int64).astype(np.int32)
+
+    def run(fed=True):
+        """fed: the product loop -- device-fed runs of 16 steps (FedRuns), the host re-deriving and checking every token; else the
+        round-3 loop (one host round trip per box, no header / footer rule), kept as the comparison."""
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.encode(px)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         boxes = np.full((B, 7), d.bos_token_id, np.int32)
-        for k in range(steps):
-            cls, box = m.decode_step(boxes, k)
-            boxes = np.concatenate([box * d.bbox_size, cls.argmax(-1)[:, None].astype(np.float32)], -1).astype(np.int64).astype(np.int32)
+        if fed:
+            m.set_feedback(sizes)
+            fr = FedRuns(m, 0, steps, 16)
+            for k in range(steps):
+                cls, box = fr.step(boxes)
+                boxes = host_token(cls, box)
+        else:
+            for k in range(steps):
+                cls, box = m.decode_step(boxes, k)
+                boxes = np.concatenate([box * d.bbox_size, cls.argmax(-1)[:, None].astype(np.float32)], -1).astype(np.int64).astype(np.int32)
         return t1 - t0, time.perf_counter() - t1
 
-    run()
+    run(); run()                                                         # (the second run captures the runs' hipGraphs)
     reps = sorted((run() for _ in range(3)), key=lambda r: r[0] + r[1])
     t_enc, t_dec = reps[1]                                               # the MEDIAN whole run: both phases from the same repetition
+    run(False)
+    _, t_dec_host = run(False)
     out = {"metric": "layout pages/s (encode + 100 greedy boxes per page; median of 3 whole runs)", "pages_per_s": round(B / (t_enc + t_dec), 1), "pages": B,
            "encode_ms": round(t_enc * 1e3, 2), "decode_step_us": round(t_dec / steps * 1e6, 1), "boxes_per_page": steps, "dtype": "bf16",
+           "decode_step_us_host_fed": round(t_dec_host / steps * 1e6, 1),
+           "loop": "device-fed runs of 16 steps replayed as hipGraphs (surya_layout_decode_steps), records read per run, every fed token re-derived "
+                   "and checked on the host; decode_step_us_host_fed = the round-3 loop (surya_layout_decode_step, one host round trip per box)",
            "config": {"workload": f"{B} synthetic pages at the processor size 768x768, LAYOUT-DEFAULT synthetic weights, pixel_values in HBM"}}
     g = torch.load(os.path.join(ROOT, "tests", "golden", "layout_default.pt"))
     m2 = HipLayoutModel(cfg, sd, dtype=torch.bfloat16, device=f"cuda:{local_rank}", max_batch=g["batch"], max_boxes=16)
@@ -749,29 +785,73 @@ def bench_table(args, local_rank):
                        np.full((B, 10), d.query_end_token_id)], 1).astype(np.int32)
     widths = [n for k, n in d.head_widths() if k != "bbox"]
 
-    def run():
+    from surya_amd.layout.model import FedRuns
+
+    def host_token(cls, box):
+        """TableRecPredictor.inference_loop's rule (surya/table_rec/__init__.py:80-118 + shaper.py:12-51), all rows at once."""
+        o, parts = 0, []
+        for n in widths:
+            parts.append(cls[:, o:o + n]); o += n
+        cat, mer, col, hdr = parts
+        return np.concatenate([np.clip(box * np.float32(d.bbox_size), 0, d.bbox_size), cat.argmax(-1)[:, None], mer.argmax(-1)[:, None],
+                               np.round(np.maximum(col, np.float32(1.0))), hdr.argmax(-1)[:, None]], -1).astype(np.int64).astype(np.int32)
+
+    def decode_pass(prompt_ids, fed=True):
+        """One decoding pass of the rows selected on the model: the prompt in one call, then fed-back tokens up to TABLE_REC_MAX_BOXES."""
+        T = prompt_ids.shape[1]
+        cls, box = m.prefill(prompt_ids)
+        tok = host_token(cls, box)
+        if fed:
+            m.set_feedback()
+            fr = FedRuns(m, T, positions - T, 16)
+        for k in range(positions - T):
+            cls, box = fr.step(tok) if fed else m.decode_step(tok, T + k)
+            tok = host_token(cls, box)
+
+    def run(fed=True):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.encode(px)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        tok = None
-        for pos in range(2, positions):
-            cls, box = m.prefill(prompt) if pos == 2 else m.decode_step(tok, pos)      # the 3-token prompt in one pass, then fed-back tokens
-            if pos >= 2:
-                o, parts = 0, []
-                for n in widths:
-                    parts.append(cls[:, o:o + n]); o += n
-                cat, mer, col, hdr = parts
-                tok = np.concatenate([box * d.bbox_size, cat.argmax(-1)[:, None], mer.argmax(-1)[:, None],
-                                      np.round(np.maximum(col, 1.0)), hdr.argmax(-1)[:, None]], -1).astype(np.int64).astype(np.int32)
+        decode_pass(prompt, fed)
         return t1 - t0, time.perf_counter() - t1
 
-    run()
+    # The second pass (surya/table_rec/__init__.py:190-230): one prompt per detected ROW -- bos, the row, query_end, then every column of
+    # the batch -- decoded against the row's table image. Synthetic stand-in for "what the first pass found" (random weights find
+    # nothing meaningful): the first 8 tables with 8 rows and 4 columns each = 64 row prompts of 3 + 32 tokens, two batches of 32.
+    rng = np.random.default_rng(9)
+    n_t, n_r, n_c = 8, 8, 4
+    cols = np.concatenate([rng.integers(0, 1025, (n_t * n_c, 6)), np.full((n_t * n_c, 1), 7), np.full((n_t * n_c, 3), [5, 0, 5])], -1)
+    rowq = np.concatenate([rng.integers(0, 1025, (n_t * n_r, 6)), np.full((n_t * n_r, 1), 6), np.full((n_t * n_r, 3), [5, 0, 5])], -1)
+    row_prompts = np.stack([np.concatenate([np.full((1, 10), d.bos_token_id), q[None], np.full((1, 10), d.query_end_token_id), cols], 0) for q in rowq]).astype(np.int32)
+    row_src = np.repeat(np.arange(n_t), n_r)
+
+    def second_pass(fed=True):
+        t0 = time.perf_counter()
+        for j in range(0, len(row_src), B):
+            m.select(row_src[j:j + B])
+            decode_pass(row_prompts[j:j + B], fed)
+        return time.perf_counter() - t0
+
+    run(); run()                                                         # (the second run captures the runs' hipGraphs)
     reps = sorted((run() for _ in range(3)), key=lambda r: r[0] + r[1])
     t_enc, t_dec = reps[1]                                               # the MEDIAN whole run: both phases from the same repetition
+    run(False)
+    _, t_dec_host = run(False)
+    m.encode(px)
+    second_pass(); second_pass()
+    t_second = sorted(second_pass() for _ in range(3))[1]
+    t_second_host = second_pass(False)
+    Tr = row_prompts.shape[1]
     out = {"metric": "table crops/s, encoder + first decoding pass (150 decoder positions per table; median of 3 whole runs)", "tables_per_s": round(B / (t_enc + t_dec), 1),
            "tables": B, "encode_ms": round(t_enc * 1e3, 2), "decode_step_us": round(t_dec / positions * 1e6, 1), "positions": positions,
+           "decode_step_us_host_fed": round(t_dec_host / positions * 1e6, 1),
+           "second_pass": {"rows_per_s": round(len(row_src) / t_second, 1), "rows": int(len(row_src)), "prompt_tokens": int(Tr), "decoded_positions_per_row": positions - Tr,
+                           "ms": round(t_second * 1e3, 2), "ms_host_fed": round(t_second_host * 1e3, 2),
+                           "note": f"the cell pass on a synthetic first-pass result: {n_t} tables x {n_r} rows, prompts = bos + row + query_end + the {n_t * n_c} columns "
+                                   f"of the batch, decoded to TABLE_REC_MAX_BOXES positions in batches of {B} rows against their table's encoder states (median of 3)"},
+           "loop": "device-fed runs of 16 steps replayed as hipGraphs, every fed token re-derived and checked on the host; *_host_fed = one host round trip per position",
            "dtype": "bf16", "config": {"workload": f"{B} synthetic table crops at the processor size 768x768, TABLE-DEFAULT synthetic weights, "
                                                    "pixel_values in HBM"}}
     g = torch.load(os.path.join(ROOT, "tests", "golden", "table_default.pt"))

@@ -331,7 +331,9 @@ int surya_det_boxes(const float* heat, long page_stride, int batch, int height, 
  * SuryaLayoutDecoder.forward (surya/layout/model/decoder.py:96-131, surya/common/adetr/decoder.py) as
  * LayoutPredictor.batch_layout_detection calls them (surya/layout/__init__.py:95-131): one `encode` per image batch, then one
  * `decode_step` per box until every image emitted its end token (the per-step host round trip is the reference's own).
- * Window 8 (64 tokens), head dim 32 in the encoder; image sides a multiple of 4 * 8 * 2^(stages-1).
+ * Window 8 (64 tokens), head dim 32 in the encoder; image sides a multiple of patch * 2^(stages-1) (the reference's per-stage sin-cos
+ * tables ask for the same), every stage grid at least one window; grids that are not whole windows are zero-padded inside every block
+ * as DonutSwinLayer.maybe_pad does (surya/common/donut/encoder.py:588-596, 668).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct surya_layout_config {
     int32_t img_h, img_w, patch, embed_dim, n_stages;

@@ -301,3 +301,61 @@ def generate(sd: SD, cfg, pixel_values: torch.Tensor, max_boxes: int, record: bo
         count += boxes.shape[1]
         boxes = nxt.to(torch.long)
     return enc, steps
+
+
+# ------------------------------------------------------------------------------------------------- the fed-back token (host rule)
+# What the reference's loops do with a step's outputs before the next decoder call -- restated per row with the reference's own
+# tensor operations, as the checker of the device-fed decode runs (surya_layout_decode_steps) and of the predictors' host rule.
+PAGE_HEADER_FOOTER_IDS = (9, 10)          # "PageFooter", "PageHeader" in ID_TO_LABEL (surya/layout/model/config.py:16-34)
+
+
+def polygon_of_prediction(pred: torch.Tensor, img_size, bbox_scaler, skew_scaler, skew_min=0.001):
+    """surya/layout/util.py:4-40: corner arithmetic on the tensor (its dtype), `.item() * scale` in Python floats."""
+    w_scale, h_scale = img_size[0] / bbox_scaler, img_size[1] / bbox_scaler
+    cx, cy, width, height = pred[0], pred[1], pred[2], pred[3]
+    x1, y1, x2, y2 = cx - width / 2, cy - height / 2, cx + width / 2, cy + height / 2
+    skew_x = torch.floor((pred[4] - skew_scaler) / 2)
+    skew_y = torch.floor((pred[5] - skew_scaler) / 2)
+    if abs(skew_x.item()) < skew_min:
+        skew_x = torch.zeros_like(skew_x)
+    if abs(skew_y.item()) < skew_min:
+        skew_y = torch.zeros_like(skew_y)
+    flat = [x1 - skew_x, y1 - skew_y, x2 - skew_x, y1 + skew_y, x2 + skew_x, y2 + skew_y, x1 + skew_x, y2 - skew_y]
+    return [[flat[2 * i].item() * w_scale, flat[2 * i + 1].item() * h_scale] for i in range(4)]
+
+
+def fed_token_layout(class_logits: torch.Tensor, box_logits: torch.Tensor, d, page_size=None, relabel_ids=None) -> torch.Tensor:
+    """surya/layout/__init__.py:117-131, 158-177 for ONE page: class_logits [labels], box_logits [6] in the model dtype; page_size =
+    (width, height) of the slice or None (rule off); relabel_ids overrides the two class ids the rule applies to (tests make the
+    rule fire on synthetic weights that way). Returns the int64 token [7] the next decoder call receives."""
+    class_pred = class_logits.argmax(-1)
+    box_preds = box_logits * d.bbox_size
+    tok = torch.cat([box_preds, class_pred[None].to(box_preds.dtype)], -1)              # batch_decoder_input: the model dtype
+    ids = tuple(relabel_ids) if relabel_ids is not None else tuple(i + d.special_token_count for i in PAGE_HEADER_FOOTER_IDS)
+    if page_size is not None and int(class_pred) in ids:
+        poly = polygon_of_prediction(tok, page_size, d.bbox_size, d.skew_scaler)
+        w, h = page_size
+        if poly[0][1] < h * .8 and poly[2][1] > h * .2 and poly[0][0] < w * .8 and poly[2][0] > w * .2:
+            logits = class_logits.clone()
+            logits[int(class_pred)] = 0
+            tok[6] = logits.argmax(-1).item()
+    return tok.to(torch.long)
+
+
+def fed_token_table(class_logits: torch.Tensor, box_logits: torch.Tensor, d, box_dim: int = 1024, special_tokens: int = 5) -> torch.Tensor:
+    """surya/table_rec/__init__.py:80-118 + LabelShaper.dict_to_labels (surya/table_rec/shaper.py:12-51) for ONE row: class_logits = the
+    property heads side by side [category | merges | colspan | is_header], box_logits [6]. Returns the int64 token [10]."""
+    o, vals = 0, {}
+    for k, n in d.head_widths():
+        if k == "bbox":
+            continue
+        seg = class_logits[o:o + n]
+        o += n
+        if k == "colspan":                                   # regression head: clamp(min = 1), round (:96-98)
+            vals[k] = int(torch.round(torch.clamp(seg, min=1))[0].item())
+        else:                                                # classification: argmax - special tokens (:91-93); dict_to_labels adds them back
+            vals[k] = int(seg.argmax(-1).item()) - special_tokens
+    bbox = (box_logits * box_dim).tolist()                   # (:99-100)
+    bbox = [0 if v < 0 else (box_dim if v > box_dim else v) for v in bbox]          # shaper.py:24-27
+    vec = bbox + [vals["category"] + special_tokens, vals["merges"] + special_tokens, vals["colspan"], vals["is_header"] + special_tokens]
+    return torch.tensor(vec, dtype=torch.float64).to(torch.long)                    # torch.tensor(labels, dtype = long): truncation

@@ -4,7 +4,7 @@
 
 Imports VikParuchuri/surya @ v0.14.6's DonutSwinLayoutModel / SuryaLayoutDecoder from /root/reference through oracle/ref_shim,
 loads the seeded synthetic weights (surya_amd.synth.make_layout_weights) into them, and records, per configuration
-(LAYOUT-TINY, LAYOUT-SMALL, LAYOUT-DEFAULT): the encoder output (a strided sample for the large one), and for N greedy steps of
+(LAYOUT-TINY, LAYOUT-SMALL, LAYOUT-DEFAULT, LAYOUT-PAD): the encoder output (a strided sample for the large one), and for N greedy steps of
 the reference's own decode loop (surya/layout/__init__.py:95-131 call shapes: prefill=True at step 0, cache_position, the fed-back
 (box * bbox_size, class) tokens) the class logits, the sigmoid bbox outputs and the fed-back tokens.
 -> tests/golden/layout_{tiny,small,default}.pt. tests/test_oracle_golden.py pins oracle/layout_oracle.py to them on the CPU,
@@ -86,6 +86,7 @@ def main():
     record("LAYOUT-TINY", 3, 12, 11, 1)
     record("LAYOUT-SMALL", 4, 16, 12, 1)
     record("LAYOUT-DEFAULT", 2, 8, 13, 8)
+    record("LAYOUT-PAD", 3, 8, 14, 1)          # stage grids that are not whole windows: the reference pads inside every block
     for f in sorted(os.listdir(GOLD)):
         if f.startswith("layout_"):
             print(f, os.path.getsize(os.path.join(GOLD, f)))

@@ -2,6 +2,7 @@
 // Written for MI355X only: no CUDA / multi-backend paths.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -174,6 +175,14 @@ struct Tuning {
 };
 inline Tuning& tuning() { static Tuning t; return t; }
 inline int& tuning_epoch() { static int e = 0; return e; }   // bumped by surya_set_tuning whenever a knob changes value
+
+// Debug aid: SURYA_AMD_POISON=1 fills every engine arena with 0xFF bytes (NaN in bf16 and fp32, -1 as an index) right after its
+// allocation, so a read of memory the engine never wrote shows up as NaN / a fault on every box instead of depending on what the
+// last tenant left in HBM (gpurun r04f: three layout tests failed on one box and on no other). Off: hipMalloc'ed memory as it comes.
+inline void poison_arena(void* p, size_t bytes) {
+    static const bool on = [] { const char* e = getenv("SURYA_AMD_POISON"); return e && e[0] == '1'; }();
+    if (on) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per function AND per device: remember, per device, the largest size
 // already granted, and raise it when a later launch of the same kernel needs more (kernels whose dynamic LDS depends on the

@@ -52,6 +52,7 @@ struct DetModel : DetBase {
         const size_t zero_off = total;
         total += 256;
         SA_HIP(hipMalloc((void**)&arena, total));
+        poison_arena(arena, total);
         SA_HIP(hipMemset(arena + zero_off, 0, 256));
         zero_page = reinterpret_cast<T*>(arena + zero_off);
         bufs.resize(n_bufs);

@@ -39,7 +39,7 @@ __global__ void patchify_kernel(const float* __restrict__ px, T* __restrict__ ro
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b,
                                                         T* __restrict__ y, const int* __restrict__ perm, long rows, int rows_per_image, int C,
-                                                        float eps) {
+                                                        float eps, int rows_per_image_out = 0) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     long drow = row;
-    if (perm) drow = (row / rows_per_image) * rows_per_image + perm[row % rows_per_image];
+    // (the window-order side has more rows per image than the token side when a stage's grid is padded to whole windows)
+    if (perm) drow = (row / rows_per_image) * (rows_per_image_out ? rows_per_image_out : rows_per_image) + perm[row % rows_per_image];
     T* yr = y + drow * C;
     for (int c = lane * 4; c < C; c += 256) {
         float v[4], wv[4], bv[4];
@@ -84,16 +85,29 @@ __global__ void add_rows_kernel(T* __restrict__ x, const T* __restrict__ tab, lo
     store4(x + row * C + c, a[0] + t[0], a[1] + t[1], a[2] + t[2], a[3] + t[3]);
 }
 
+// Window-order rows that no token maps to = the zero padding of a stage grid that is not a multiple of the window (DonutSwinLayer.maybe_pad,
+// donut/encoder.py:588-596: F.pad AFTER layernorm_before, so the padded tokens enter the projections as zero vectors -- their q / k / v
+// are the biases -- and take part in the attention like any other token; the rows they produce are cut off again, :668).
+template <typename T>
+__global__ void zero_rows_kernel(T* __restrict__ y, const int* __restrict__ pad_rows, int n_pad, int B, int rows_per_image, int C) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cv = C / 4;
+    if (idx >= (long)B * n_pad * cv) return;
+    const long r = idx / cv;
+    const int c = (int)(idx % cv) * 4;
+    store4(y + ((r / n_pad) * rows_per_image + pad_rows[r % n_pad]) * C + c, 0.f, 0.f, 0.f, 0.f);
+}
+
 // x[row] += a[perm(row)]: window reverse + reverse cyclic shift + residual add (donut/encoder.py:654-672).
 template <typename T>
 __global__ void gather_add_kernel(T* __restrict__ x, const T* __restrict__ a, const int* __restrict__ perm, long rows, int rows_per_image,
-                                  int C) {
+                                  int C, int rows_per_image_src = 0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cv = C / 4;
     if (idx >= rows * cv) return;
     const long row = idx / cv;
     const int c = (int)(idx % cv) * 4;
-    const long src = (row / rows_per_image) * rows_per_image + perm[row % rows_per_image];
+    const long src = (row / rows_per_image) * (rows_per_image_src ? rows_per_image_src : rows_per_image) + perm[row % rows_per_image];
     float xv[4], av[4];
     load4(x + row * C + c, xv);
     load4(a + src * C + c, av);
@@ -878,17 +892,22 @@ __device__ __forceinline__ int argmax_first(const float* v, int n, int zeroed = 
     return best;
 }
 
-// the reference's prediction_to_polygon corners 0 and 2 against the page box (surya/layout/util.py:4-40, __init__.py:158-164)
+// The reference's prediction_to_polygon corners 0 and 2 against the page box (surya/layout/util.py:4-40, __init__.py:158-164). The
+// corner arithmetic there is TENSOR arithmetic in the model dtype (each operation rounded to T), the final `.item() * scale` and the
+// comparisons are Python floats (IEEE double, no contraction).
+template <typename T>
 __device__ inline bool header_footer_in_page_middle(const float* bp, int pw, int ph, int bbox_size, int skew_scaler) {
 #pragma clang fp contract(off)
+    auto R = [](float v) { return Ty<T>::rnd(v); };
+    const float hw = R(bp[2] / 2.0f), hh = R(bp[3] / 2.0f);
+    const float x1 = R(bp[0] - hw), y1 = R(bp[1] - hh), x2 = R(bp[0] + hw), y2 = R(bp[1] + hh);
+    float sx = floorf(R(R(bp[4] - (float)skew_scaler) / 2.0f)), sy = floorf(R(R(bp[5] - (float)skew_scaler) / 2.0f));
+    if (fabsf(sx) < 0.001f) sx = 0.f;
+    if (fabsf(sy) < 0.001f) sy = 0.f;
     const double bs = (double)bbox_size;
     const double w_scale = (double)pw / bs, h_scale = (double)ph / bs;
-    const double cx = (double)bp[0], cy = (double)bp[1], wd = (double)bp[2], ht = (double)bp[3];
-    const double x1 = cx - wd / 2.0, y1 = cy - ht / 2.0, x2 = cx + wd / 2.0, y2 = cy + ht / 2.0;
-    double sx = floor(((double)bp[4] - (double)skew_scaler) / 2.0), sy = floor(((double)bp[5] - (double)skew_scaler) / 2.0);
-    if (fabs(sx) < 0.001) sx = 0.0;
-    if (fabs(sy) < 0.001) sy = 0.0;
-    const double p0x = (x1 - sx) * w_scale, p0y = (y1 - sy) * h_scale, p2x = (x2 + sx) * w_scale, p2y = (y2 + sy) * h_scale;
+    const double p0x = (double)R(x1 - sx) * w_scale, p0y = (double)R(y1 - sy) * h_scale;
+    const double p2x = (double)R(x2 + sx) * w_scale, p2y = (double)R(y2 + sy) * h_scale;
     return p0y < (double)ph * .8 && p2y > (double)ph * .2 && p0x < (double)pw * .8 && p2x > (double)pw * .2;
 }
 
@@ -959,12 +978,12 @@ __global__ __launch_bounds__(256) void layout_heads_kernel(const T* __restrict__
             const float* bx = outs + label_count;
             int tok[10];
             float bp[6];
-            for (int i = 0; i < 6; ++i) bp[i] = __fmul_rn(bx[i], (float)fb.bbox_size);
+            for (int i = 0; i < 6; ++i) bp[i] = Ty<T>::rnd(__fmul_rn(bx[i], (float)fb.bbox_size));      // a tensor op in the model dtype
             if (fb.family == 0) {
                 for (int i = 0; i < 6; ++i) tok[i] = (int)bp[i];                    // .astype(int64): truncation
                 int label = argmax_first(cl, label_count);
                 if (fb.page_sizes && (label == fb.relabel_a || label == fb.relabel_b) &&
-                    header_footer_in_page_middle(bp, fb.page_sizes[2 * b], fb.page_sizes[2 * b + 1], fb.bbox_size, fb.skew_scaler))
+                    header_footer_in_page_middle<T>(bp, fb.page_sizes[2 * b], fb.page_sizes[2 * b + 1], fb.bbox_size, fb.skew_scaler))
                     label = argmax_first(cl, label_count, label);
                 tok[6] = label;
             } else {

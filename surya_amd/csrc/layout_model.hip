@@ -57,6 +57,9 @@ struct LayoutModel : LayoutBase {
     // encoder workspaces
     T *patch_rows, *x, *hbuf, *qkv, *att, *mlp;
     std::vector<int*> perm;                      // [stage * 2 + (shift > 0)] device permutation tables (token -> window-order row)
+    std::vector<int*> pad_rows;                  // [stage * 2 + (shift > 0)] window-order rows of the zero padding (grids that are not whole windows)
+    std::vector<int> pad_count;
+    std::vector<int> grid_hp, grid_wp;           // per stage: the grid rounded up to whole windows
     // decoder
     T *ckv;                                      // [layer][B][Lk][2 * kvd]
     T *cvT = nullptr;                            // bf16: [layer][B][nkv][hd][Lkp] transposed cross-attention values (cross_attn_mfma_kernel)
@@ -100,9 +103,20 @@ struct LayoutModel : LayoutBase {
         const size_t qkv_d = qd + 2 * kv;
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = lalign(off + bytes); return o; };
-        const size_t o_patch = take(rows0 * 64 * sizeof(T)), o_x = take(rows0 * E * sizeof(T)), o_h = take(rows0 * E * sizeof(T));
-        const size_t o_qkv = take(rows0 * 3 * E * sizeof(T)), o_att = take(rows0 * E * sizeof(T)), o_mlp = take(rows0 * 4 * E * sizeof(T));
-        enc_qkv_bytes = rows0 * 3 * E * sizeof(T); enc_mlp_bytes = rows0 * 4 * E * sizeof(T);
+        // window-order workspaces hold the PADDED grid of a stage (rows of whole windows); rows x width shrinks by two per stage unless the
+        // padding outgrows it, so take the largest stage
+        size_t win_elems = 0;
+        {
+            size_t h2 = gh(), w2 = gw(), dim2 = E;
+            for (int s = 0; s < c.n_stages; ++s) {
+                const size_t hp = (h2 + c.window - 1) / c.window * c.window, wp = (w2 + c.window - 1) / c.window * c.window;
+                win_elems = std::max(win_elems, B * hp * wp * dim2);
+                h2 = (h2 + 1) / 2; w2 = (w2 + 1) / 2; dim2 *= 2;
+            }
+        }
+        const size_t o_patch = take(rows0 * 64 * sizeof(T)), o_x = take(rows0 * E * sizeof(T)), o_h = take(win_elems * sizeof(T));
+        const size_t o_qkv = take(win_elems * 3 * sizeof(T)), o_att = take(win_elems * sizeof(T)), o_mlp = take(rows0 * 4 * E * sizeof(T));
+        enc_qkv_bytes = win_elems * 3 * sizeof(T); enc_mlp_bytes = rows0 * 4 * E * sizeof(T);
         const size_t o_ckv = take((size_t)c.dec_layers * B * Lk * 2 * kv * sizeof(T));
         Lkp = (Lk + 31) & ~31;
         const size_t o_cvt = take((size_t)c.dec_layers * B * kv * Lkp * sizeof(T));
@@ -129,6 +143,13 @@ struct LayoutModel : LayoutBase {
             }
         }
         SA_HIP(hipMalloc((void**)&arena, off));
+        poison_arena(arena, off);
+        // The self-attention caches must hold FINITE data from the start: the first decode step of a row (no cached token yet) loads
+        // cache row 0 as the clamped duplicate behind its masked key columns, P = 0 there, and 0 x NaN = NaN. hipMalloc does not clear
+        // memory -- on a box whose last tenant left NaN bit patterns in HBM every output of that model was NaN (gpurun r04f: three tests
+        // failed on one box only; SURYA_AMD_POISON=1 reproduces it everywhere). Rows only ever get overwritten with finite values.
+        SA_HIP(hipMemset(arena + o_k, 0, kv_elems * sizeof(T)));
+        SA_HIP(hipMemset(arena + o_v, 0, kv_elems * sizeof(T)));
         char* b = arena;
         patch_rows = (T*)(b + o_patch); x = (T*)(b + o_x); hbuf = (T*)(b + o_h); qkv = (T*)(b + o_qkv); att = (T*)(b + o_att); mlp = (T*)(b + o_mlp);
         ckv = (T*)(b + o_ckv); cvT = (T*)(b + o_cvt); kcache = (T*)(b + o_k); vcache = (T*)(b + o_v);
@@ -137,25 +158,40 @@ struct LayoutModel : LayoutBase {
         cross_scratch = (float*)(b + o_cscr); cross_map_dev = (int*)(b + o_cmap);
         boxes_dev = (int*)(b + o_boxes); slots_dev = (int*)(b + o_slots); len_dev = (int*)(b + o_len);
         cls_dev = (float*)(b + o_cls); box_dev = (float*)(b + o_box); tabs_dev = (const T**)(b + o_tabs);
-        {   // window-order row of every token, per stage and shift (window_partition after torch.roll(-shift), donut/encoder.py:624-636)
+        {   // window-order row of every token, per stage and shift (window_partition after F.pad to whole windows and torch.roll(-shift),
+            // donut/encoder.py:588-636), and the window-order rows nothing maps to (the padding)
             int h = gh(), wd = gw();
             for (int s = 0; s < c.n_stages; ++s) {
                 const int ws = c.window;
-                if (h % 2 && s + 1 < c.n_stages) return SA_ERR_SHAPE;
-                const bool part_ok = std::min(h, wd) > ws;                 // else one window = the whole map, no shift (:551-559)
-                const int wse = part_ok ? ws : std::min(h, wd);
-                if (wse != ws || h % ws || wd % ws) return SA_ERR_UNSUPPORTED;     // padded / sub-window resolutions are not built
+                if ((h % 2 || wd % 2) && s + 1 < c.n_stages) return SA_ERR_SHAPE;      // (the reference's sin-cos table is sized for grid >> stage)
+                if (std::min(h, wd) < ws) return SA_ERR_UNSUPPORTED;       // a map below the window: the reference's [64][64] bias would not fit either
+                const bool part_ok = std::min(h, wd) > ws;                 // else no shift (:551-559)
+                const int hp = (h + ws - 1) / ws * ws, wp = (wd + ws - 1) / ws * ws;
+                grid_hp.push_back(hp); grid_wp.push_back(wp);
                 for (int sh = 0; sh < 2; ++sh) {
                     const int shift = (sh && part_ok) ? ws / 2 : 0;
                     std::vector<int> p((size_t)h * wd);
+                    std::vector<char> hit((size_t)hp * wp, 0);
                     for (int y = 0; y < h; ++y)
                         for (int xx = 0; xx < wd; ++xx) {
-                            const int ys = ((y - shift) % h + h) % h, xs = ((xx - shift) % wd + wd) % wd;
-                            p[(size_t)y * wd + xx] = ((ys / ws) * (wd / ws) + xs / ws) * ws * ws + (ys % ws) * ws + xs % ws;
+                            const int ys = ((y - shift) % hp + hp) % hp, xs = ((xx - shift) % wp + wp) % wp;
+                            const int r = ((ys / ws) * (wp / ws) + xs / ws) * ws * ws + (ys % ws) * ws + xs % ws;
+                            p[(size_t)y * wd + xx] = r;
+                            hit[r] = 1;
                         }
                     int* d = (int*)(b + o_perm[2 * s + sh]);
                     SA_HIP(hipMemcpy(d, p.data(), p.size() * sizeof(int), hipMemcpyHostToDevice));
                     perm.push_back(d);
+                    std::vector<int> pads;
+                    for (int r = 0; r < hp * wp; ++r)
+                        if (!hit[r]) pads.push_back(r);
+                    int* pd = nullptr;
+                    if (!pads.empty()) {
+                        SA_HIP(hipMalloc((void**)&pd, pads.size() * sizeof(int)));
+                        SA_HIP(hipMemcpy(pd, pads.data(), pads.size() * sizeof(int), hipMemcpyHostToDevice));
+                    }
+                    pad_rows.push_back(pd);
+                    pad_count.push_back((int)pads.size());
                 }
                 h /= 2; wd /= 2;
             }
@@ -180,6 +216,7 @@ struct LayoutModel : LayoutBase {
     }
     ~LayoutModel() override {
         free_rings();
+        for (int* pd : pad_rows) if (pd) (void)hipFree(pd);
         if (arena) (void)hipFree(arena);
         if (pinned) (void)hipHostFree(pinned);
     }
@@ -190,8 +227,8 @@ struct LayoutModel : LayoutBase {
         GemmArgs<T, T> a{X, ldx, Wt, ldw, C, ldc, bias, R, ldr, M, N, K};
         return launch_gemm<T, T, EPI>(a, s);
     }
-    int layernorm(const T* in, int wi, int bi, T* out, const int* pm, long rows, int rpi, int C, float eps, hipStream_t s) {
-        hipLaunchKernelGGL(lay::layernorm_kernel<T>, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, s, in, W(wi), W(bi), out, pm, rows, rpi, C, eps);
+    int layernorm(const T* in, int wi, int bi, T* out, const int* pm, long rows, int rpi, int C, float eps, hipStream_t s, int rpi_out = 0) {
+        hipLaunchKernelGGL(lay::layernorm_kernel<T>, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, s, in, W(wi), W(bi), out, pm, rows, rpi, C, eps, rpi_out);
         return (int)hipGetLastError();
     }
 
@@ -220,21 +257,28 @@ struct LayoutModel : LayoutBase {
                 const int wb = sb + SA_LS_COUNT + bi * SA_LB_COUNT;
                 const bool shifted = (bi % 2 == 1) && std::min(h, wd) > ws;
                 const int* pm = perm[2 * st + (shifted ? 1 : 0)];
-                if ((rc = layernorm(x, wb + SA_LB_LN1_W, wb + SA_LB_LN1_B, hbuf, pm, rows, rpi, dim, c.enc_eps, s))) return rc;
-                if ((rc = gemm<EPI_BIAS>(hbuf, dim, W(wb + SA_LB_QKV_W), dim, qkv, qkv_n, W(wb + SA_LB_QKV_B), nullptr, 0, (int)rows, qkv_n, dim, s)))
+                const int hp = grid_hp[st], wp = grid_wp[st], rpw = hp * wp;                  // the grid in whole windows
+                const long rows_w = (long)B * rpw;
+                const int pi = 2 * st + (shifted ? 1 : 0);
+                if (pad_count[pi]) {
+                    const long n4 = (long)B * pad_count[pi] * (dim / 4);
+                    hipLaunchKernelGGL(lay::zero_rows_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, hbuf, pad_rows[pi], pad_count[pi], B, rpw, dim);
+                }
+                if ((rc = layernorm(x, wb + SA_LB_LN1_W, wb + SA_LB_LN1_B, hbuf, pm, rows, rpi, dim, c.enc_eps, s, rpw))) return rc;
+                if ((rc = gemm<EPI_BIAS>(hbuf, dim, W(wb + SA_LB_QKV_W), dim, qkv, qkv_n, W(wb + SA_LB_QKV_B), nullptr, 0, (int)rows_w, qkv_n, dim, s)))
                     return rc;
-                const int nwx = wd / ws, nwy = h / ws;
+                const int nwx = wp / ws, nwy = hp / ws;
                 if constexpr (std::is_same<T, bf16_t>::value)
-                    hipLaunchKernelGGL(lay::swin_window_attn_mfma_kernel, dim3((unsigned)(rows / 64), nh), dim3(128), 0, s, qkv,
+                    hipLaunchKernelGGL(lay::swin_window_attn_mfma_kernel, dim3((unsigned)(rows_w / 64), nh), dim3(128), 0, s, qkv,
                                        reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
                 else
-                    hipLaunchKernelGGL(lay::swin_window_attn_kernel<T>, dim3((unsigned)(rows / 64), nh), dim3(256), 0, s, qkv,
+                    hipLaunchKernelGGL(lay::swin_window_attn_kernel<T>, dim3((unsigned)(rows_w / 64), nh), dim3(256), 0, s, qkv,
                                        reinterpret_cast<const float*>(w[wb + SA_LB_RELBIAS]), att, nh, nkv, nwx, nwy, shifted ? ws / 2 : 0, ws);
-                if ((rc = gemm<EPI_BIAS>(att, dim, W(wb + SA_LB_PROJ_W), dim, hbuf, dim, W(wb + SA_LB_PROJ_B), nullptr, 0, (int)rows, dim, dim, s)))
+                if ((rc = gemm<EPI_BIAS>(att, dim, W(wb + SA_LB_PROJ_W), dim, hbuf, dim, W(wb + SA_LB_PROJ_B), nullptr, 0, (int)rows_w, dim, dim, s)))
                     return rc;
                 {
                     const long n4 = rows * (dim / 4);
-                    hipLaunchKernelGGL(lay::gather_add_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, hbuf, pm, rows, rpi, dim);
+                    hipLaunchKernelGGL(lay::gather_add_kernel<T>, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, s, x, hbuf, pm, rows, rpi, dim, rpw);
                 }
                 if ((rc = layernorm(x, wb + SA_LB_LN2_W, wb + SA_LB_LN2_B, hbuf, nullptr, rows, rpi, dim, c.enc_eps, s))) return rc;
                 if ((rc = gemm<EPI_GELU>(hbuf, dim, W(wb + SA_LB_FC1_W), dim, mlp, 4 * dim, W(wb + SA_LB_FC1_B), nullptr, 0, (int)rows, 4 * dim, dim, s)))

@@ -277,6 +277,7 @@ struct RecModel : RecBase {
         w.assign(weights, weights + n);
         arena_bytes = layout(c, nullptr);
         SA_HIP(hipMalloc((void**)&arena, arena_bytes));
+        poison_arena(arena, arena_bytes);
         layout(c, this);
         {
             const int half = c.dec_head_dim / 2, n = c.max_kv_len * half;

@@ -87,6 +87,11 @@ def layout_config(name: str) -> LayoutConfig:
         dec = LayoutDecoderConfig(num_hidden_layers=2, hidden_size=64, intermediate_size=128, encoder_hidden_size=128,
                                   num_attention_heads=2, num_key_value_heads=1)
         return LayoutConfig(name="LAYOUT-TINY", encoder=enc, decoder=dec)
+    if name == "LAYOUT-PAD":        # stage grids 44 x 52, 22 x 26, 11 x 13: none a multiple of the window -- every block pads (maybe_pad, donut/encoder.py:588-596)
+        enc = SwinConfig(image_size=(176, 208), embed_dim=64, depths=(2, 2, 2), num_heads=(2, 4, 8), num_kv_heads=(2, 4, 4), encoder_length=160)
+        dec = LayoutDecoderConfig(num_hidden_layers=2, hidden_size=128, intermediate_size=256, encoder_hidden_size=256,
+                                  num_attention_heads=4, num_key_value_heads=2)
+        return LayoutConfig(name="LAYOUT-PAD", encoder=enc, decoder=dec)
     raise KeyError(name)
 
 
@@ -94,10 +99,9 @@ def layout_config(name: str) -> LayoutConfig:
 # setting of each (csrc/layout_model.hip: every decoder layer has cross + self attention, all of it global and causal; GELU(tanh)
 # gated MLP; bias-free attention projections; Swin with qkv bias, exact GELU, no absolute position embedding). A checkpoint that says
 # otherwise would load and silently compute something else -- so a key that is present must carry the assumed value.
-_ASSUMED_ENCODER = {"qkv_bias": True, "hidden_act": "gelu", "use_absolute_embeddings": False, "hidden_dropout_prob": 0.0,
-                    "attention_probs_dropout_prob": 0.0, "drop_path_rate": 0}
+_ASSUMED_ENCODER = {"qkv_bias": True, "hidden_act": "gelu", "use_absolute_embeddings": False}     # (dropout / drop-path rates are inference no-ops)
 _ASSUMED_DECODER = {"hidden_activation": "gelu_pytorch_tanh", "attention_bias": False, "causal": True, "block_types": ("attention",),
-                    "attention_dropout": 0.0, "aux_heads": 0, "tie_word_embeddings": False, "max_pause_tokens": 0}
+                    "aux_heads": 0, "tie_word_embeddings": False, "max_pause_tokens": 0}
 _ALL_LAYERS = ("cross_attn_layers", "encoder_cross_attn_layers", "self_attn_layers", "global_attn_layers")
 
 

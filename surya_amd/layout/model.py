@@ -31,6 +31,14 @@ class LayoutConfigC(C.Structure):
                 ("family", C.c_int32), ("box_embed", C.c_int32), ("category_count", C.c_int32), ("merge_count", C.c_int32)]
 
 
+class LayoutFeedbackC(C.Structure):
+    """surya_layout_feedback (include/surya_amd.h)."""
+    _fields_ = [("skew_scaler", C.c_int32), ("relabel_ids", C.c_int32 * 2), ("head_widths", C.c_int32 * 4), ("page_sizes", C.POINTER(C.c_int32))]
+
+
+RING_STEPS = 16            # LayoutModel::RING_STEPS: the longest device-fed run
+
+
 def _relative_position_index(ws: int) -> torch.Tensor:
     """surya/common/donut/encoder.py:348-359."""
     coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
@@ -254,9 +262,101 @@ class HipLayoutModel:
                 "surya_layout_decode_step")
         return self._cls[: self.batch].copy(), self._box[: self.batch].copy()
 
+    # ---------------------------------------------------------------------------------------------- device-fed decode steps (round 4)
+    def set_feedback(self, page_sizes=None):
+        """The constants of the fed-back token rule and, for the layout family, each row's slice size [(width, height)] for the
+        PageHeader / PageFooter rule (None = rule off). After encode() / select(), before the first decode_steps()."""
+        d = self.cfg.decoder
+        fb = LayoutFeedbackC()
+        if self.is_table:
+            widths = [n for k, n in d.head_widths() if k != "bbox"]
+            fb.head_widths[:] = widths
+            fb.relabel_ids[:] = [-1, -1]
+        else:
+            from .config import ID_TO_LABEL
+            ids = {v: k for k, v in ID_TO_LABEL.items()}
+            fb.skew_scaler = d.skew_scaler
+            fb.relabel_ids[:] = [ids["PageHeader"] + d.special_token_count, ids["PageFooter"] + d.special_token_count]
+        keep = None
+        if page_sizes is not None and not self.is_table:
+            keep = np.ascontiguousarray(page_sizes, np.int32).reshape(self.batch, 2)
+            fb.page_sizes = L.np_ptr(keep)
+        L.check(self.lib.surya_layout_set_feedback(self.handle, C.byref(fb), C.c_int(self.batch), self._stream), "surya_layout_set_feedback")
+
+    def decode_steps(self, boxes, position: int, n_steps: int, ring: int = 0):
+        """Enqueue n_steps (<= RING_STEPS) decode steps from cache position `position` whose fed-back tokens stay on the device; boxes
+        int32 [B, token width] feeds the first of them from the host, None continues from the previous run. Records go to ring `ring`."""
+        b = None
+        if boxes is not None:
+            b = np.ascontiguousarray(boxes, np.int32).reshape(self.batch, self.tok_width)
+        L.check(self.lib.surya_layout_decode_steps(self.handle, L.np_ptr(b) if b is not None else None, C.c_int(self.batch), C.c_int(position),
+                                                   C.c_int(n_steps), C.c_int(ring), self._stream), "surya_layout_decode_steps")
+
+    def wait_steps(self, n_steps: int, ring: int = 0):
+        """(class_logits [n, B, label_count], bbox [n, B, 6], fed_tokens [n, B, token width]) of the run enqueued into ring `ring`."""
+        cls = np.empty((n_steps, self.batch, self.label_count), np.float32)
+        box = np.empty((n_steps, self.batch, 6), np.float32)
+        tok = np.empty((n_steps, self.batch, self.tok_width), np.int32)
+        L.check(self.lib.surya_layout_wait_steps(self.handle, C.c_int(ring), C.c_int(self.batch), C.c_int(n_steps), L.np_ptr(cls, C.c_float),
+                                                 L.np_ptr(box, C.c_float), L.np_ptr(tok)), "surya_layout_wait_steps")
+        return cls, box, tok
+
     def encoder_states(self) -> torch.Tensor:
         e = self.cfg.encoder
         n = (e.grid[0] >> (len(e.depths) - 1)) * (e.grid[1] >> (len(e.depths) - 1))
         out = torch.empty((self.encoded, n, e.hidden_size), dtype=self.dtype, device=self.device)
         L.check(self.lib.surya_layout_encoder_states(self.handle, L.ptr(out), C.c_int(self.encoded), self._stream), "surya_layout_encoder_states")
         return out
+
+
+class FedRuns:
+    """Step-at-a-time view of the device-fed decode runs for the predictors' greedy loops (layout/predictor.py, table_rec/predictor.py).
+
+    The loops keep the reference's shape -- one model call per emitted box, the next token derived on the host from that call's
+    outputs -- but the model calls are served from runs of `k` steps that the device feeds itself (surya_layout_decode_steps), the run
+    after the current one already enqueued while the host works through this one. `step(nxt)` takes the token the HOST derived for
+    the step and returns that step's (class_logits, bbox); it checks the host's token against the one the device fed (they are the
+    same rule implemented twice: a mismatch would mean the recorded outputs belong to a different token stream, so it raises).
+
+    `model` is a HipLayoutModel (or the CPU oracle stand-in of the tests with the same three methods)."""
+
+    def __init__(self, model, position: int, max_steps: int, k: int = 8):
+        self.m, self.pos, self.left, self.k = model, position, max_steps, max(1, min(int(k), RING_STEPS))
+        self.buf = None            # (cls, box, tok) of the run being consumed
+        self.cur = 0
+        self.pending = None        # (ring, n) of the run enqueued behind it
+        self.ring = 0
+        self.fed = None            # the token the device fed to the step that comes next
+
+    def _enqueue(self, boxes):
+        n = min(self.k, self.left)
+        if n <= 0:
+            return None
+        self.m.decode_steps(boxes, self.pos, n, self.ring)
+        run = (self.ring, n)
+        self.pos += n
+        self.left -= n
+        self.ring ^= 1
+        return run
+
+    def step(self, nxt: np.ndarray):
+        nxt = np.ascontiguousarray(nxt, np.int32)
+        if self.buf is None or self.cur >= self.buf[0].shape[0]:
+            if self.buf is None:                                  # the first step: fed from the host
+                run = self._enqueue(nxt)
+            else:
+                run = self.pending
+            if run is None:
+                raise L.SuryaAmdError("FedRuns.step: more steps requested than max_steps")
+            self.pending = self._enqueue(None)                    # keep the device busy while the host works through `run`
+            self.buf = self.m.wait_steps(run[1], run[0])
+            self.cur = 0
+        if self.fed is not None and not np.array_equal(self.fed, nxt):
+            bad = np.argwhere(self.fed != nxt)[0]
+            raise L.SuryaAmdError(f"device-fed token differs from the host's rule at row {int(bad[0])}, component {int(bad[1])}: "
+                                  f"device {self.fed[bad[0]].tolist()} vs host {nxt[bad[0]].tolist()}")
+        cls, box, tok = self.buf
+        i = self.cur
+        self.cur += 1
+        self.fed = tok[i]
+        return cls[i], box[i]

@@ -26,19 +26,37 @@ LAYOUT_SLICE_SIZE = {"height": 1200, "width": 1200}
 LAYOUT_MAX_BOXES = 100                                     # surya/settings.py:108
 
 
-def prediction_to_polygon(pred, img_size, bbox_scaler, skew_scaler, skew_min=0.001):
-    """surya/layout/util.py:4-40 on a length-7 float vector (cx, cy, w, h, xskew, yskew, label)."""
-    w_scale, h_scale = img_size[0] / bbox_scaler, img_size[1] / bbox_scaler
-    cx, cy, width, height = (float(pred[i]) for i in range(4))
-    x1, y1, x2, y2 = cx - width / 2, cy - height / 2, cx + width / 2, cy + height / 2
-    skew_x = float(np.floor((float(pred[4]) - skew_scaler) / 2))
-    skew_y = float(np.floor((float(pred[5]) - skew_scaler) / 2))
-    if abs(skew_x) < skew_min:
-        skew_x = 0.0
-    if abs(skew_y) < skew_min:
-        skew_y = 0.0
-    pts = [x1 - skew_x, y1 - skew_y, x2 - skew_x, y1 + skew_y, x2 + skew_x, y2 + skew_y, x1 + skew_x, y2 - skew_y]
-    return [[pts[2 * i] * w_scale, pts[2 * i + 1] * h_scale] for i in range(4)]
+def _round_bf16(a: np.ndarray) -> np.ndarray:
+    """fp32 values rounded to the nearest bfloat16 (ties to even), kept as fp32 -- what a bf16 tensor op leaves behind."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + 0x7FFF)) & 0xFFFF0000).view(np.float32)
+
+
+def polygons_of_predictions(preds: np.ndarray, sizes: np.ndarray, bbox_scaler, skew_scaler, skew_min=0.001, dtype="float32") -> np.ndarray:
+    """surya/layout/util.py:4-40 for a batch: preds [n, >= 6] (the fed-back token as floats), sizes [n, 2] = (width, height) ->
+    float64 [n, 4, 2]. The reference does the corner arithmetic with TENSOR ops, i.e. in the model dtype (every intermediate rounded to
+    fp32, or to bf16 for a bf16 model), and only the final `.item() * scale` in Python floats; `dtype` names that dtype."""
+    R = _round_bf16 if dtype in ("bfloat16", "bf16") else (lambda a: a)
+    p = R(np.asarray(preds, np.float32))
+    sz = np.asarray(sizes, np.float64).reshape(-1, 2)
+    w_scale, h_scale = sz[:, 0] / bbox_scaler, sz[:, 1] / bbox_scaler
+    two = np.float32(2)
+    cx, cy = p[:, 0], p[:, 1]
+    hw, hh = R(p[:, 2] / two), R(p[:, 3] / two)
+    x1, y1, x2, y2 = R(cx - hw), R(cy - hh), R(cx + hw), R(cy + hh)
+    skew_x = np.floor(R(R(p[:, 4] - np.float32(skew_scaler)) / two))
+    skew_y = np.floor(R(R(p[:, 5] - np.float32(skew_scaler)) / two))
+    skew_x = np.where(np.abs(skew_x) < skew_min, np.float32(0), skew_x)
+    skew_y = np.where(np.abs(skew_y) < skew_min, np.float32(0), skew_y)
+    xs = np.stack([R(x1 - skew_x), R(x2 - skew_x), R(x2 + skew_x), R(x1 + skew_x)], -1).astype(np.float64) * w_scale[:, None]
+    ys = np.stack([R(y1 - skew_y), R(y1 + skew_y), R(y2 + skew_y), R(y2 - skew_y)], -1).astype(np.float64) * h_scale[:, None]
+    return np.stack([xs, ys], -1)
+
+
+def prediction_to_polygon(pred, img_size, bbox_scaler, skew_scaler, skew_min=0.001, dtype="float32"):
+    """surya/layout/util.py:4-40 on one length-7 vector (cx, cy, w, h, xskew, yskew, label)."""
+    v = np.asarray([float(pred[i]) for i in range(6)], np.float32)[None]
+    return polygons_of_predictions(v, np.asarray(img_size)[None], bbox_scaler, skew_scaler, skew_min, dtype)[0].tolist()
 
 
 class LayoutImageProcessor:
@@ -149,41 +167,48 @@ class LayoutPredictor(BasePredictor):
         return results
 
     def _detect_chunk(self, chunk, orig_sizes, dcfg, top_k) -> List[LayoutResult]:
+        """The greedy box loop of surya/layout/__init__.py:110-177 for one encoder batch. One model call per box as there, served from
+        device-fed runs (model.FedRuns): the host derives every fed-back token itself and the run records are checked against it. The
+        per-step host work covers all unfinished pages at once (numpy / one batched softmax + top-k) instead of a Python loop per page."""
+        from .model import FedRuns
         n = len(chunk)
         px = torch.from_numpy(np.stack(self.processor(chunk)["pixel_values"]))
         self.model.encode(px.pin_memory().to(self.model.device, non_blocking=True).contiguous())
         assert dcfg.pause_token_count == 0, "pause tokens in the decoder prompt are not built"
+        sizes = np.asarray(orig_sizes, np.int64).reshape(n, 2)
+        self.model.set_feedback(sizes)
+        runs = FedRuns(self.model, 0, LAYOUT_MAX_BOXES, settings.LAYOUT_STEPS_PER_SYNC)
+        mdtype = "bfloat16" if getattr(self.model, "dtype", torch.float32) == torch.bfloat16 else "float32"
         boxes = np.full((n, 7), dcfg.bos_token_id, np.int32)
         preds = [[] for _ in range(n)]
         all_done = np.zeros(n, bool)
         sp = dcfg.special_token_count
+        header_footer = [k + sp for k, v in ID_TO_LABEL.items() if v in ("PageHeader", "PageFooter")]
         for position in range(LAYOUT_MAX_BOXES):
-            cls, box = self.model.decode_step(boxes, position)
+            cls, box = runs.step(boxes)
             class_preds = cls.argmax(-1)
             box_preds = box * dcfg.bbox_size
+            if mdtype == "bfloat16":
+                box_preds = _round_bf16(box_preds)                   # a tensor op in the model dtype (exact for bbox_size = 1024)
             all_done |= (class_preds == dcfg.eos_token_id) | (class_preds == dcfg.pad_token_id)
             if all_done.all():
                 break
             nxt = np.concatenate([box_preds, class_preds[:, None].astype(np.float32)], -1)      # float tokens, truncated below (:131)
-            for j in range(n):
-                if all_done[j]:
-                    continue
+            act = np.nonzero(~all_done)[0]
+            polys = polygons_of_predictions(nxt[act], sizes[act], dcfg.bbox_size, dcfg.skew_scaler, dtype=mdtype)
+            logits = cls[act].copy()
+            w, h = sizes[act, 0], sizes[act, 1]
+            # page headers / footers in the middle of a page take their next-best label (:158-169)
+            mid = (np.isin(class_preds[act], header_footer) & (polys[:, 0, 1] < h * .8) & (polys[:, 2, 1] > h * .2) & (polys[:, 0, 0] < w * .8)
+                   & (polys[:, 2, 0] > w * .2))
+            if mid.any():
+                rows = np.nonzero(mid)[0]
+                logits[rows, class_preds[act][rows]] = 0
+                nxt[act[rows], 6] = logits[rows].argmax(-1)
+            probs, idx = torch.topk(torch.softmax(torch.from_numpy(logits), dim=-1), k=top_k, dim=-1)
+            for r, j in enumerate(act):
                 p = nxt[j].copy()
-                poly = prediction_to_polygon(p, orig_sizes[j], dcfg.bbox_size, dcfg.skew_scaler)
-                label = int(p[6]) - sp
-                logits = torch.from_numpy(cls[j].copy())
-                text_label = ID_TO_LABEL.get(label)
-                w, h = orig_sizes[j]
-                if (text_label in ("PageHeader", "PageFooter") and poly[0][1] < h * .8 and poly[2][1] > h * .2 and poly[0][0] < w * .8
-                        and poly[2][0] > w * .2):
-                    # page headers / footers in the middle of a page take their next-best label (:158-169)
-                    logits[int(p[6])] = 0
-                    new = int(logits.argmax(-1))
-                    label = new - sp
-                    p[6] = new
-                    nxt[j, 6] = new
-                probs, idx = torch.topk(torch.softmax(logits, dim=-1), k=top_k, dim=-1)
-                preds[j].append({"token": p, "polygon": poly, "label": label, "top_k_probs": probs, "top_k_indices": idx})
+                preds[j].append({"token": p, "polygon": polys[r].tolist(), "label": int(p[6]) - sp, "top_k_probs": probs[r], "top_k_indices": idx[r]})
             boxes = nxt.astype(np.int64).astype(np.int32)
         out = []
         for j in range(n):

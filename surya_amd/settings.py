@@ -58,6 +58,9 @@ class Settings:
         # RecognitionPredictor.min_prefill_ratio (surya/recognition/__init__.py:71). Scheduling only: results do not depend on it.
         self.RECOGNITION_MIN_PREFILL_RATIO: float = _env("RECOGNITION_MIN_PREFILL_RATIO", float, 0.2)
         self.RECOGNITION_STEPS_PER_SYNC: int = _env("RECOGNITION_STEPS_PER_SYNC", int, 4)
+        # layout / table recognition: decode steps per device-fed run (the host reads the records of this many boxes at a time; the
+        # boxes after a page's end token are discarded, so results do not depend on it). 1..16.
+        self.LAYOUT_STEPS_PER_SYNC: int = _env("LAYOUT_STEPS_PER_SYNC", int, 8)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
         # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the
         # same inputs). Off by default: the reference has no collectives, and a torchrun job where every rank OCRs its own

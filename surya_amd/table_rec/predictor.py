@@ -18,7 +18,7 @@ from PIL import Image
 
 from ..common.geometry import PolygonBox
 from ..common.predictor import BasePredictor, ModelLoader
-from ..layout.model import HipLayoutModel
+from ..layout.model import FedRuns, HipLayoutModel
 from ..settings import settings
 from .config import BOX_DIM, BOX_PROPERTIES, CATEGORY_TO_ID, MAX_BOXES, MERGE_KEYS, MERGE_VALUES, SPECIAL_TOKENS, TableRecConfig, table_config
 from .processor import TableRecProcessor
@@ -106,16 +106,20 @@ class TableRecPredictor(BasePredictor):
         if T > PROMPT_CAPACITY:
             raise ValueError(f"decoder prompt of {T} tokens exceeds the {PROMPT_CAPACITY} positions kept for prompts")
         self.model.select(src_index)
+        self.model.set_feedback()
         predictions: List[List[dict]] = [[] for _ in range(n)]
         all_done = np.zeros(n, bool)
         position, token_count, step_tokens = 0, 0, T
         ids = batch_input_ids.astype(np.int32)
+        runs = None
         while token_count < TABLE_REC_MAX_BOXES:
             if position == 0:                                # the prompt: one pass over its T tokens (the reference's prefill = True call)
                 cls, box = self.model.prefill(ids)
                 position = ids.shape[1]
-            else:                                            # the one fed-back token
-                cls, box = self.model.decode_step(ids[:, 0], position)
+                # the fed-back tokens: one model call per box as in the reference, served from device-fed runs (layout/model.FedRuns)
+                runs = FedRuns(self.model, position, TABLE_REC_MAX_BOXES - T, settings.LAYOUT_STEPS_PER_SYNC)
+            else:
+                cls, box = runs.step(ids[:, 0])
                 position += 1
             props = split_property_logits(dcfg, cls)
             category = props["category"].argmax(-1)

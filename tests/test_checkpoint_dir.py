@@ -192,3 +192,31 @@ def test_table_predictor_from_checkpoint_dir(hip_lib, tmp_path):
     finally:
         tp.TABLE_REC_MAX_BOXES = old
     assert [r.model_dump() for r in a] == [r.model_dump() for r in b]
+
+
+def test_config_json_architecture_switches_are_checked_not_dropped():
+    """A config.json key the HIP engine does not read must carry the value it implements: a decoder without cross attention
+    in some layer, a non-causal decoder, a Swin without qkv bias or an encoder config without encoder_length raise a clear ValueError
+    instead of loading and computing something else; inference no-ops (dropout rates) and matching values pass."""
+    import dataclasses
+    from surya_amd.layout.config import layout_config, layout_config_from_reference_json
+    from surya_amd.table_rec.config import table_config, table_config_from_reference_json
+    cfg = layout_config("LAYOUT-TINY")
+    enc, dec = dataclasses.asdict(cfg.encoder), dataclasses.asdict(cfg.decoder)
+    n = dec["num_hidden_layers"]
+    ok = {"encoder": {**enc, "drop_path_rate": 0.1, "qkv_bias": True, "hidden_act": "gelu"},
+          "decoder": {**dec, "cross_attn_layers": list(range(n)), "double_residual_flow": True, "attention_dropout": 0.1, "causal": True}}
+    assert dataclasses.replace(layout_config_from_reference_json(ok), name=cfg.name) == cfg
+    for where, key, value in (("decoder", "cross_attn_layers", [0]), ("decoder", "causal", False), ("decoder", "double_residual_flow", False),
+                              ("decoder", "hidden_activation", "silu"), ("encoder", "qkv_bias", False), ("encoder", "use_absolute_embeddings", True)):
+        bad = {"encoder": dict(ok["encoder"]), "decoder": dict(ok["decoder"])}
+        bad[where][key] = value
+        with pytest.raises(ValueError, match=key):
+            layout_config_from_reference_json(bad)
+    no_len = {"encoder": {k: v for k, v in enc.items() if k != "encoder_length"}, "decoder": dec}
+    with pytest.raises(ValueError, match="encoder_length"):
+        layout_config_from_reference_json(no_len)
+    tcfg = table_config("TABLE-TINY")
+    tenc, tdec = dataclasses.asdict(tcfg.encoder), dataclasses.asdict(tcfg.decoder)
+    with pytest.raises(ValueError, match="double_residual_flow"):
+        table_config_from_reference_json({"encoder": tenc, "decoder": {**tdec, "double_residual_flow": True}})

@@ -15,7 +15,8 @@ from surya_amd.synth import make_layout_weights
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = [("LAYOUT-TINY", "layout_tiny.pt"), ("LAYOUT-SMALL", "layout_small.pt"), ("LAYOUT-DEFAULT", "layout_default.pt")]
+CASES = [("LAYOUT-TINY", "layout_tiny.pt"), ("LAYOUT-SMALL", "layout_small.pt"), ("LAYOUT-DEFAULT", "layout_default.pt"),
+         ("LAYOUT-PAD", "layout_pad.pt")]          # LAYOUT-PAD: 176 x 208 pixels, stage grids 44 x 52 / 22 x 26 / 11 x 13 -- every Swin block pads to whole windows
 
 
 def _pixels(cfg, batch, seed):
@@ -56,7 +57,7 @@ def test_layout_encoder_and_teacher_forced_decoder(hip_lib, name, fixture, dtype
     print(f"{name} {dtype}: encoder err {err_e:.2e} (max {g['encoder_absmax']:.2f}), worst class-logit err {worst_c:.2e} x max, worst box err {worst_b:.2e}")
 
 
-@pytest.mark.parametrize("name,fixture", CASES[:2])
+@pytest.mark.parametrize("name,fixture", CASES[:2] + CASES[3:])
 def test_layout_free_running_tokens_fp32(hip_lib, name, fixture):
     """The greedy loop of LayoutPredictor (feed back box * bbox_size and the argmax class): fp32 mode reproduces the reference's tokens."""
     g = torch.load(os.path.join(GOLD, fixture))

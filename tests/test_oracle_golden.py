@@ -214,7 +214,8 @@ def test_host_assembly_and_tokenizer_match_reference_vectors():
 
 
 # ------------------------------------------------------------------------------------------ layout model family
-@pytest.mark.parametrize("name,fixture", [("LAYOUT-TINY", "layout_tiny.pt"), ("LAYOUT-SMALL", "layout_small.pt"), ("LAYOUT-DEFAULT", "layout_default.pt")])
+@pytest.mark.parametrize("name,fixture", [("LAYOUT-TINY", "layout_tiny.pt"), ("LAYOUT-SMALL", "layout_small.pt"), ("LAYOUT-DEFAULT", "layout_default.pt"),
+                                          ("LAYOUT-PAD", "layout_pad.pt")])
 def test_layout_oracle_matches_reference(name, fixture):
     """oracle/layout_oracle.py (Donut-Swin encoder + ADETR decoder with cross / self attention) against fixtures recorded from the
     reference's own DonutSwinLayoutModel / SuryaLayoutDecoder (oracle/make_golden_layout.py): encoder output, and -- teacher-forced on

@@ -960,6 +960,12 @@ def test_live_layout_host_logic_against_reference():
             tok = torch.tensor(rng.integers(0, 1025, size=7).astype(np.float32))
             size = (int(rng.integers(50, 3000)), int(rng.integers(50, 3000)))
             assert lp.prediction_to_polygon(tok.numpy(), size, 1024, 512) == ru.prediction_to_polygon(tok, size, 1024, 512)
+            # what the loop really passes: sigmoid * 1024 in the model dtype -- the reference's corner arithmetic is tensor arithmetic in
+            # THAT dtype (fp32 on the CPU path, bf16 on its GPU path), only the final scaling is Python floats
+            frac = torch.tensor((rng.random(7) * 1024).astype(np.float32))
+            assert lp.prediction_to_polygon(frac.numpy(), size, 1024, 512) == ru.prediction_to_polygon(frac, size, 1024, 512)
+            half = frac.to(torch.bfloat16)
+            assert lp.prediction_to_polygon(half.float().numpy(), size, 1024, 512, dtype="bfloat16") == ru.prediction_to_polygon(half, size, 1024, 512)
         # merging per-slice results: same boxes on both sides
         labels = ["Text", "Picture", "Figure", "Table", "SectionHeader"]
 

@@ -36,7 +36,7 @@ def bucket(name):
     if m:
         bm, bn = int(m.group(1)), int(m.group(2))
         if bm >= 128 and bn >= 128:
-            return "gemm_nt 128x128 / 256x256 (encoder + prefill GEMMs, lm_head)"
+            return "gemm_nt 128x128 / 256x256 / 256x320 (encoder + prefill GEMMs, lm_head)"
         return "gemm_nt tall 256x{32,64} (decode-step GEMMs, M<=256)" if bm == 256 else "gemm_nt small tiles"
     return "conv_gemm (implicit-GEMM convolutions, NHWC)" if "conv_gemm_kernel" in name else None
 
