@@ -578,8 +578,8 @@ struct LayoutModel : LayoutBase {
     // ------------------------------------------------------------------------------------------------ device-fed decode steps (round 4)
     // n_steps decode steps whose fed-back tokens never leave the device (lay::layout_heads_kernel<T, true>), recorded in ring `ring`
     // ([step][row] class logits / boxes / fed tokens); one D2H copy + event at the end, no host synchronisation: the caller enqueues
-    // the next run before it waits for this one. A run is replayed as a hipGraph once its (rows, steps) shape has been seen twice;
-    // the cache position lives in len_dev, so the position is not part of the shape.
+    // the next run before it waits for this one. With surya_set_tuning("graph", 1) a run is replayed as a hipGraph once its (rows,
+    // steps) shape has been seen twice (the cache position lives in len_dev, so it is not part of the shape); measured slower, off by default.
     static constexpr int RING_STEPS = 16;
     float *cls_ring = nullptr, *box_ring = nullptr;
     int *tok_ring = nullptr, *page_sizes_dev = nullptr;
@@ -684,7 +684,9 @@ struct LayoutModel : LayoutBase {
         fed_ready = false;
         const long key = (long)B * 64 + n_steps + (long)ring * (1L << 40);
         bool replayed = false;
-        if (use_graph && tuning().graph != 2 && !gemm_profiler().enabled) {                 // surya_set_tuning("graph", 2): plain launches for the layout runs too
+        // hipGraph replay is opt-in (surya_set_tuning("graph", 1)), as for the recogniser: a run is ~1400 kernel nodes and the replay measured
+        // SLOWER than plain launches enqueued ahead of the device (gpurun r04e / r04f, 32 pages: 628 vs 552 us per step; host-fed loop 570-587)
+        if (use_graph && tuning().graph == 1 && !gemm_profiler().enabled) {
             auto it = graphs.find(key);
             if (it == graphs.end() && seen_keys.count(key)) {
                 hipGraph_t g = nullptr;

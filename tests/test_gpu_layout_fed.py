@@ -95,6 +95,7 @@ def test_layout_graph_replay_equals_eager_and_fedruns_serves_single_steps(hip_li
     d = cfg.decoder
     B = 4
     m = HipLayoutModel(cfg, make_layout_weights(cfg, 0), dtype=torch.bfloat16, max_batch=4, max_boxes=40)
+    L.check(m.lib.surya_set_tuning(b"graph", C.c_int(1)), "surya_set_tuning(graph)")          # replay is opt-in (measured slower than plain launches)
     px = _pixels(cfg, B, 3).cuda().contiguous()
     first = np.full((B, 7), d.bos_token_id, np.int32)
     sizes = np.array([[612, 792]] * B, np.int32)
@@ -131,6 +132,7 @@ def test_layout_graph_replay_equals_eager_and_fedruns_serves_single_steps(hip_li
     wrong[1, 6] += 1
     with pytest.raises(L.SuryaAmdError, match="device-fed token differs"):
         fr.step(wrong)
+    L.check(m.lib.surya_set_tuning(b"graph", C.c_int(0)), "surya_set_tuning(graph)")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
