@@ -1,87 +1,101 @@
-"""Large pages are cut into slices along their long axis before layout detection and the per-slice results merged afterwards
-(host logic of surya/layout/slicer.py:11-139: same thresholds, same merge rule)."""
+"""ImageSlicer: pages that are too large for one pass of the layout model are cut into strips along their long side and the per-strip
+LayoutResults stitched back together (drop-in for surya/layout/slicer.py:11-139: same thresholds, same strip geometry, same merge rule
+for boxes that a cut went through).
+
+The geometry lives in one place (`_strips`): a page is either left whole or cut into equal steps of max(slice size, side // max_slices
++ 1) pixels along the longer side, the last strip taking what is left."""
 from __future__ import annotations
 
-import math
 from typing import List, Tuple
 
 from PIL import Image
 
 from .schema import LayoutResult
 
+_AXES = {"width": 0, "height": 1}
+
 
 class ImageSlicer:
-    merge_tolerance = .05
-    merge_margin = .05
+    merge_tolerance = .05            # share of a box that must lie inside its neighbour (after the margin) to count as touching
+    merge_margin = .05               # boxes are widened by this share of the smaller one, across the cut, before that test
 
     def __init__(self, slice_min_dims, slice_sizes, max_slices=4):
         self.slice_min_dims, self.slice_sizes, self.max_slices = slice_min_dims, slice_sizes, max_slices
 
-    def _slice_size(self, dimension: int, dim_type: str) -> int:
-        return max(self.slice_sizes[dim_type], dimension // self.max_slices + 1)
+    # ------------------------------------------------------------------------------------------------------------- geometry
+    def _step(self, size: Tuple[int, int]):
+        """(name of the long side, strip length along it)."""
+        side = "width" if size[0] > size[1] else "height"
+        extent = size[_AXES[side]]
+        return side, max(self.slice_sizes[side], extent // self.max_slices + 1)
 
-    def slice_count(self, image: Image.Image) -> int:
-        w, h = image.size
-        return math.ceil(w / self._slice_size(w, "width")) if w > h else math.ceil(h / self._slice_size(h, "height"))
-
-    def slice(self, images: List[Image.Image]):
-        slices, positions = [], []
-        for idx, image in enumerate(images):
-            w, h = image.size
-            if w > self.slice_min_dims["width"] or h > self.slice_min_dims["height"]:
-                if w > h:
-                    size = self._slice_size(w, "width")
-                    for i, x in enumerate(range(0, w, size)):
-                        slices.append(image.crop((x, 0, min(x + size, w), h)))
-                        positions.append((idx, i, 0))
-                else:
-                    size = self._slice_size(h, "height")
-                    for i, y in enumerate(range(0, h, size)):
-                        slices.append(image.crop((0, y, w, min(y + size, h))))
-                        positions.append((idx, 0, i))
-            else:
-                slices.append(image)
-                positions.append((idx, 0, 0))
-        return slices, positions
-
-    def join(self, results: List[LayoutResult], tile_positions: List[Tuple[int, int, int]]) -> List[LayoutResult]:
-        out, cur = [], None
-        for idx, (result, (image_idx, tile_x, tile_y)) in enumerate(zip(results, tile_positions)):
-            if idx == 0 or image_idx != tile_positions[idx - 1][0]:
-                if cur is not None:
-                    out.append(cur)
-                cur = result
-            else:
-                cur = self.merge_results(cur, result, "width" if tile_x > 0 else "height")
-        if cur is not None:
-            out.append(cur)
+    def _strips(self, size: Tuple[int, int]):
+        """[(crop box, (tile_x, tile_y))] of a page; one whole-page entry when the page is within the minimum dimensions."""
+        w, h = size
+        if w <= self.slice_min_dims["width"] and h <= self.slice_min_dims["height"]:
+            return [((0, 0, w, h), (0, 0))]
+        side, step = self._step(size)
+        out = []
+        for k, start in enumerate(range(0, size[_AXES[side]], step)):
+            stop = min(start + step, size[_AXES[side]])
+            out.append(((start, 0, stop, h), (k, 0)) if side == "width" else ((0, start, w, stop), (0, k)))
         return out
 
-    def merge_results(self, res1: LayoutResult, res2: LayoutResult, merge_dir="width") -> LayoutResult:
-        bbox = res1.image_bbox.copy()
-        remove = set()
-        horizontal = merge_dir == "width"
-        if horizontal:
-            bbox[2] += res2.image_bbox[2]
-        else:
-            bbox[3] += res2.image_bbox[3]
-        max_position = max([box.position for box in res1.bboxes]) + 1       # (raises on an empty first slice, as the reference does)
-        for i, box2 in enumerate(res2.bboxes):
-            if horizontal:
-                box2.shift(x_shift=res1.image_bbox[2])
+    def slice_count(self, image: Image.Image) -> int:
+        """Strips a page WOULD be cut into (the batching of LayoutPredictor counts them for every page, small ones included)."""
+        side, step = self._step(image.size)
+        return -(-image.size[_AXES[side]] // step)
+
+    def slice(self, images: List[Image.Image]):
+        pieces, positions = [], []
+        for index, image in enumerate(images):
+            strips = self._strips(image.size)
+            for box, (tx, ty) in strips:
+                pieces.append(image if len(strips) == 1 and box == (0, 0) + image.size else image.crop(box))
+                positions.append((index, tx, ty))
+        return pieces, positions
+
+    # -------------------------------------------------------------------------------------------------------------- stitching
+    def join(self, results: List[LayoutResult], tile_positions: List[Tuple[int, int, int]]) -> List[LayoutResult]:
+        pages: List[LayoutResult] = []
+        last_page = None
+        for result, (page, tile_x, _tile_y) in zip(results, tile_positions):
+            if page != last_page:
+                pages.append(result)
             else:
-                box2.shift(y_shift=res1.image_bbox[3])
-            box2.position += max_position
-            for box1 in res1.bboxes:
-                margin = {"x_margin": self.merge_margin} if horizontal else {"y_margin": self.merge_margin}
-                touch = (box1.intersection_pct(box2, **margin) > self.merge_tolerance or
-                         box2.intersection_pct(box1, **margin) > self.merge_tolerance)
-                if horizontal:
-                    aligned = box1.y_overlap(box2) > box1.height // 2 or box2.y_overlap(box1) > box2.height // 2
-                else:
-                    aligned = box1.x_overlap(box2) > box1.width // 2 or box2.x_overlap(box1) > box2.width // 2
-                same = box1.label == box2.label or (box1.label in ["Picture", "Figure"] and box2.label in ["Picture", "Figure"])
-                if touch and aligned and same:
-                    box1.merge(box2)
-                    remove.add(i)
-        return LayoutResult(image_bbox=bbox, bboxes=res1.bboxes + [b for i, b in enumerate(res2.bboxes) if i not in remove], sliced=True)
+                pages[-1] = self.merge_results(pages[-1], result, "width" if tile_x > 0 else "height")
+            last_page = page
+        return pages
+
+    def _continues(self, first, second, across: str) -> bool:
+        """`second` (already shifted into page coordinates) is the part of `first` beyond a cut made across `across`."""
+        margin = {"x_margin" if across == "width" else "y_margin": self.merge_margin}
+        touching = max(first.intersection_pct(second, **margin), second.intersection_pct(first, **margin)) > self.merge_tolerance
+        if across == "width":
+            lined_up = first.y_overlap(second) > first.height // 2 or second.y_overlap(first) > second.height // 2
+        else:
+            lined_up = first.x_overlap(second) > first.width // 2 or second.x_overlap(first) > second.width // 2
+        pictures = ("Picture", "Figure")
+        alike = first.label == second.label or (first.label in pictures and second.label in pictures)
+        return touching and lined_up and alike
+
+    def merge_results(self, res1: LayoutResult, res2: LayoutResult, merge_dir="width") -> LayoutResult:
+        """res2 = the strip after res1 along `merge_dir`: its boxes move by res1's extent and continue res1's reading order; a box that
+        continues one of res1's boxes is absorbed by it (the absorbing box grows at once, so it may swallow further parts)."""
+        axis = _AXES[merge_dir]
+        page_box = list(res1.image_bbox)
+        page_box[2 + axis] += res2.image_bbox[2 + axis]
+        offset = res1.image_bbox[2 + axis]
+        next_position = max(box.position for box in res1.bboxes) + 1        # (an empty first strip raises, as in the reference)
+        kept = []
+        for part in res2.bboxes:
+            part.shift(**({"x_shift": offset} if axis == 0 else {"y_shift": offset}))
+            part.position += next_position
+            absorbed = False
+            for whole in res1.bboxes:
+                if self._continues(whole, part, merge_dir):
+                    whole.merge(part)
+                    absorbed = True
+            if not absorbed:
+                kept.append(part)
+        return LayoutResult(image_bbox=page_box, bboxes=res1.bboxes + kept, sliced=True)

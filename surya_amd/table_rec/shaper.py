@@ -1,7 +1,12 @@
-"""LabelShaper: token vectors <-> box property dicts of the table-recognition decoder (surya/table_rec/shaper.py:8-145).
+"""LabelShaper: the token layout of the table-recognition decoder (drop-in for surya/table_rec/shaper.py:8-145).
 
-A token is BOX_PROPERTIES laid end to end: bbox (cx, cy, w, h, xskew + 512, yskew + 512) | category + 5 | merges + 5 | colspan |
-is_header + 5 (classification values are shifted past the 5 special tokens on the way INTO the model)."""
+A decoder token is a row of numbers, one span per box property in BOX_PROPERTIES order:
+
+    bbox (cx, cy, w, h, xskew + 512, yskew + 512) | category + 5 | merges + 5 | colspan | is_header + 5
+
+regression properties take as many columns as they have values, classification properties one column holding the class index shifted
+past the 5 special tokens. The conversions work on whole batches as float64 matrices (the reference walks dicts item by item; the
+numbers it produces are the ones below, tests/test_oracle_vs_reference.py holds the two equal on random inputs)."""
 from __future__ import annotations
 
 import math
@@ -11,79 +16,85 @@ import numpy as np
 
 from .config import BOX_DIM, BOX_PROPERTIES, SPECIAL_TOKENS
 
+# corner k of a box = centre + SIGN[k] * half extent, then skewed by SKEW[k] * skew: TL, TR, BR, BL
+_CORNER_SIGN = ((-1, -1), (1, -1), (1, 1), (-1, 1))
+_SKEW_SIGN = ((-1, -1), (-1, 1), (1, 1), (1, -1))
+
 
 class LabelShaper:
     def __init__(self):
-        self.property_keys = [k for k, _, _ in BOX_PROPERTIES]
+        self.property_keys = [name for name, _, _ in BOX_PROPERTIES]
+        self._kind = {name: kind for name, _, kind in BOX_PROPERTIES}
+        self._values = {name: count for name, count, _ in BOX_PROPERTIES}
+        self._span, column = {}, 0
+        for name in self.property_keys:
+            width = self._values[name] if self._kind[name] == "regression" else 1
+            self._span[name] = (column, column + width)
+            column += width
+        self._columns = column
 
-    def dict_to_labels(self, label_components: List[dict]):
-        """:12-51. Clamps each bbox to [0, BOX_DIM] IN PLACE (the predictor's stored predictions see the clamp), then flattens."""
-        if not label_components:
-            return []
-        for k, kcount, mode in BOX_PROPERTIES:
-            for lc in label_components:
-                if k not in lc:
-                    raise ValueError(f"Missing key {k} in label component {lc}")
-                if mode == "classification":
-                    assert isinstance(lc[k], int)
-                else:
-                    assert (isinstance(lc[k], (int, float)) and kcount == 1) or len(lc[k]) == kcount
-        out = []
-        for lc in label_components:
-            bbox = lc["bbox"]
-            for i in range(len(bbox)):
-                bbox[i] = 0 if bbox[i] < 0 else (BOX_DIM if bbox[i] > BOX_DIM else bbox[i])
-            vec = []
-            for k, _, mode in BOX_PROPERTIES:
-                item = lc[k]
-                if isinstance(item, (list, tuple)):
-                    vec += list(item)
-                elif isinstance(item, (float, int)):
-                    vec.append(item + SPECIAL_TOKENS if mode == "classification" else item)
-                else:
-                    raise ValueError(f"Invalid item {item} for key {k}")
-            out.append(vec)
-        return out
-
+    # ---------------------------------------------------------------------------------------------------------- token layout
     def component_idx(self, key):
-        idx = 0
-        for k, kcount, mode in BOX_PROPERTIES:
-            incr = kcount if mode == "regression" else 1
-            if k == key:
-                return idx, idx + incr
-            idx += incr
-        raise ValueError(f"Key {key} not found in properties")
-
-    def get_box_property(self, key, add_special_tokens=True):
-        for k, kcount, mode in BOX_PROPERTIES:
-            if k == key:
-                return k, kcount + (SPECIAL_TOKENS if mode == "classification" and add_special_tokens else 0), mode
-        raise ValueError(f"Key {key} not found in properties")
+        if key not in self._span:
+            raise ValueError(f"{key!r} is not a box property")
+        return self._span[key]
 
     def component_idx_dict(self):
-        return {k: self.component_idx(k) for k, _, _ in BOX_PROPERTIES}
+        return dict(self._span)
+
+    def get_box_property(self, key, add_special_tokens=True):
+        """(name, number of classes or values, kind); classification heads also cover the special tokens unless told otherwise."""
+        if key not in self._kind:
+            raise ValueError(f"{key!r} is not a box property")
+        extra = SPECIAL_TOKENS if (add_special_tokens and self._kind[key] == "classification") else 0
+        return key, self._values[key] + extra, self._kind[key]
+
+    # ------------------------------------------------------------------------------------------------------- dicts -> tokens
+    def dict_to_labels(self, label_components: List[dict]):
+        """Property dicts -> token rows. Every bbox is clamped to [0, BOX_DIM] IN its dict first (the predictor keeps those dicts as its
+        predictions, so they see the clamp, shaper.py:24-27)."""
+        n = len(label_components)
+        if n == 0:
+            return []
+        rows = np.zeros((n, self._columns), np.float64)
+        for name, (lo, hi) in self._span.items():
+            try:
+                column = [item[name] for item in label_components]
+            except KeyError:
+                raise ValueError(f"a label component has no {name!r} entry") from None
+            if self._kind[name] == "classification":
+                assert all(isinstance(v, int) for v in column), f"{name}: class indices must be ints"
+                rows[:, lo] = np.asarray(column, np.float64) + SPECIAL_TOKENS
+                continue
+            values = np.asarray(column, np.float64).reshape(n, -1)
+            assert values.shape[1] == hi - lo, f"{name}: {hi - lo} values per box expected"
+            if name == "bbox":
+                values = np.clip(values, 0, BOX_DIM)
+                for item, clamped in zip(label_components, values.tolist()):
+                    item["bbox"][:] = clamped
+            rows[:, lo:hi] = values
+        return rows.tolist()
 
     def convert_polygons_to_bboxes(self, label_components: List[Dict]):
-        """:82-111: 4 corners -> (cx, cy, w, h, xskew, yskew) with the skews shifted by BOX_DIM // 2 into positive space."""
-        for lc in label_components:
-            poly = np.clip(lc["polygon"], 0, BOX_DIM)
-            (x1, y1), (x2, y2), (x3, y3), (x4, y4) = poly
-            cx, cy = (x1 + x2 + x3 + x4) / 4, (y1 + y2 + y3 + y4) / 4
-            width, height = (x2 + x3) / 2 - (x1 + x4) / 2, (y3 + y4) / 2 - (y2 + y1) / 2
-            x_skew = (x3 + x4) / 2 - (x1 + x2) / 2 + BOX_DIM // 2
-            y_skew = (y2 + y3) / 2 - (y1 + y4) / 2 + BOX_DIM // 2
-            lc["bbox"] = [cx, cy, width, height, x_skew, y_skew]
+        """4 corners (clipped to the box space) -> bbox (cx, cy, w, h, xskew, yskew), the skews shifted by BOX_DIM // 2 into positive
+        numbers (:82-111). Sums are written corner by corner: the order of the additions is part of the result."""
+        if not label_components:
+            return label_components
+        p = np.clip(np.asarray([item["polygon"] for item in label_components], np.float64), 0, BOX_DIM)
+        x, y = p[:, :, 0], p[:, :, 1]
+        (x1, x2, x3, x4), (y1, y2, y3, y4) = x.T, y.T
+        bbox = np.stack([(x1 + x2 + x3 + x4) / 4, (y1 + y2 + y3 + y4) / 4,
+                         (x2 + x3) / 2 - (x1 + x4) / 2, (y3 + y4) / 2 - (y2 + y1) / 2,
+                         (x3 + x4) / 2 - (x1 + x2) / 2 + BOX_DIM // 2, (y2 + y3) / 2 - (y1 + y4) / 2 + BOX_DIM // 2], -1)
+        for item, row in zip(label_components, bbox.tolist()):
+            item["bbox"] = row
         return label_components
 
+    # ------------------------------------------------------------------------------------------------------- tokens -> shapes
     def convert_bbox_to_polygon(self, box, skew_scaler=BOX_DIM // 2, skew_min=.001):
-        """:113-145."""
-        cx, cy, width, height = box[0], box[1], box[2], box[3]
-        x1, y1, x2, y2 = cx - width / 2, cy - height / 2, cx + width / 2, cy + height / 2
-        skew_x = math.floor((box[4] - skew_scaler) / 2)
-        skew_y = math.floor((box[5] - skew_scaler) / 2)
-        if abs(skew_x) < skew_min:
-            skew_x = 0
-        if abs(skew_y) < skew_min:
-            skew_y = 0
-        flat = [x1 - skew_x, y1 - skew_y, x2 - skew_x, y1 + skew_y, x2 + skew_x, y2 + skew_y, x1 + skew_x, y2 - skew_y]
-        return [[flat[2 * i], flat[2 * i + 1]] for i in range(4)]
+        """bbox -> its 4 corners TL, TR, BR, BL (:113-145): whole-number skews (floor of half the shifted value), none below skew_min."""
+        centre, half = (box[0], box[1]), (box[2] / 2, box[3] / 2)
+        skew = [math.floor((box[4 + axis] - skew_scaler) / 2) for axis in (0, 1)]
+        skew = [0 if abs(s) < skew_min else s for s in skew]
+        return [[centre[axis] + sign[axis] * half[axis] + lean[axis] * skew[axis] for axis in (0, 1)]
+                for sign, lean in zip(_CORNER_SIGN, _SKEW_SIGN)]
