@@ -1135,6 +1135,13 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
                 const int nk = a.K / Ty<TI>::KE;
                 if (tuning().persist && nk >= 2 && nk % 2 == 0) return launch_gemm_persist<TI, TO, EPI>(a, s);
             }
+            // bigtile = 2: the same tile on FOUR waves (128 x 128 per wave, 256 accumulator registers in AGPRs, one wave per SIMD):
+            // two thirds of the LDS fragment bytes per MFMA of the 8-wave layout (32 KB per 64 MFMAs instead of 24 KB per 32). A third
+            // stage does not fit (3 x 64 KB > 160 KB of LDS). Same K order and MFMA: bit-identical outputs.
+            // A/B: tools/microbench/bigtile_ab.py 1 2.
+            if constexpr (sizeof(TI) == 2 && EPI != EPI_ARGMAX) {
+                if (bigtile == 2) return launch_gemm_cfg<TI, TO, 256, 256, 2, 2, EPI, false, 2>(a, s);
+            }
             return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
         }
     }
