@@ -76,6 +76,7 @@ def parse():
                     help="A/B aid: sa::Tuning launch-policy knob set through surya_set_tuning before anything runs (e.g. bigtile=0)")
     ap.add_argument("--layout-only", action="store_true", help="profiling aid: run only the layout + table_rec legs and print their objects")
     ap.add_argument("--texify-only", action="store_true", help="profiling aid: run only the texify leg and print its object")
+    ap.add_argument("--e2e-only", action="store_true", help="profiling aid: run only the end-to-end leg (configs[3]) and print its object")
     ap.add_argument("--e2e-pages", type=int, default=128)
     ap.add_argument("--host-profile", action="store_true", help="cProfile one extra untimed pass of the device loop (stderr)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for smoke tests)")
@@ -542,6 +543,26 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
         passes.append((time.perf_counter() - t0, phases))
     passes.sort(key=lambda x: x[0])
     dt, phases = passes[1]
+    # the serial schedule of the same call (detect every page, then recognise: the reference's order) for comparison, and the check
+    # that the streamed call's OCRResults are the serial call's field for field
+    serial = None
+    if world == 1 and getattr(pred, "stream_detection", False) and phases.get("streamed"):
+        pred.stream_detection = False
+        try:
+            one()
+            sp = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o_ser, _, ph = one()
+                torch.cuda.synchronize()
+                sp.append((time.perf_counter() - t0, ph))
+            sp.sort(key=lambda x: x[0])
+            serial = {"wall_ms": round(sp[1][0] * 1e3, 1), "phases_ms": {k: round(v, 1) for k, v in sp[1][1].items()},
+                      "results_identical_to_streamed": bool(len(o_ser) == len(o) and all(a.model_dump() == b.model_dump()
+                                                                                         for a, b in zip(o_ser, o)))}
+        finally:
+            pred.stream_detection = True
     # detection alone, for the split of the wall time (not part of the timed passes above)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -566,9 +587,12 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
             "recognise_phases_ms": {k: round(v, 1) for k, v in phases.items()},
             "tokens": int(sum(len(c.chars) for r in o for c in r.text_lines)),
             "detected_boxes": int(sum(len(r.bboxes) for r in d)),
+            "serial_schedule": serial,
             "note": "wall clock of ONE RecognitionPredictor.__call__(images, det_predictor=DetectionPredictor): PIL pages in, OCRResult out; "
                     "the recogniser is fed by the detector's own boxes (heat-map plane 0 replaced by the drawn text rows after each forward, "
-                    "see docstring); host pre/post-processing, H2D / D2H and continuous-batching refills included; max_tokens="
+                    "see docstring); host pre/post-processing, H2D / D2H and continuous-batching refills included; streamed: the detector "
+                    "feeds the continuous-batching loop batch by batch (lines of the first pages decode while later pages are detected), "
+                    "serial_schedule = the same call with RECOGNITION_STREAM_DETECTION=0; max_tokens="
                     f"{args.max_tokens}"}
 
 
@@ -986,6 +1010,9 @@ def main():
         return
     RecognitionPredictor.model_loader_cls = Loader
     pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
+    if args.e2e_only:
+        print(json.dumps(bench_e2e(args, pred, local_rank, world, rank, lambda: None)), flush=True)
+        return
     # The workload is ONE list of args.lines x world crops (seed 1234), widest first -- the predictor's own ordering -- dealt round-robin
     # to the ranks exactly as RecognitionPredictor.sharded_prediction_loop deals them (surya_amd.dist.shard_indices): every rank
     # gets args.lines lines of the same width mix (weak scaling). At N = 1 this is the round-2 workload unchanged.

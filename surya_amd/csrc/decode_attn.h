@@ -521,7 +521,14 @@ __global__ __launch_bounds__(256) void decode_attn_flash_kernel(const float* __r
 //     separates the per-wave flash pass from the final combine.
 // Arithmetic (slab order, rounding points, MFMA order, combine) is the third version's; outputs agree to the bit unless hipcc contracts
 // the rotation differently (pinned with explicit fma / mul below).
-template <int D, int MAXG>
+// DB (round 4, long contexts -- the texify horizon of 200..970 cached keys): two K/V tile buffers. The single-buffered loop above
+// exposes every tile's fetch (barrier, issue, vmcnt(0), barrier, compute: ~5.5 us per 128 keys at 590 cached keys, of which ~1.4 are
+// compute); with DB tile t + 1 is requested right after the barrier that frees its buffer and lands while tile t is computed: one
+// barrier per tile, fetch and compute overlapped. 2 x 64 KB + the q operand = 136 KB of LDS for D = 128, i.e. one workgroup per CU:
+// the host picks DB only when some active slot's context exceeds one tile (rec_model.hip, ctx bound kept on the host), where the
+// launch has at most one workgroup per CU anyway at the task's batch (128 slots x 2 kv heads). Same arithmetic, same order: outputs
+// are bit-identical to the single-buffered kernel.
+template <int D, int MAXG, bool DB = false>
 __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __restrict__ qkv_part, int S, const bf16_t* __restrict__ qkv_bias,
                                                                  bf16_t* __restrict__ out, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                                  const int* __restrict__ active_slots, const int* __restrict__ row_len,
@@ -540,9 +547,11 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
     static_assert(D % 32 == 0 && D <= 128 && MAXG <= 32 && 1024 % ROWB == 0, "geometry");
     static_assert((MAXG + 2) * IPH <= 256 && MAXG * CW * 4 <= 32 * ROWB, "one prologue pass; a wave's records fit its own K rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;                                // [KT][ROWB], chunk c of row r at c ^ (r & XM)
-    unsigned char* Vs = Ks + KT * ROWB;                      // [KT][ROWB], linear
-    unsigned char* qT = Vs + KT * ROWB;                      // [32][ROWB] q heads (rows >= G are zero), chunk-swizzled like K
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int BUFB = 2 * KT * ROWB;                      // one tile buffer: K rows, then V rows
+    unsigned char* Ks = smem;                                // [KT][ROWB], chunk c of row r at c ^ (r & XM)      (buffer 0)
+    unsigned char* Vs = Ks + KT * ROWB;                      // [KT][ROWB], linear                                 (buffer 0)
+    unsigned char* qT = smem + NBUF * BUFB;                  // [32][ROWB] q heads (rows >= G are zero), chunk-swizzled like K
 
     SA_DA_STAMP(0)
     const int G = nq / nkv;
@@ -559,19 +568,21 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
     // Rows of tile `base` that a 16-key MFMA step can touch get finite data (cached rows, clamped duplicates past len) -- EXCEPT row
     // `len` itself: the lanes that would fill it are masked off (LDS-DMA honours EXEC), so the new token's K / V rows, which this
     // workgroup writes with ordinary LDS stores, never race with a late-landing duplicate and need no barrier of their own.
-    auto issue_tile = [&](int base) {
+    auto issue_tile = [&](int base, int buf) {
         const int rows = min(KT, (total - base + 15) & ~15);
         const int ngroups = (rows + RPI - 1) / RPI;
+        unsigned char* Kd = Ks + buf * BUFB;
+        unsigned char* Vd = Vs + buf * BUFB;
         for (int g = wave; g < ngroups; g += 4) {
             const int r = g * RPI + lane / CPR, pc = lane % CPR;
             const long j = min(base + r, max(len - 1, 0));
             if (base + r != len) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(kb + j * ROWB + ((pc ^ (r & XM)) << 4)), (lptr_t)(Ks + g * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(vb + j * ROWB + (pc << 4)), (lptr_t)(Vs + g * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(kb + j * ROWB + ((pc ^ (r & XM)) << 4)), (lptr_t)(Kd + g * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(vb + j * ROWB + (pc << 4)), (lptr_t)(Vd + g * 1024), 16, 0, 0);
             }
         }
     };
-    issue_tile(0);
+    issue_tile(0, 0);
     SA_DA_STAMP(1)
 
     // ---- prologue: this row's q / k / v = bias + sum of the split-K slabs, rounded; RoPE; all thread-local
@@ -647,20 +658,20 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
         const int c = e0 / 8, w = e0 % 8;
         store4(reinterpret_cast<T*>(rowp + ((c ^ swz) << 4)) + w, v[0] * mul, v[1] * mul, v[2] * mul, v[3] * mul);
     };
-    auto put_new_rows = [&]() {                               // K-new (rotated) and V-new rows of the tile that holds index len
+    auto put_new_rows = [&](int buf) {                        // K-new (rotated) and V-new rows of the tile that holds index len
         if (on && hh == G) {
-            lds_put4(Ks + new_row * ROWB, new_row & XM, i0, ylo, 1.f);
-            lds_put4(Ks + new_row * ROWB, new_row & XM, i0 + half, yhi, 1.f);
+            lds_put4(Ks + buf * BUFB + new_row * ROWB, new_row & XM, i0, ylo, 1.f);
+            lds_put4(Ks + buf * BUFB + new_row * ROWB, new_row & XM, i0 + half, yhi, 1.f);
         } else if (on && hh == G + 1) {
-            lds_put4(Vs + new_row * ROWB, 0, i0, ylo, 1.f);
-            lds_put4(Vs + new_row * ROWB, 0, i0 + half, yhi, 1.f);
+            lds_put4(Vs + buf * BUFB + new_row * ROWB, 0, i0, ylo, 1.f);
+            lds_put4(Vs + buf * BUFB + new_row * ROWB, 0, i0 + half, yhi, 1.f);
         }
     };
     if (on && hh < G) {
         lds_put4(qT + hh * ROWB, hh & XM, i0, ylo, scale);
         lds_put4(qT + hh * ROWB, hh & XM, i0 + half, yhi, scale);
     }
-    if (new_tile == 0) put_new_rows();
+    if (new_tile == 0) put_new_rows(0);
     SA_DA_STAMP(3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA rows of tile 0 (not tracked by the compiler)
     __syncthreads();
@@ -686,15 +697,28 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
     float mrun = -INFINITY, lrun = 0.f;
     const int tr_off = (((lane & 15) >> 2) + h * 4) * D + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;   // elements, see attn_mfma.h
     const int n_tiles = (total + KT - 1) / KT;
+    if (DB && n_tiles > 1) issue_tile(KT, 1);                // lands while tile 0 is computed (buffer 1 is untouched so far)
     for (int t = 0; t < n_tiles; ++t) {
         const int base = t * KT, nk = min(KT, total - base);
+        const int buf = DB ? (t & 1) : 0;
         if (t > 0) {
-            __syncthreads();                                 // every wave is done with the previous tile
-            issue_tile(base);
-            if (new_tile == t) put_new_rows();               // the new token's rows fall into this tile (the DMA above skips row `len`)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (DB) {
+                // tile t was requested one iteration ago into the buffer tile t - 2 has left (every wave passed the previous barrier
+                // after computing it); the new token's rows are ordinary LDS stores into rows the DMA skips
+                if (new_tile == t) put_new_rows(buf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t (nothing younger is in flight)
+                __syncthreads();                             // tile t complete for everyone; everyone is done with tile t - 1
+                if (t + 1 < n_tiles) issue_tile(base + KT, buf ^ 1);
+            } else {
+                __syncthreads();                             // every wave is done with the previous tile
+                issue_tile(base, 0);
+                if (new_tile == t) put_new_rows(0);          // the new token's rows fall into this tile (the DMA above skips row `len`)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
+        const unsigned char* Kt = Ks + buf * BUFB;
+        const unsigned char* Vt = Vs + buf * BUFB;
         const int k0 = wave * 32;
         if (k0 < nk) {                                       // wave-uniform
             f32x16 sacc;
@@ -703,7 +727,7 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
             const int krow = k0 + hl;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * ROWB + (((kk * 2 + h) ^ (krow & XM)) << 4));
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Kt + krow * ROWB + (((kk * 2 + h) ^ (krow & XM)) << 4));
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sacc, 0, 0, 0);
             }
             float bm = -INFINITY;                            // register 4g + r = key k0 + 8g + 4h + r
@@ -741,7 +765,7 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
                     pf[3] = pack2(sacc[8 * st + 6], sacc[8 * st + 7]);
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) {
-                        const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vs) + (k0 + st * 16) * D + db * 32 + tr_off;
+                        const bf16_t* vp = reinterpret_cast<const bf16_t*>(Vt) + (k0 + st * 16) * D + db * 32 + tr_off;
                         typedef short s16x4_t __attribute__((ext_vector_type(4)));
                         typedef short s16x8_t __attribute__((ext_vector_type(8)));
                         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
@@ -755,8 +779,8 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
         }
     }
     SA_DA_STAMP(5)
-    // ---- split-KV combine of the four waves: records live in each wave's own K rows (rows 32w..32w+31: read by wave w only, and the
-    // last tile's LDS-DMA has landed), so no barrier is needed before they are written
+    // ---- split-KV combine of the four waves: records live in each wave's own K rows of buffer 0 (rows 32w..32w+31: read by wave w
+    // only, in whichever tile used that buffer, and no LDS-DMA is in flight any more), so no barrier is needed before they are written
     const float ltot = lrun + __shfl_xor(lrun, 32, 64);
     if (hl < G) {
         float* rec = reinterpret_cast<float*>(Ks + wave * 32 * ROWB) + hl * CW;
@@ -802,8 +826,8 @@ __global__ __launch_bounds__(256) void decode_attn_flash2_kernel(const float* __
     SA_DA_STAMP(8)
 }
 
-template <int D, int MAXG>
-static inline size_t decode_attn_flash2_lds() { return (size_t)2 * 128 * D * 2 + (size_t)32 * D * 2 + 64; }
+template <int D, int MAXG, bool DB = false>
+static inline size_t decode_attn_flash2_lds() { return (size_t)(DB ? 2 : 1) * 2 * 128 * D * 2 + (size_t)32 * D * 2 + 64; }
 
 template <int D, int MAXG>
 static inline size_t decode_attn_flash_lds() {

@@ -200,6 +200,11 @@ struct RecModel : RecBase {
     std::set<long> seen_keys;
     bool use_graph = true;
     int graph_epoch = 0;                                 // tuning_epoch() the cached graphs were captured under
+    // Host-side upper bounds of kv_len (set at prefill, +1 per decode step of an active slot): they only pick the decode-attention
+    // variant -- two K/V tile buffers once some active context exceeds one 128-key tile -- and never enter a result.
+    std::vector<int> h_len, h_active;
+    int ctx_bound = 0;                                   // cached keys + the new one, max over the active slots, of the step being enqueued
+                                                         // (not consulted with hipGraph replay on: a captured step must not depend on host state)
     // MXFP8 decode weights (surya_rec_set_mx_weights; gemm_mx.h): e4m3 copies + e8m0 block scales of the decoder projections
     // and lm_head, used by the decode steps only (prefill keeps the bf16 weights), and MXFP8 twins of the four decode-step
     // activation buffers, written by the kernels that produce the bf16 ones.
@@ -711,7 +716,13 @@ struct RecModel : RecBase {
     }
 #define SA_DEC_MFMA(DD, GG) SA_DEC_LAUNCH((decode_attn_mfma_kernel<T, DD, GG>), (decode_attn_mfma_lds<T, DD, GG>()))
 #define SA_DEC_FLASH3(DD, GG) SA_DEC_LAUNCH((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), at8, sat, c.max_slots)
-#define SA_DEC_FLASH4(DD, GG) SA_DEC_LAUNCH((decode_attn_flash2_kernel<DD, GG>), (decode_attn_flash2_lds<DD, GG>()), at8, sat, c.max_slots)
+#define SA_DEC_FLASH4(DD, GG)                                                                                                         \
+    {                                                                                                                                 \
+        const int dbk = tuning().dattn_db;                                                                                            \
+        if (dbk == 1 || (dbk == 0 && !tuning().graph && ctx_bound > 128 && M * nkv <= 256))   /* one workgroup per CU either way */          \
+            SA_DEC_LAUNCH((decode_attn_flash2_kernel<DD, GG, true>), (decode_attn_flash2_lds<DD, GG, true>()), at8, sat, c.max_slots) \
+        else SA_DEC_LAUNCH((decode_attn_flash2_kernel<DD, GG, false>), (decode_attn_flash2_lds<DD, GG, false>()), at8, sat, c.max_slots) \
+    }
 #define SA_DEC_FLASH(DD, GG) { if (tuning().dattn == 3) SA_DEC_FLASH3(DD, GG) else SA_DEC_FLASH4(DD, GG) }
         bool launched = false;
         if constexpr (std::is_same<T, bf16_t>::value) {
@@ -847,6 +858,8 @@ struct RecModel : RecBase {
             const int a = seq_offsets[i], L = seq_offsets[i + 1] - a;
             if (L <= 0 || L >= c.max_kv_len || slot_ids[i] < 0 || slot_ids[i] >= c.max_slots) return SA_ERR_ARG;
             lens[i] = L; last_row[i] = a + L - 1;
+            if (h_len.size() < (size_t)c.max_slots) h_len.resize(c.max_slots, 0);
+            h_len[slot_ids[i]] = L;
             for (int t = 0; t < L; ++t) {
                 const int id = input_ids[a + t];
                 if (id < 0 || id >= c.vocab) return SA_ERR_ARG;
@@ -911,6 +924,9 @@ struct RecModel : RecBase {
     int set_active(const int32_t* slots, int n, hipStream_t s) override {
         if (n < 0 || n > c.max_slots) return SA_ERR_ARG;
         n_active = n;
+        for (int i = 0; i < n; ++i)
+            if (slots[i] < 0 || slots[i] >= c.max_slots) return SA_ERR_ARG;
+        h_active.assign(slots, slots + n);
         if (n == 0) return SA_OK;
         st_small.begin();
         const int* d = st_small.put(slots, n);
@@ -929,7 +945,13 @@ struct RecModel : RecBase {
         int rc;
         const Half h{0, M, part, s};
         const bool fuse = can_fuse_embed();
+        if (h_len.size() < (size_t)c.max_slots) h_len.resize(c.max_slots, 0);
         for (int step = 0; step < n_steps; ++step) {
+            ctx_bound = 0;
+            for (int a : h_active) {
+                ctx_bound = std::max(ctx_bound, h_len[a] + 1);
+                h_len[a] = std::min(h_len[a] + 1, c.max_kv_len);
+            }
             if ((step == 0 || !fuse) && (rc = decode_embed(h))) return rc;
             for (int l = 0; l < c.dec_layers; ++l)
                 if ((rc = decode_layer(l, h))) return rc;
@@ -1292,7 +1314,12 @@ int surya_op_decode_attn(int dtype, int head_dim, const float* qkv_part, int n_s
                            active_slots, row_len, cs, heads, kv_heads, max_kv_len, scale, ##__VA_ARGS__);                       \
     }
 #define SA_OPD_FLASH3(DD, GG) SA_OPD((decode_attn_flash_kernel<DD, GG>), (decode_attn_flash_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
-#define SA_OPD_FLASH4(DD, GG) SA_OPD((decode_attn_flash2_kernel<DD, GG>), (decode_attn_flash2_lds<DD, GG>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+#define SA_OPD_FLASH4(DD, GG)                                                                                                                 \
+    {   /* no host length bound at the op level: the two-buffer variant is picked by the knob alone (tests run both) */                       \
+        if (tuning().dattn_db == 1)                                                                                                           \
+            SA_OPD((decode_attn_flash2_kernel<DD, GG, true>), (decode_attn_flash2_lds<DD, GG, true>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0) \
+        else SA_OPD((decode_attn_flash2_kernel<DD, GG, false>), (decode_attn_flash2_lds<DD, GG, false>()), bf16_t, (uint8_t*)nullptr, (uint8_t*)nullptr, 0) \
+    }
 #define SA_OPD_FLASH(DD, GG) { if (tuning().dattn == 3) SA_OPD_FLASH3(DD, GG) else SA_OPD_FLASH4(DD, GG) }
 #define SA_OPD_MFMA(DD, GG) SA_OPD((decode_attn_mfma_kernel<float, DD, GG>), (decode_attn_mfma_lds<float, DD, GG>()), float)
     if (dtype == SA_DTYPE_BF16) {          // the dispatch of RecModel::decode_layer
@@ -1426,7 +1453,8 @@ int surya_set_tuning(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
         {"bigtile", &t.bigtile}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}, {"dattn", &t.dattn}, {"rnorm", &t.rnorm},
-        {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}, {"kvprefetch", &t.kvprefetch}};
+        {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}, {"kvprefetch", &t.kvprefetch},
+        {"dattn_db", &t.dattn_db}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) {
             if (*e.v != value) ++tuning_epoch();        // captured decode graphs are stale (RecModel::decode_steps drops them)

@@ -178,13 +178,25 @@ class DetectionPredictor(BasePredictor):
         return out
 
     def _detect_device(self, images, batch_size=None, include_maps=False) -> List[TextDetectionResult]:
+        return [r for batch in self._iter_detect_device(images, batch_size, include_maps) for r in batch]
+
+    def iter_detect(self, images: List[Image.Image], batch_size=None) -> Generator[List[TextDetectionResult], None, None]:
+        """The results of `__call__(images, batch_size)` handed over batch by batch, in page order, each as soon as ITS boxes have
+        left the device (the next batch is already launched by then). What RecognitionPredictor's streamed detect -> recognise
+        call consumes (recognition/predictor.py `_call_streamed`): lines of the first pages are admitted to the continuous-batching
+        loop while the detector still works on the later ones. Single process, device post-processing only."""
+        if not self.device_postprocess or self.shard_pages:
+            raise RuntimeError("iter_detect needs the device post-processing path of one process (no DETECTOR_POSTPROCESS_HOST, no page sharding)")
+        return self._iter_detect_device(images, batch_size, False)
+
+    def _iter_detect_device(self, images, batch_size=None, include_maps=False):
         if getattr(self, "_post", None) is None:
             self._post = HipDetPost(self.model.device)
         tt, lt = settings.DETECTOR_TEXT_THRESHOLD, settings.DETECTOR_BLANK_THRESHOLD
-        out: List[TextDetectionResult] = []
 
         def finish(job):
             """Results of one launched batch (waits for ITS event only)."""
+            out: List[TextDetectionResult] = []
             jobs, n_pages, tiles_of, split_heights, sizes, heat, pw = job
             res = {}
             for pages_, pending, psizes in jobs:
@@ -202,6 +214,7 @@ class DetectionPredictor(BasePredictor):
                     am = np.vstack([maps[t, 1, :r] for t, r in zip(tiles_of[pg], rows)])
                     hi, ai = Image.fromarray((hm * 255).astype(np.uint8)), Image.fromarray((am * 255).astype(np.uint8))
                 out.append(result_from_device_boxes(bx, cf, list(psize), sizes[pg], hi, ai))
+            return out
 
         # One batch in flight ahead of the one being read: the generator prepares (PIL convert / resize, pinned staging) and
         # launches batch i + 1 while the GPU still works on batch i, whose boxes are only then waited for.
@@ -223,11 +236,10 @@ class DetectionPredictor(BasePredictor):
                 jobs.append(([pg], self._post.launch(full, tt, lt), [(pw, full.shape[1])]))
             job = (jobs, n_pages, tiles_of, split_heights, sizes, heat, pw)
             if prev is not None:
-                finish(prev)
+                yield finish(prev)
             prev = job
         if prev is not None:
-            finish(prev)
-        return out
+            yield finish(prev)
 
     def resize_image(self, img: Image.Image) -> np.ndarray:
         """The reference's double LANCZOS resize to the processor size (surya/detection/__init__.py:50-57), uint8 HWC."""

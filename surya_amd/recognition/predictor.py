@@ -226,6 +226,9 @@ def rec_config_from_reference_json(raw: dict) -> RecConfig:
                      num_register_tokens=raw.get("num_register_tokens", 4))
 
 
+FEED_END = object()          # what a `generate(feed=...)` callable returns once no further lines will come
+
+
 @dataclass
 class RecognitionPrompt:
     id: int
@@ -410,22 +413,29 @@ class RecognitionPredictor(BasePredictor):
         return {"prompts": prompts, "max_tokens": max_tokens, "tiles": tiles, "tile_offs": tile_offs, "grids": grids,
                 "prompt_ids": prompt_ids}
 
-    def generate(self, prep: dict, recognition_batch_size: int | None = None, on_done=None, on_flush=None) -> tuple:
+    def generate(self, prep: dict | None, recognition_batch_size: int | None = None, on_done=None, on_flush=None, feed=None) -> tuple:
         """Device half: continuous batching over KV slots until every line stopped (reference :501-607).
         on_done(line, tokens, scores, bbox_rows[T, 6]) is called once per line, as soon as its stream is final; on_flush() after
-        every host synchronisation point that finished at least one line (so a caller can hand the lines over in batches)."""
-        prompts, batch_max_tokens = prep["prompts"], prep["max_tokens"]
-        tiles, tile_offs, grids, prompt_ids = prep["tiles"], prep["tile_offs"], prep["grids"], prep["prompt_ids"]
-        n = len(prompts)
-        predicted_tokens = [[] for _ in range(n)]
-        scores = [[] for _ in range(n)]
+        every host synchronisation point that finished at least one line (so a caller can hand the lines over in batches).
+
+        `feed` (optional) makes the line list open-ended: `feed(block)` returns the next `prepare_lines` dict whose prompts carry
+        the ids that continue the ones already admitted (queue order == id order), None when nothing is ready (only for block =
+        False) or FEED_END. The loop polls it between decode calls and blocks on it only when it has nothing left to run, so lines
+        can be admitted while their producer (the detector of a streamed detect -> recognise call) still works on later pages.
+        Scheduling decisions never change a line's stream (slot / batch-composition invariance), so the result per line is the
+        one the closed list gives. A streamed call states its token budget up front in the first dict (`overall_max_tokens`)."""
+        prompts, grids, prompt_ids = [], [], []
+        batch_max_tokens: dict = {}
+        predicted_tokens, scores = [], []
+        chunk_tiles, chunk_offs, chunk_base = [], [], []      # per admitted dict: its tile tensor, local tile offsets, first id
+        line_chunk = np.zeros(0, np.int64)                    # id -> index into the three lists above
         if recognition_batch_size is None:
             recognition_batch_size = self.get_batch_size()
         recognition_batch_size = min(recognition_batch_size, self.model.max_slots)
         self.setup_cache(recognition_batch_size)
-        self.prompt_queue.extend(prompts)
-        overall_max_tokens = max(batch_max_tokens.values())
-        batch_bboxes = np.zeros((n, overall_max_tokens, 6), np.float32)
+        first = prep if prep is not None else {}
+        overall_max_tokens = int(first.get("overall_max_tokens") or max(first["max_tokens"].values()))
+        batch_bboxes = np.zeros((0, overall_max_tokens, 6), np.float32)
         eos, pad, nop = self.processor.eos_token_id, self.processor.pad_token_id, self.processor.no_output_token
         steps_per_sync = max(1, min(settings.RECOGNITION_STEPS_PER_SYNC, 8))
         max_prefill = self.model.c.max_prefill_tokens
@@ -433,13 +443,64 @@ class RecognitionPredictor(BasePredictor):
         # loop cost 1.2-1.6 us per token, a third of the device's own time per decode call, and fought the assembly thread for
         # the GIL). batch_prompt_mapping stays the slot table the scheduling decisions read; slot_line mirrors it as an array.
         cap = max(1, overall_max_tokens) + 1
-        tok_mat = np.zeros((n, cap), np.int64)
-        sc_mat = np.zeros((n, cap), np.float32)
-        line_len = np.zeros(n, np.int64)
-        max_tok = np.asarray([batch_max_tokens[i] for i in range(n)], np.int64)
+        tok_mat = np.zeros((0, cap), np.int64)
+        sc_mat = np.zeros((0, cap), np.float32)
+        line_len = np.zeros(0, np.int64)
+        max_tok = np.zeros(0, np.int64)
         slot_line = np.full(recognition_batch_size, -1, np.int64)
         REP = 40                                               # detect_repeat_token's window
         rep_cols = np.arange(-REP, 0)
+
+        def admit(d):
+            """Append the lines of one prepare_lines dict (ids continue the admitted ones)."""
+            nonlocal batch_bboxes, tok_mat, sc_mat, line_len, max_tok, line_chunk
+            new = d["prompts"]
+            base, m = len(prompts), len(new)
+            if m == 0:
+                return
+            assert [p.id for p in new] == list(range(base, base + m)), "fed prompts must continue the admitted ids"
+            mt = np.asarray([d["max_tokens"][p.id] for p in new], np.int64)
+            assert int(mt.max()) <= overall_max_tokens, "a fed line's token budget exceeds the call's overall_max_tokens"
+            prompts.extend(new)
+            grids.extend(d["grids"])
+            prompt_ids.extend(d["prompt_ids"])
+            batch_max_tokens.update(d["max_tokens"])
+            predicted_tokens.extend([] for _ in range(m))
+            scores.extend([] for _ in range(m))
+            chunk_tiles.append(d["tiles"]); chunk_offs.append(d["tile_offs"]); chunk_base.append(base)
+            line_chunk = np.concatenate([line_chunk, np.full(m, len(chunk_base) - 1, np.int64)])
+            batch_bboxes = np.concatenate([batch_bboxes, np.zeros((m, overall_max_tokens, 6), np.float32)])
+            tok_mat = np.concatenate([tok_mat, np.zeros((m, cap), np.int64)])
+            sc_mat = np.concatenate([sc_mat, np.zeros((m, cap), np.float32)])
+            line_len = np.concatenate([line_len, np.zeros(m, np.int64)])
+            max_tok = np.concatenate([max_tok, mt])
+            self.prompt_queue.extend(new)
+
+        def tiles_of(first_id, last_id):
+            """Tile rows of the consecutive lines first_id..last_id (all of one admitted dict)."""
+            c = int(line_chunk[first_id])
+            assert c == int(line_chunk[last_id])
+            o, b0 = chunk_offs[c], chunk_base[c]
+            return chunk_tiles[c][int(o[first_id - b0]): int(o[last_id - b0 + 1])]
+
+        feed_done = feed is None
+
+        def poll(block):
+            """Admit what the feed has ready; with `block`, wait for the next dict (or the end)."""
+            nonlocal feed_done
+            got = False
+            while not feed_done:
+                nxt = feed(block and not got)
+                if nxt is None:
+                    break
+                if nxt is FEED_END:
+                    feed_done = True
+                    break
+                admit(nxt)
+                got = got or bool(nxt["prompts"])
+
+        if prep is not None:
+            admit(prep)
 
         def finished(p_idx):
             L_ = int(line_len[p_idx])
@@ -509,17 +570,24 @@ class RecognitionPredictor(BasePredictor):
                 t = int(grids[p.id][0]) * int(grids[p.id][1]) // merge2
                 if len(cand) >= recognition_batch_size or (cand and ntok_img + t > ahead_cap):
                     break
+                if cand and line_chunk[p.id] != line_chunk[cand[0]]:
+                    break                              # one tile tensor per encoder pass: the next admitted dict waits its turn
                 cand.append(p.id)
                 ntok_img += t
-            a_, b_ = int(tile_offs[cand[0]]), int(tile_offs[cand[-1] + 1])
-            self.model.encode_ahead(tiles[a_:b_], [grids[i] for i in cand])
+            self.model.encode_ahead(tiles_of(cand[0], cand[-1]), [grids[i] for i in cand])
             ahead.extend(cand)
 
         # The device runs one decode call ahead of the host: call n + 1 is enqueued before call n's tokens are looked at,
         # so the bookkeeping above overlaps with GPU work. A line that stops inside call n rides along in call n + 1
         # (its outputs are dropped: the slot is unmapped by then); new lines are admitted only with nothing in flight.
         inflight, ring = None, 0
-        while self.prompt_queue or self.num_active_slots > 0 or inflight:
+        while True:
+            if not feed_done:
+                poll(block=not (self.prompt_queue or self.num_active_slots > 0 or inflight))
+            if not (self.prompt_queue or self.num_active_slots > 0 or inflight):
+                if feed_done:
+                    break
+                continue
             if (self.num_empty_slots / recognition_batch_size) > self.min_prefill_ratio and self.prompt_queue:
                 if inflight:
                     absorb(inflight)
@@ -531,12 +599,11 @@ class RecognitionPredictor(BasePredictor):
                 take, ntok = [], 0
                 while self.prompt_queue and len(take) < len(empty) and (not look_ahead or len(take) < len(ahead)):
                     L_ = len(prompt_ids[self.prompt_queue[0].id])
-                    if take and ntok + L_ > max_prefill:
+                    if take and (ntok + L_ > max_prefill or line_chunk[self.prompt_queue[0].id] != line_chunk[take[0].id]):
                         break
                     take.append(self.prompt_queue.popleft())
                     ntok += L_
                 slots = empty[: len(take)]
-                a, b = int(tile_offs[take[0].id]), int(tile_offs[take[-1].id + 1])   # queue order == id order
                 if look_ahead:
                     for p in take:
                         assert ahead.popleft() == p.id
@@ -544,7 +611,8 @@ class RecognitionPredictor(BasePredictor):
                     if not ahead and self.prompt_queue:
                         encode_ahead()                 # the next lines' encoder pass runs beside the decode steps below
                 else:
-                    self.model.prefill(tiles[a:b], [grids[p.id] for p in take], [prompt_ids[p.id] for p in take], slots)
+                    self.model.prefill(tiles_of(take[0].id, take[-1].id), [grids[p.id] for p in take],   # queue order == id order
+                                       [prompt_ids[p.id] for p in take], slots)
                 tok, sc, bb = self.model.read_outputs(1)
                 ids_, sl_ = np.asarray([p.id for p in take], np.int64), np.asarray(slots, np.int64)
                 first = tok[0, sl_]
@@ -833,6 +901,9 @@ class RecognitionPredictor(BasePredictor):
         if bboxes is None and polygons is None:
             assert det_predictor is not None, (
                 "You need to pass in a detection predictor if you don't provide bboxes or polygons")
+            if self._can_stream(det_predictor):
+                return self._call_streamed(images, task_names, det_predictor, detection_batch_size, recognition_batch_size,
+                                           highres_images, sort_lines, math_mode, return_words, drop_repeated_text, stamps, t_call)
             flat = self.detect_and_slice_bboxes(images, task_names, det_predictor, detection_batch_size, highres_images)
         else:
             if bboxes is not None:
@@ -894,6 +965,149 @@ class RecognitionPredictor(BasePredictor):
                               assemble_tail_ms=(time.perf_counter() - t2) * 1e3)
             assert all(t is not None for t in text_lines)
 
+        results, start = [], 0
+        for idx, image in enumerate(images):
+            end = start + flat["slice_map"][idx]
+            lines = text_lines[start:end]
+            start = end
+            if sort_lines:
+                lines = sort_text_lines(lines)
+            results.append(OCRResult(text_lines=lines, image_bbox=[0, 0, image.size[0], image.size[1]]))
+        stamps["total_ms"] = (time.perf_counter() - t_call) * 1e3
+        return results
+
+    # ---------------------------------------------------------------------- streamed detect -> recognise
+    # One call, two threads: a producer runs the detector batch by batch (DetectionPredictor.iter_detect) and turns each
+    # batch's boxes into a prepared chunk of lines (LineRefs, width sort within the chunk, device pre-processing, prompt ids);
+    # the calling thread runs the continuous-batching loop and admits a chunk as soon as it exists, so the recogniser decodes the
+    # first pages' lines while the detector still works on the later pages. Both threads launch on the same HIP stream (device
+    # work is ordered by submission, no cross-stream hand-off), each waits only on its own events. The reference detects every
+    # page before the first crop is recognised (recognition/__init__.py:371-399, 836-845); the order of the work does not enter
+    # any result: a line's tokens do not depend on its slot or batch mates, and results are re-assembled by original position.
+    stream_detection: bool = settings.RECOGNITION_STREAM_DETECTION
+
+    def _can_stream(self, det_predictor) -> bool:
+        return (self.stream_detection and self.device_preprocess and not self.shard_lines
+                and callable(getattr(det_predictor, "iter_detect", None)) and getattr(det_predictor, "device_postprocess", False)
+                and not getattr(det_predictor, "shard_pages", False))
+
+    def _call_streamed(self, images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images,
+                       sort_lines, math_mode, return_words, drop_repeated_text, stamps, t_call) -> List[OCRResult]:
+        import queue
+        import sys
+        import threading
+        # by line id (admission order): slices / task_names / input_text; by ORIGINAL position (page order): the rest
+        flat = {"slices": [], "slice_map": [], "polygons": [], "task_names": [], "input_text": [], "res_scales": []}
+        orig_of: List[int] = []                               # line id -> original position
+        q: "queue.Queue" = queue.Queue()
+        overall_max_tokens = max([settings.RECOGNITION_MAX_TOKENS or self.tasks[t]["max_tokens"] for t in task_names] or [1])
+        device = self.model.device
+        det_wall = [0.0]
+        stop = threading.Event()
+
+        def produce():
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(device)             # the current device is per thread
+                page, t_p = 0, time.perf_counter()
+                for dets in det_predictor.iter_detect(images, batch_size=detection_batch_size):
+                    if stop.is_set():
+                        break
+                    pages, refs, polys_all, scales_all, tasks_all = [], [], [], [], []
+                    for det_pred in dets:
+                        image, highres, task = images[page], highres_images[page], task_names[page]
+                        polygons = [b.polygon for b in det_pred.bboxes]
+                        if highres:
+                            ws, hs = highres.size[0] / image.size[0], highres.size[1] / image.size[1]
+                            src = highres
+                            polys_px = [[[int(pt[0] * ws), int(pt[1] * hs)] for pt in poly] for poly in polygons]
+                            scale = (ws, hs)
+                        else:
+                            src, polys_px, scale = image, polygons, (1, 1)
+                        pages.append(page_pixels(src))
+                        refs.extend(poly_ref(len(pages) - 1, src.size[0], src.size[1], poly) for poly in polys_px)
+                        polys_all.extend(polygons)
+                        scales_all.extend([scale] * len(polygons))
+                        tasks_all.extend([task] * len(polygons))
+                        flat["slice_map"].append(len(polygons))
+                        page += 1
+                    if not refs:
+                        continue
+                    base_orig, base_id = len(flat["polygons"]), len(flat["slices"])
+                    # widest first inside the chunk: the length bucketing of the reference's global sort (:847-854), per arrival
+                    order = sorted(range(len(refs)), key=lambda i: -refs[i].shape[1])
+                    prompts = [RecognitionPrompt(id=base_id + k, task_name=tasks_all[i], text=None, image=refs[i], math_mode=math_mode)
+                               for k, i in enumerate(order)]
+                    tiles, tile_offs, grids, prompt_ids = self.preprocess_prompts_device(prompts, pages)
+                    # everything the assembly thread reads about these lines is in place BEFORE the chunk can be admitted
+                    flat["polygons"].extend(polys_all)
+                    flat["res_scales"].extend(scales_all)
+                    flat["slices"].extend(refs[i] for i in order)
+                    flat["task_names"].extend(tasks_all[i] for i in order)
+                    flat["input_text"].extend([None] * len(order))
+                    orig_of.extend(base_orig + i for i in order)
+                    q.put({"prompts": prompts, "tiles": tiles, "tile_offs": tile_offs, "grids": grids, "prompt_ids": prompt_ids,
+                           "max_tokens": {p.id: settings.RECOGNITION_MAX_TOKENS or self.tasks[p.task_name]["max_tokens"]
+                                          for p in prompts}})
+                det_wall[0] = (time.perf_counter() - t_p) * 1e3
+                q.put(FEED_END)
+            except BaseException as e:                        # surfaces in the calling thread
+                q.put(e)
+
+        def feed(block):
+            try:
+                item = q.get(block)
+            except queue.Empty:
+                return None
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
+        bbox_size = self.model.cfg.bbox_size
+
+        def assemble(batch):
+            return self._assemble_batch(flat, [(k, orig_of[k], t, sc, bb) for k, t, sc, bb in batch], drop_repeated_text,
+                                        return_words, bbox_size)
+
+        futures, pending = [], []
+        # the producer's Python work (box lists, line descriptors) must not keep the scheduler from its next launch for a
+        # whole default switch interval (5 ms = a decode call of 4 steps)
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 5e-4))
+        producer = threading.Thread(target=produce, name="surya-amd-detect", daemon=True)
+        try:
+            with ThreadPoolExecutor(1) as pool:
+                def on_done(k, tokens, sc, bbox_rows):
+                    pending.append((k, list(tokens), list(sc), bbox_rows.copy()))
+
+                def on_flush():
+                    if pending:
+                        batch = pending[:]
+                        pending.clear()
+                        futures.append(([b[0] for b in batch], pool.submit(assemble, batch)))
+                t0 = time.perf_counter()
+                producer.start()
+                try:
+                    self.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": overall_max_tokens}, recognition_batch_size,
+                                  on_done=on_done, on_flush=on_flush, feed=feed)
+                except BaseException:
+                    stop.set()                         # the producer ends after the batch it is working on
+                    raise
+                producer.join()                        # it has put FEED_END: nothing left to run
+                on_flush()
+                t2 = time.perf_counter()
+                n = len(orig_of)
+                text_lines = [None] * n
+                for ks, f in futures:
+                    for k, line in zip(ks, f.result()):
+                        text_lines[orig_of[k]] = line
+                stamps.update(streamed=1.0, detect_thread_ms=det_wall[0], device_loop_ms=(t2 - t0) * 1e3,
+                              assemble_tail_ms=(time.perf_counter() - t2) * 1e3)
+        finally:
+            sys.setswitchinterval(old_switch)
+        if n == 0:
+            return []
+        assert all(t is not None for t in text_lines) and len(flat["slice_map"]) == len(images)
         results, start = [], 0
         for idx, image in enumerate(images):
             end = start + flat["slice_map"][idx]

@@ -62,6 +62,8 @@ class Settings:
         # boxes after a page's end token are discarded, so results do not depend on it). 1..16.
         self.LAYOUT_STEPS_PER_SYNC: int = _env("LAYOUT_STEPS_PER_SYNC", int, 8)
         self.RECOGNITION_ENCODE_AHEAD: bool = bool(_env("RECOGNITION_ENCODE_AHEAD", int, 1))
+        # detect -> recognise calls admit the first pages' lines while the detector still works on the later pages (predictor._call_streamed)
+        self.RECOGNITION_STREAM_DETECTION: bool = bool(_env("RECOGNITION_STREAM_DETECTION", int, 1))
         # multi-GPU: shard ONE call's lines / pages over the ranks of the initialised process group (all ranks must pass the
         # same inputs). Off by default: the reference has no collectives, and a torchrun job where every rank OCRs its own
         # pages must not meet one.

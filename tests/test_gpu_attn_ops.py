@@ -247,6 +247,26 @@ def test_decode_attn_flash2_agrees_with_flash(hip_lib):
     assert (o3.float() - o4.float()).abs().max().item() <= 2e-2 * max(1.0, o3.float().abs().max().item())
 
 
+@pytest.mark.parametrize("d,nq,nkv,lens,Tmax", [(128, 10, 2, DECODE_LENS, 1024), (64, 8, 2, [0, 7, 64, 127, 128, 130, 257, 383, 384, 500], 512),
+                                                (32, 4, 2, [0, 127, 128, 129, 255, 256, 257, 511], 520)])
+def test_decode_attn_two_tile_buffers_bit_identical_and_vs_fp32(hip_lib, d, nq, nkv, lens, Tmax):
+    """decode_attn_flash2_kernel<.., DB = true> (dattn_db = 1: next tile fetched while this one is computed; the variant the model
+    picks once an active context exceeds one 128-key tile) against fp32 PyTorch, and bit for bit against the single-buffered kernel:
+    outputs AND the appended cache rows, over contexts of 1 ... 8 tiles incl. the tile edges and the new row opening a fresh tile."""
+    outs = {}
+    try:
+        for db in (-1, 1):
+            L.check(hip_lib.surya_set_tuning(b"dattn_db", C.c_int(db)), "surya_set_tuning")
+            outs[db] = _decode_case(hip_lib, torch.bfloat16, d, nq, nkv, lens, 3, Tmax, seed=5 + d, ret_raw=True)
+        worst, ref_max, worst_kv = _decode_case(hip_lib, torch.bfloat16, d, nq, nkv, lens, 2, Tmax, seed=d)
+    finally:
+        L.check(hip_lib.surya_set_tuning(b"dattn_db", C.c_int(0)), "surya_set_tuning")
+    for a, b in zip(outs[-1], outs[1]):
+        assert torch.equal(a, b)
+    assert worst <= 2e-2 * ref_max, f"max err {worst} vs max|ref| {ref_max}"
+    assert worst_kv <= 4e-2
+
+
 def test_decode_attn_fp32_mode_vs_fp32(hip_lib):
     worst, ref_max, worst_kv = _decode_case(hip_lib, torch.float32, 128, 10, 2, DECODE_LENS, 3, 1024, seed=11)
     assert worst <= 2e-5 * ref_max and worst_kv <= 1e-5, (worst, worst_kv)

@@ -138,3 +138,73 @@ def test_end_to_end_detect_crop_recognise(hip_lib):
         for line, box in zip(r.text_lines, d.bboxes):
             assert line.polygon == box.polygon
     assert sum(len(r.text_lines) for r in out) > 0
+
+
+def _det_with_drawn_rows(pages, rows, size, batch):
+    """A detector whose text map is replaced by the rows drawn on each page (random weights find one blob per page), as
+    bench.py's e2e leg does, so a call yields a realistic number of line boxes per page."""
+    from surya_amd.detection.predictor import DetectionPredictor
+    cfg_d = det_config("DET-TINY")
+    masks = np.zeros((len(pages), size, size), np.uint8)
+    for i, rr in enumerate(rows):
+        for x0, y0, x1, y1 in rr:
+            masks[i, y0 + 5:y1 - 5, x0 + 3:x1 - 3] = 1
+    masks_d = torch.from_numpy(masks).to("cuda:0")
+    page_of = {id(im): i for i, im in enumerate(pages)}
+
+    class Det(DetectionPredictor):
+        batch_size = batch
+
+        def batch_heatmaps(self, images, batch_size=None):
+            off = 0
+            for heat, split_index, split_heights, sizes in super().batch_heatmaps(images, batch_size):
+                n = split_index[-1] + 1
+                idx = torch.tensor([page_of[id(im)] for im in images[off:off + n]], device=heat.device)
+                heat[:, 0] = masks_d[idx].float() * 0.9 + 0.03
+                off += n
+                yield heat, split_index, split_heights, sizes
+
+    return Det(checkpoint={"config": cfg_d, "state_dict": make_det_weights(cfg_d, 0), "size": size}, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("slots,det_batch", [(8, 2), (32, 3)])
+def test_streamed_detect_recognise_equals_the_serial_call(hip_lib, slots, det_batch):
+    """RecognitionPredictor(images, det_predictor=...) with the detector feeding the scheduler batch by batch
+    (_call_streamed: lines admitted while later pages are still being detected) returns the OCRResults of the serial
+    call -- detect everything, sort, recognise -- field for field; iter_detect's batches concatenate to __call__'s list."""
+    from surya_amd.synth import make_pages_with_lines
+    size = 256
+    pages_np, rows = make_pages_with_lines(7, size, seed=99)
+    pages = [Image.fromarray(p) for p in pages_np]
+    det = _det_with_drawn_rows(pages, rows, size, det_batch)
+    cfg, sd, rec = make_rec_predictor(max_slots=slots, max_tokens=7)
+    whole = det(pages)
+    parts = list(det.iter_detect(pages))
+    assert [len(p) for p in parts] == [det_batch] * (7 // det_batch) + ([7 % det_batch] if 7 % det_batch else [])
+    assert [b.polygon for r in whole for b in r.bboxes] == [b.polygon for p in parts for r in p for b in r.bboxes]
+    assert sum(len(r.bboxes) for r in whole) > 3 * slots or slots > 8          # more lines than slots: refills happen mid-stream
+    rec.stream_detection = False
+    serial = rec(pages, det_predictor=det, return_words=True)
+    assert "streamed" not in rec.last_timing
+    rec.stream_detection = True
+    streamed = rec(pages, det_predictor=det, return_words=True)
+    assert rec.last_timing.get("streamed") == 1.0
+    assert len(serial) == len(streamed) == 7
+    for a, b, d in zip(serial, streamed, whole):
+        assert len(a.text_lines) == len(d.bboxes)
+        assert a.model_dump() == b.model_dump()
+    # pages without any line (blank) in the middle of the stream, and a call that finds nothing at all
+    blank = Image.fromarray(np.full((size, size, 3), 255, np.uint8))
+    mixed = [pages[0], blank, blank, pages[1], blank]
+    det2 = _det_with_drawn_rows(mixed, [rows[0], [], [], rows[1], []], size, 2)
+    rec.stream_detection = False
+    s2 = rec(mixed, det_predictor=det2)
+    rec.stream_detection = True
+    t2 = rec(mixed, det_predictor=det2)
+    assert [r.model_dump() for r in s2] == [r.model_dump() for r in t2] and len(t2) == 5
+    only_blank = [blank, blank, blank]
+    det3 = _det_with_drawn_rows(only_blank, [[], [], []], size, 2)
+    rec.stream_detection = False
+    s3 = rec(only_blank, det_predictor=det3)
+    rec.stream_detection = True
+    assert rec(only_blank, det_predictor=det3) == s3

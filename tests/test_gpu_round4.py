@@ -23,7 +23,7 @@ from util import make_prompts
 pytestmark = pytest.mark.gpu
 
 GRIDS = [(6, 38), (10, 18), (8, 24), (6, 10), (12, 12), (2, 30)]
-DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1, kvprefetch=0)
+DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1, kvprefetch=0, dattn_db=0)
 
 
 def tune(**kw):
@@ -46,10 +46,10 @@ def build(cfg_name, dtype, max_slots=8, max_kv_len=256):
     return cfg, m
 
 
-def run_steps(m, cfg, calls):
-    tiles, seqs = make_prompts(cfg, GRIDS)
+def run_steps(m, cfg, calls, grids=GRIDS):
+    tiles, seqs = make_prompts(cfg, grids)
     slots = list(range(len(seqs)))
-    m.prefill(tiles.cuda(), GRIDS, seqs, slots)
+    m.prefill(tiles.cuda(), grids, seqs, slots)
     t0, s0, b0 = m.read_outputs(1)
     m.set_active(slots)
     toks, scs, bbs = [t0[0][slots].copy()], [s0[0][slots].copy()], [b0[0][slots].copy()]
@@ -102,6 +102,27 @@ def test_decode_attention_kernels_agree_inside_the_model(hip_lib):
     assert same >= 0.9
     eq = a[0] == b[0]
     assert np.allclose(a[1][eq], b[1][eq], rtol=5e-2, atol=1e-3)
+
+
+def test_two_buffer_decode_attention_is_picked_by_context_and_changes_nothing(hip_lib):
+    """Contexts that cross one 128-key tile during the run (prompts of ~20 ... ~150 tokens + 14 steps): the model switches to the
+    two-buffer decode attention by its host-side context bound (dattn_db = 0); never (-1) and always (1) must give the same tokens,
+    scores and boxes bit for bit -- also with hipGraph replay on, where the bound is not consulted."""
+    cfg, m = build("REC-SMALL", torch.bfloat16, max_kv_len=320)
+    grids = [(12, 44), (14, 40), (6, 10), (16, 36), (10, 48)]
+    calls = [4, 4, 1, 4, 1]
+    runs = {}
+    for db in (-1, 0, 1):
+        tune(dattn_db=db)
+        runs[db] = run_steps(m, cfg, calls, grids)
+    for db in (0, 1):
+        for x, y in zip(runs[-1], runs[db]):
+            assert np.array_equal(x, y), db
+    tune(dattn_db=0, graph=1)
+    for rep in range(3):
+        g = run_steps(m, cfg, calls, grids)
+        for x, y in zip(runs[-1], g):
+            assert np.array_equal(x, y), rep
 
 
 def test_graph_cache_is_dropped_when_a_mode_changes(hip_lib):

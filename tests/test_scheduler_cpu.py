@@ -169,3 +169,94 @@ def test_no_speculative_call_when_budgets_are_known():
         settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
     assert all(len(t) == 11 for t in toks)
     assert pred.model.stats["steps"] == 10 and pred.model.stats["decode_calls"] == 3      # 4 + 4 + 2
+
+
+def _chunks(prep, cuts):
+    """Split one prepare_lines dict into consecutive dicts at the line ids in `cuts` (each with its OWN tile tensor and local
+    tile offsets, the ids continuing), as the producer of a streamed detect -> recognise call hands them over."""
+    offs, out = prep["tile_offs"], []
+    edges = [0] + list(cuts) + [len(prep["prompts"])]
+    for a, b in zip(edges[:-1], edges[1:]):
+        out.append({"prompts": prep["prompts"][a:b], "max_tokens": {i: prep["max_tokens"][i] for i in range(a, b)},
+                    "tiles": prep["tiles"][offs[a]:offs[b]].copy(), "tile_offs": offs[a:b + 1] - offs[a],
+                    "grids": prep["grids"][a:b], "prompt_ids": prep["prompt_ids"][a:b]})
+    return out
+
+
+@pytest.mark.parametrize("n_lines,max_tokens,slots,sps,ahead,cuts,lag", [
+    (23, 12, 4, 4, True, (5, 6, 17), 0), (23, 12, 4, 3, False, (5, 6, 17), 2), (40, 6, 7, 1, True, (1, 20, 39), 1),
+    (64, 20, 8, 4, True, (16, 32, 48), 3), (30, 64, 8, 4, True, (29,), 50), (27, 90, 5, 3, False, (9, 9, 18), 4),
+    (12, 9, 16, 4, True, (4, 8), 7)])
+def test_fed_loop_equals_closed_list(n_lines, max_tokens, slots, sps, ahead, cuts, lag):
+    """generate(feed=...): lines handed over in chunks WHILE the loop runs (a chunk becomes available `lag` polls after the
+    previous one was taken; an empty chunk and a long drought -- the loop has to block -- are among the cases) give every line
+    the stream of the closed list, under the fake model's C-ABI contract checks."""
+    from surya_amd.recognition.predictor import FEED_END
+    old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD)
+    settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = sps, ahead
+    try:
+        pred, prep = make(n_lines, max_tokens, slots)
+        pending = deque(_chunks(prep, cuts))
+        state = {"wait": 0, "blocked": 0, "polls": 0}
+        done, flushes = [], []
+
+        def feed(block):
+            state["polls"] += 1
+            if not pending:
+                return FEED_END
+            if state["wait"] > 0 and not block:
+                state["wait"] -= 1
+                return None
+            state["blocked"] += bool(block)
+            state["wait"] = lag
+            return pending.popleft()
+
+        overall = max(prep["max_tokens"].values())
+        toks, boxes, scores = pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": overall}, slots, feed=feed,
+                                            on_done=lambda k, t, s, b: done.append((k, list(t), b.copy())),
+                                            on_flush=lambda: flushes.append(len(done)))
+    finally:
+        settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
+    m = pred.model
+    assert not m.inflight and not m.ahead and m.prefill_out is None and not pending
+    assert len(toks) == n_lines and boxes.shape[0] == n_lines
+    for i in range(n_lines):
+        exp = expected(i, prep["max_tokens"][i])
+        assert toks[i] == exp, (i, toks[i], exp)
+        assert len(scores[i]) == len(exp)
+        assert (boxes[i, :len(exp), 0].numpy() == i).all()
+    assert sorted(k for k, _, _ in done) == list(range(n_lines))           # on_done exactly once per line ...
+    for k, t, b in done:
+        assert t == toks[k] and (b[:len(t), 0] == k).all()                 # ... with the line's final stream and its own boxes
+    if lag >= 50:
+        assert state["blocked"] >= 1                                       # nothing left to run: the loop waited for the feed
+
+
+def test_fed_loop_propagates_a_producer_failure():
+    from surya_amd.recognition.predictor import FEED_END
+    pred, prep = make(10, 8, 4)
+    first, second = _chunks(prep, (4,))
+    calls = {"n": 0}
+
+    def feed(block):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            return first
+        if not block:
+            return None
+        raise RuntimeError("detector failed")
+
+    with pytest.raises(RuntimeError, match="detector failed"):
+        pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": 8}, 4, feed=feed)
+
+
+def test_fed_loop_rejects_ids_out_of_sequence_and_oversized_budgets():
+    pred, prep = make(6, 8, 4)
+    a, b = _chunks(prep, (3,))
+    it = iter([b])
+    with pytest.raises(AssertionError, match="continue the admitted ids"):
+        pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": 8}, 4, feed=lambda block: next(it))
+    pred, prep = make(6, 8, 4)
+    it = iter([prep])
+    with pytest.raises(AssertionError, match="overall_max_tokens"):
+        pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": 4}, 4, feed=lambda block: next(it))
