@@ -71,6 +71,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// bf16 rows of 128 ... 1024 channels (the Swin stages): the kernel above gives a whole wave to a row -- at C = 128 half its lanes idle, the
+// other half move 8 bytes each and read the row three times (stage 1 of 32 pages = 1.18 M rows: 489 us for 600 MB, 1.2 TB/s). Here a row
+// belongs to LPR = min(64, C / 8) lanes that hold it in registers (one 16-byte load per 8 channels), several rows share a wave, the two
+// reductions run inside the LPR-lane group, and a workgroup walks 256 / LPR rows. Same two-pass statistics in fp32; the sums associate
+// differently (lane-local 8, then a butterfly), i.e. agreement with the kernel above to fp32 rounding, not to the bit -- bf16 mode only.
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                  const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                                  const int* __restrict__ perm, long rows, int rows_per_image, float eps,
+                                                                  int rows_per_image_out) {
+    constexpr int C = LPR * 8 * NV, RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;                          // dead rows shadow the last one (the shuffles below need every lane)
+    const bf16_t* xr = x + (live ? row : rows - 1) * C;
+    u32x4 raw[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) raw[v] = *reinterpret_cast<const u32x4*>(xr + (v * LPR + sub) * 8);
+    float f[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[v][2 * i] = __uint_as_float(raw[v][i] << 16);
+            f[v][2 * i + 1] = __uint_as_float(raw[v][i] & 0xFFFF0000u);
+            s += f[v][2 * i] + f[v][2 * i + 1];
+        }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = f[v][i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+    long drow = row;
+    if (perm) drow = (row / rows_per_image) * (rows_per_image_out ? rows_per_image_out : rows_per_image) + perm[row % rows_per_image];
+    bf16_t* yr = y + drow * C;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c0 = (v * LPR + sub) * 8;
+        float wv[8], bv[8];
+        load4(w + c0, reinterpret_cast<float(&)[4]>(wv[0])); load4(w + c0 + 4, reinterpret_cast<float(&)[4]>(wv[4]));
+        load4(b + c0, reinterpret_cast<float(&)[4]>(bv[0])); load4(b + c0 + 4, reinterpret_cast<float(&)[4]>(bv[4]));
+        store4(yr + c0, (f[v][0] - mean) * rstd * wv[0] + bv[0], (f[v][1] - mean) * rstd * wv[1] + bv[1],
+               (f[v][2] - mean) * rstd * wv[2] + bv[2], (f[v][3] - mean) * rstd * wv[3] + bv[3]);
+        store4(yr + c0 + 4, (f[v][4] - mean) * rstd * wv[4] + bv[4], (f[v][5] - mean) * rstd * wv[5] + bv[5],
+               (f[v][6] - mean) * rstd * wv[6] + bv[6], (f[v][7] - mean) * rstd * wv[7] + bv[7]);
+    }
+}
+
 // x[row] += tab[row % rows_per_image] (2-D sin-cos table at a stage's entry, learned position embeddings at the encoder's exit).
 template <typename T>
 __global__ void add_rows_kernel(T* __restrict__ x, const T* __restrict__ tab, long rows, int rows_per_image, int C) {

@@ -228,6 +228,21 @@ struct LayoutModel : LayoutBase {
         return launch_gemm<T, T, EPI>(a, s);
     }
     int layernorm(const T* in, int wi, int bi, T* out, const int* pm, long rows, int rpi, int C, float eps, hipStream_t s, int rpi_out = 0) {
+        if constexpr (std::is_same<T, bf16_t>::value) {      // rows held in registers by C / 8 lanes (layout_kernels.h); 16-byte aligned rows
+            if (rows > 0 && tuning().lay_ln) {
+#define SA_LN_ROWS(LPR, NV)                                                                                                              \
+    {                                                                                                                                    \
+        hipLaunchKernelGGL((lay::layernorm_rows_bf16_kernel<LPR, NV>), dim3((unsigned)cdivl(rows, 256 / LPR)), dim3(256), 0, s, in, W(wi), W(bi), \
+                           out, pm, rows, rpi, eps, rpi_out);                                                                            \
+        return (int)hipGetLastError();                                                                                                   \
+    }
+                if (C == 128) SA_LN_ROWS(16, 1)
+                if (C == 256) SA_LN_ROWS(32, 1)
+                if (C == 512) SA_LN_ROWS(64, 1)
+                if (C == 1024) SA_LN_ROWS(64, 2)
+#undef SA_LN_ROWS
+            }
+        }
         hipLaunchKernelGGL(lay::layernorm_kernel<T>, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, s, in, W(wi), W(bi), out, pm, rows, rpi, C, eps, rpi_out);
         return (int)hipGetLastError();
     }
@@ -531,8 +546,13 @@ struct LayoutModel : LayoutBase {
                 bool done = false;
                 if constexpr (std::is_same<T, bf16_t>::value) {
                     done = true;
-                    if (d == 64 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<64, 8>), (decode_attn_flash_lds<64, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
-                    else if (d == 32 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<32, 8>), (decode_attn_flash_lds<32, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                    // round 4: the thread-local-prologue kernel of the recogniser's decode step (decode_attn.h, fourth version; dattn = 3 keeps the third)
+                    if (tuning().dattn == 3) {
+                        if (d == 64 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<64, 8>), (decode_attn_flash_lds<64, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                        else if (d == 32 && G <= 8) SA_LAY_DEC((decode_attn_flash_kernel<32, 8>), (decode_attn_flash_lds<32, 8>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                        else done = false;
+                    } else if (d == 64 && G <= 8) SA_LAY_DEC((decode_attn_flash2_kernel<64, 8, false>), (decode_attn_flash2_lds<64, 8, false>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+                    else if (d == 32 && G <= 8) SA_LAY_DEC((decode_attn_flash2_kernel<32, 8, false>), (decode_attn_flash2_lds<32, 8, false>()), (uint8_t*)nullptr, (uint8_t*)nullptr, 0)
                     else done = false;
                 }
                 if (!done) {
