@@ -1109,9 +1109,9 @@ def main():
                 "achieved_with_splitk_slabs": None if mfma_bound else round(dom["gbs_with_splitk_slabs"], 2),
                 "frac_with_splitk_slabs": None if mfma_bound else round(dom["gbs_with_splitk_slabs"] / peak, 4),
                 "traffic": tr.get("bytes_per_launch") if isinstance(tr, dict) else tr,
-                "traffic_source": (tr.get("source") if isinstance(tr, dict) else None) or
-                                  "profiles/hbm_traffic.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  "(tools/profile_round.sh), bytes per launch of this bucket; PMC passes cannot run inside the timed process",
+                "traffic_source": "profiles/hbm_traffic.json = separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  "(tools/profile_round.sh), bytes per launch of this bucket; PMC passes cannot run inside the timed process; "
+                                  + str(traffic_for("source") or ""),
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 # an event pair around an EMPTY kernel costs this much: rocprofv3's begin->end duration of the same launches
                 # lies between avg_launch_ms - event_pair_null_ms and avg_launch_ms
