@@ -264,7 +264,14 @@ enum { SA_DET_INPUT = 0,       /* fp32 NCHW pixels -> NHWC, channels padded to `
        SA_DET_LITEMLA,         /* ReLU linear attention; in0 = qkv conv, in1 = aggregated qkv; p0 = head dim */
        SA_DET_UPCAT,           /* bilinear resize of in0 into channels [p0, p0+cin) of `out` (cout wide)     */
        SA_DET_CLASSIFY,        /* 1x1 conv to `cout` labels + sigmoid -> fp32 planes                         */
-       SA_DET_UPSAMPLE_OUT };  /* fp32 planes -> output size, bilinear                                       */
+       SA_DET_UPSAMPLE_OUT,    /* fp32 planes -> output size, bilinear                                       */
+       /* Decode head in its folded form (round 4; surya/detection/model/encoderdecoder.py:699-722 is linear up to the ReLU, and a
+        * 1x1 convolution commutes with a bilinear resize): linear_fuse(cat(up(linear_c_s(x_s)))) = sum_s up(A_s x_s) + c with
+        * A_s = (bn_scale * W_fuse[:, s]) W_c_s built at load. The 4 x decoder_layer_hidden concat and the K = 4 x 128 GEMM over it
+        * never exist: every stage runs ONE 1x1 conv to decoder_hidden channels at its own resolution, and the sum + ReLU + classifier
+        * + sigmoid is one pass over the full-resolution stage. */
+       SA_DET_UPSUM_SRC,       /* declares in0 ([hin, win, cin] per image) as a low-resolution addend of the next UPSUM_CLASSIFY (<= 3) */
+       SA_DET_UPSUM_CLASSIFY };/* planes = sigmoid(classifier(relu(in0 + sum of the bilinearly resized addends))): in0 [hin, win, cin], `cout` labels */
 enum { SA_ACT_NONE = 0, SA_ACT_HSWISH = 1, SA_ACT_RELU = 2 };
 
 typedef struct surya_det_op {

@@ -172,6 +172,7 @@ struct Tuning {
     int dattn_db = 0;        // bf16 decode attention with two K/V tile buffers (decode_attn_flash2_kernel<.., true>: next tile's fetch overlaps this tile's
                              // compute): 0 = when some active slot's context exceeds one 128-key tile (host bound), 1 = always, -1 = never
     int lay_ln = 1;          // layout / table encoder LayerNorm (bf16): 1 = rows held in registers by C / 8 lanes (layernorm_rows_bf16_kernel), 0 = a wave per row
+    int det_head_blk = 1;    // detector's folded decode head: 1 = register-blocked sum + classify (4 x 2 pixel blocks), 0 = per-pixel kernel
     int persist = 0;         // 256x256 bf16 GEMMs as a persistent tile loop (next tile's K-tiles in flight during the epilogue): 1 = on. Measured
                              // bit-identical and NOT faster (r04b: -1.5 ... +1.5 % per encoder / prefill shape, prefill of 256 lines 33.8 vs 33.4 ms):
                              // the hidden first-K-tile round trip is paid back in the two-pass epilogue and the per-tile tile-map arithmetic

@@ -642,6 +642,260 @@ __global__ __launch_bounds__(256) void classify_sigmoid_kernel(const T* __restri
     }
 }
 
+// Decode head, folded (SA_DET_UPSUM_CLASSIFY, include/surya_amd.h): per full-resolution pixel
+//   v = z0 + sum_s bilinear(z_s)       (fp32; z_s = the stage's own 1x1 conv to the decoder width, bias and BatchNorm folded into z0's)
+//   y = T(relu(v))                     (what the reference stores after linear_fuse + batch_norm + ReLU, :717-719)
+//   plane_l = T(sigmoid(T(w_l . y + b_l)))
+// replacing upsample_concat x 4 + the K = 512 fuse GEMM + classify_sigmoid: the [P, 512] concat (1.07 GB per 16 pages at 1024^2) is
+// neither written nor read, and neither is the fuse GEMM's output. Same lane geometry as classify_sigmoid_kernel: 16 lanes share a
+// pixel and walk its channel row in 16-byte steps; the low-resolution taps of neighbouring pixels are the same cache lines.
+struct UpsumSrc {
+    const void* p[3];
+    int h[3], w[3];
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_upsum_classify_kernel(const T* __restrict__ z0, UpsumSrc src, const T* __restrict__ w,
+                                                                  const T* __restrict__ bias, float* __restrict__ out, long P, int H0,
+                                                                  int W0, int C, int L) {
+    constexpr int V = Ty<T>::V16;
+    const int sub = threadIdx.x & 15;
+    const long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long pc = p < P ? p : P - 1;                      // clamped: all 16 lanes of a row take part in the DPP sums
+    const int x = (int)(pc % W0), y = (int)((pc / W0) % H0);
+    const long b = pc / ((long)W0 * H0);
+    long o00[3], o01[3], o10[3], o11[3];
+    float ly[3], lx[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < src.n) {
+            int y0, y1, x0, x1;
+            bilin_coeff(y, src.h[s], (float)src.h[s] / (float)H0, y0, y1, ly[s]);
+            bilin_coeff(x, src.w[s], (float)src.w[s] / (float)W0, x0, x1, lx[s]);
+            const long base = b * src.h[s] * src.w[s];
+            o00[s] = (base + (long)y0 * src.w[s] + x0) * C; o01[s] = (base + (long)y0 * src.w[s] + x1) * C;
+            o10[s] = (base + (long)y1 * src.w[s] + x0) * C; o11[s] = (base + (long)y1 * src.w[s] + x1) * C;
+        }
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* row = z0 + pc * C;
+    for (int c = sub * V; c < C; c += 16 * V) {
+        float v[V];
+        unpack16(*reinterpret_cast<const uint4*>(row + c), v, (T*)nullptr);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (s < src.n) {
+                const T* zs = reinterpret_cast<const T*>(src.p[s]) + c;
+                float a[V], bq[V], cq[V], d[V];
+                unpack16(*reinterpret_cast<const uint4*>(zs + o00[s]), a, (T*)nullptr);
+                unpack16(*reinterpret_cast<const uint4*>(zs + o01[s]), bq, (T*)nullptr);
+                unpack16(*reinterpret_cast<const uint4*>(zs + o10[s]), cq, (T*)nullptr);
+                unpack16(*reinterpret_cast<const uint4*>(zs + o11[s]), d, (T*)nullptr);
+#pragma unroll
+                for (int i = 0; i < V; ++i)     // the expression of upsample_concat_kernel
+                    v[i] += (1.f - ly[s]) * ((1.f - lx[s]) * a[i] + lx[s] * bq[i]) + ly[s] * ((1.f - lx[s]) * cq[i] + lx[s] * d[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = Ty<T>::rnd(fmaxf(v[i], 0.f));
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (l < L) {
+                float wv[V];
+                unpack16(*reinterpret_cast<const uint4*>(w + (long)l * C + c), wv, (T*)nullptr);
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[l] += v[i] * wv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) acc[l] = row16_sum(acc[l]);
+    if (sub == 0 && p < P) {
+        const long HW = (long)H0 * W0, r = p % HW;
+        for (int l = 0; l < L; ++l) {
+            const float z = Ty<T>::rnd(acc[l] + Ty<T>::ld(bias + l));
+            out[(b * L + l) * HW + r] = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));       // expit in the model dtype, then .float()
+        }
+    }
+}
+
+// The same pass, register-blocked (gpurun r04k: the per-pixel kernel above issues 13 16-byte loads per pixel and channel chunk --
+// 4 taps x 3 addends + z0 -- and is bound by the texture-address path, ~1.1 ms per 16 pages, which ate everything the fold had
+// saved). Here 16 lanes own a 4 x 2 block of output pixels; for a stage R = 2 / 4 / 8 times coarser (R a power of two, block aligned)
+// the taps of the 8 pixels are a 3 x 4 / 2 x 3 / 2 x 2 tile of the coarse map whose positions RELATIVE to the first pixel's tap are
+// compile-time constants, so the tile is loaded once (12 / 6 / 4 loads instead of 32), interpolated horizontally once per tile row and
+// vertically per pixel: 30 loads per 8 pixels instead of 104. The bilinear form is PyTorch's with the source index clamped instead of
+// the source coordinate (a border pixel reads the edge row twice with weights that sum to 1): equal up to one fp32 rounding.
+template <int R, int BH> struct UpsumGeo {              // BH = pixel rows of the block (2, or 1: fewer registers, a third wave per SIMD)
+    static constexpr int NR = (R == 2 && BH == 2) ? 3 : 2, NC = R == 2 ? 4 : (R == 4 ? 3 : 2);
+    __device__ static constexpr int offy(int py) { return (R == 2 && BH == 2) ? py : 0; }
+    __device__ static constexpr int offx(int px) { return R == 2 ? (px + 1) / 2 : (R == 4 ? px / 2 : 0); }
+};
+
+// The arithmetic runs on fp32 PAIRS (v_pk_mul_f32 / v_pk_fma_f32: the first blocked version spent ~30 scalar VALU operations per value
+// -- 1.14 ms per 16 pages, gpurun r04k, VALU-bound at one wave per SIMD -- unpack, two interpolation passes, a software bf16 rounding
+// and two multiply-adds); the bf16 path rounds y with v_cvt_pk_bf16_f32 and feeds the classifier's bf16 weight pairs to
+// v_dot2c_f32_bf16 (exact products, fp32 accumulation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+template <typename T> struct UpsumPk;
+template <> struct UpsumPk<bf16_t> {
+    static constexpr int NP = 4;                             // pairs per 16-byte chunk
+    __device__ __forceinline__ static void unpack(const uint4& r, f32x2 (&o)[4]) {
+        o[0] = f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+        o[1] = f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+        o[2] = f32x2{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)};
+        o[3] = f32x2{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+    }
+};
+template <> struct UpsumPk<float> {
+    static constexpr int NP = 2;
+    __device__ __forceinline__ static void unpack(const uint4& r, f32x2 (&o)[2]) {
+        o[0] = f32x2{__uint_as_float(r.x), __uint_as_float(r.y)};
+        o[1] = f32x2{__uint_as_float(r.z), __uint_as_float(r.w)};
+    }
+};
+
+// An addend's tap tile as it comes from memory. Loading (upsum_load) and using (upsum_apply) are separate calls so that the kernel can
+// request z0's 8 rows and all three tiles -- 30 16-byte loads per lane -- BEFORE the first value is needed: with the loads placed next
+// to their uses the compiler waited per tile row, eight dependent L2 / HBM round trips per channel chunk (701 us per 16 pages, r04k).
+template <int R, int BH> struct UpsumTile { uint4 raw[UpsumGeo<R, BH>::NR][UpsumGeo<R, BH>::NC]; int iy0, ix0; };
+
+template <typename T, int R, int BH>
+__device__ __forceinline__ void upsum_load(UpsumTile<R, BH>& t, const T* __restrict__ zs, long img, int Hs, int Ws, int C, int by, int bx) {
+    typedef UpsumGeo<R, BH> G;
+    // first pixel's source coordinate and tap (may be -1 at the top / left edge: clamped when the tile is addressed)
+    const float sy0 = ((float)(BH * by) + 0.5f) / (float)R - 0.5f, sx0 = ((float)(4 * bx) + 0.5f) / (float)R - 0.5f;
+    t.iy0 = (int)floorf(sy0); t.ix0 = (int)floorf(sx0);
+#pragma unroll
+    for (int r = 0; r < G::NR; ++r) {
+        const int row = min(max(t.iy0 + r, 0), Hs - 1);
+#pragma unroll
+        for (int c = 0; c < G::NC; ++c) {
+            const int col = min(max(t.ix0 + c, 0), Ws - 1);
+            t.raw[r][c] = *reinterpret_cast<const uint4*>(zs + ((img * Hs + row) * Ws + col) * C);
+        }
+    }
+}
+
+template <typename T, int R, int BH, int NP>
+__device__ __forceinline__ void upsum_apply(f32x2 (&v)[BH][4][NP], const UpsumTile<R, BH>& tile, int by, int bx) {
+    typedef UpsumGeo<R, BH> G;
+    float lyv[BH], lxv[4];
+#pragma unroll
+    for (int py = 0; py < BH; ++py) lyv[py] = (((float)(BH * by + py) + 0.5f) / (float)R - 0.5f) - (float)(tile.iy0 + G::offy(py));
+#pragma unroll
+    for (int px = 0; px < 4; ++px) lxv[px] = (((float)(4 * bx + px) + 0.5f) / (float)R - 0.5f) - (float)(tile.ix0 + G::offx(px));
+#pragma unroll
+    for (int r = 0; r < G::NR; ++r) {                       // one tile row at a time: interpolate it for the block's 4 columns, hand it to the rows that use it
+        f32x2 t[G::NC][NP];
+#pragma unroll
+        for (int c = 0; c < G::NC; ++c) UpsumPk<T>::unpack(tile.raw[r][c], t[c]);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const f32x2 l1 = f32x2{lxv[px], lxv[px]}, l0 = f32x2{1.f - lxv[px], 1.f - lxv[px]};
+            f32x2 hx[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) hx[i] = l0 * t[G::offx(px)][i] + l1 * t[G::offx(px) + 1][i];
+#pragma unroll
+            for (int py = 0; py < BH; ++py) {
+                if (G::offy(py) == r) {                     // compile-time after unrolling: this row is the pixel row's upper tap ...
+                    const f32x2 wy = f32x2{1.f - lyv[py], 1.f - lyv[py]};
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) v[py][px][i] += wy * hx[i];
+                } else if (G::offy(py) + 1 == r) {          // ... or its lower tap
+                    const f32x2 wy = f32x2{lyv[py], lyv[py]};
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) v[py][px][i] += wy * hx[i];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int R1, int R2, int R3, int BH>   // ratios of the addends (0 = absent); pixel rows per block
+__global__ __launch_bounds__(256) void head_upsum_classify_blk_kernel(const T* __restrict__ z0, const T* __restrict__ z1,
+                                                                      const T* __restrict__ z2, const T* __restrict__ z3,
+                                                                      const T* __restrict__ w, const T* __restrict__ bias,
+                                                                      float* __restrict__ out, int B, int H0, int W0, int C, int L) {
+    constexpr int V = Ty<T>::V16, NP = UpsumPk<T>::NP;
+    constexpr bool BF = std::is_same<T, bf16_t>::value;
+    const int sub = threadIdx.x & 15;
+    const int bw = W0 / 4, bh = H0 / BH;
+    const long nblk = (long)B * bh * bw;
+    const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long gc = g < nblk ? g : nblk - 1;                // clamped: all 16 lanes take part in the DPP sums
+    const int bx = (int)(gc % bw), by = (int)((gc / bw) % bh);
+    const long img = gc / ((long)bw * bh);
+    float acc[BH][4][2];                                     // bf16: dot2 accumulators; fp32: the two halves are kept apart in accp
+    f32x2 accp[BH][4][2];
+#pragma unroll
+    for (int py = 0; py < BH; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) { acc[py][px][l] = 0.f; accp[py][px][l] = f32x2{0.f, 0.f}; }
+    const long w1off = (long)(L > 1 ? 1 : 0) * C;
+    for (int c = sub * V; c < C; c += 16 * V) {
+        // every load of this chunk first ...
+        uint4 zr[BH][4];
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+                zr[py][px] = *reinterpret_cast<const uint4*>(z0 + ((img * H0 + BH * by + py) * W0 + 4 * bx + px) * C + c);
+        UpsumTile<R1 ? R1 : 2, BH> t1; UpsumTile<R2 ? R2 : 2, BH> t2; UpsumTile<R3 ? R3 : 2, BH> t3;
+        if constexpr (R1 > 0) upsum_load<T, R1, BH>(t1, z1 + c, img, H0 / R1, W0 / R1, C, by, bx);
+        if constexpr (R2 > 0) upsum_load<T, R2, BH>(t2, z2 + c, img, H0 / R2, W0 / R2, C, by, bx);
+        if constexpr (R3 > 0) upsum_load<T, R3, BH>(t3, z3 + c, img, H0 / R3, W0 / R3, C, by, bx);
+        const uint4 w0r = *reinterpret_cast<const uint4*>(w + c), w1r = *reinterpret_cast<const uint4*>(w + w1off + c);
+        // ... then the arithmetic, in load order
+        f32x2 v[BH][4][NP];
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) UpsumPk<T>::unpack(zr[py][px], v[py][px]);
+        if constexpr (R1 > 0) upsum_apply<T, R1, BH, NP>(v, t1, by, bx);
+        if constexpr (R2 > 0) upsum_apply<T, R2, BH, NP>(v, t2, by, bx);
+        if constexpr (R3 > 0) upsum_apply<T, R3, BH, NP>(v, t3, by, bx);
+        const uint32_t w0u[4] = {w0r.x, w0r.y, w0r.z, w0r.w}, w1u[4] = {w1r.x, w1r.y, w1r.z, w1r.w};
+        f32x2 w0p[NP], w1p[NP];
+        if constexpr (!BF) { UpsumPk<T>::unpack(w0r, w0p); UpsumPk<T>::unpack(w1r, w1p); }
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const f32x2 yv = f32x2{fmaxf(v[py][px][i].x, 0.f), fmaxf(v[py][px][i].y, 0.f)};
+                    if constexpr (BF) {
+                        const bf16x2_t yb = __builtin_convertvector(yv, bf16x2_t);       // y = T(relu(v)), round to nearest even
+                        acc[py][px][0] = __builtin_amdgcn_fdot2_f32_bf16(yb, __builtin_bit_cast(bf16x2_t, w0u[i]), acc[py][px][0], false);
+                        acc[py][px][1] = __builtin_amdgcn_fdot2_f32_bf16(yb, __builtin_bit_cast(bf16x2_t, w1u[i]), acc[py][px][1], false);
+                    } else {
+                        accp[py][px][0] += yv * w0p[i];
+                        accp[py][px][1] += yv * w1p[i];
+                    }
+                }
+    }
+    const long HW = (long)H0 * W0;
+    const float bl[2] = {Ty<T>::ld(bias), Ty<T>::ld(bias + (L > 1 ? 1 : 0))};     // once, not per output (16 dependent round trips in r04k's ISA)
+#pragma unroll
+    for (int py = 0; py < BH; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const float a = row16_sum(BF ? acc[py][px][l] : accp[py][px][l].x + accp[py][px][l].y);
+                if (sub == 0 && g < nblk && l < L) {
+                    const float z = Ty<T>::rnd(a + bl[l]);
+                    out[(img * L + l) * HW + (long)(BH * by + py) * W0 + 4 * bx + px] = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));
+                }
+            }
+}
+
 // fp32 planes [N, Hs, Ws] -> [N, Hd, Wd], bilinear align_corners=False (detection/__init__.py:121-129).
 __global__ void upsample_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -69,8 +69,44 @@ struct DetModel : DetBase {
                 hipStream_t s, int pix = 3) override {
         if (B <= 0 || B > max_batch) return SA_ERR_ARG;
         int rc;
+        UpsumSrc upsum{};                                   // low-resolution addends declared for the next SA_DET_UPSUM_CLASSIFY
         for (const surya_det_op& op : ops) {
             switch (op.type) {
+                case SA_DET_UPSUM_SRC: {
+                    if (upsum.n >= 3) return SA_ERR_UNSUPPORTED;
+                    upsum.p[upsum.n] = bufs[op.in0]; upsum.h[upsum.n] = op.hin; upsum.w[upsum.n] = op.win;
+                    ++upsum.n;
+                    break;
+                }
+                case SA_DET_UPSUM_CLASSIFY: {
+                    const long HWl = (long)op.hin * op.win, P = (long)B * HWl;
+                    if (op.cin % Ty<T>::V16 || op.cout > 4) return SA_ERR_SHAPE;
+                    // the register-blocked kernel takes addends exactly 2 / 4 / 8 times coarser (every shipped configuration: the stage
+                    // strides are 2) and <= 2 labels; anything else runs the per-pixel kernel
+                    bool blk = tuning().det_head_blk && upsum.n == 3 && op.cout <= 2 && op.hin % 8 == 0 && op.win % 8 == 0;
+                    for (int i = 0; i < 3 && blk; ++i)
+                        blk = upsum.h[i] * (2 << i) == op.hin && upsum.w[i] * (2 << i) == op.win;
+                    if (blk && tuning().det_head_blk == 2) {     // 4 x 1 blocks
+                        const long nblk = (long)B * op.hin * (op.win / 4);
+                        hipLaunchKernelGGL((head_upsum_classify_blk_kernel<T, 2, 4, 8, 1>), dim3((unsigned)cdivl(nblk, 16)), dim3(256), 0, s,
+                                           bufs[op.in0], reinterpret_cast<const T*>(upsum.p[0]), reinterpret_cast<const T*>(upsum.p[1]),
+                                           reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx), WT(op.b_idx), planes, B, op.hin, op.win,
+                                           op.cin, op.cout);
+                    } else if (blk) {                            // 4 x 2 blocks
+                        const long nblk = (long)B * (op.hin / 2) * (op.win / 4);
+                        hipLaunchKernelGGL((head_upsum_classify_blk_kernel<T, 2, 4, 8, 2>), dim3((unsigned)cdivl(nblk, 16)), dim3(256), 0, s,
+                                           bufs[op.in0], reinterpret_cast<const T*>(upsum.p[0]), reinterpret_cast<const T*>(upsum.p[1]),
+                                           reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx), WT(op.b_idx), planes, B, op.hin, op.win,
+                                           op.cin, op.cout);
+                    } else {
+                        hipLaunchKernelGGL(head_upsum_classify_kernel<T>, dim3((unsigned)cdivl(P, 16)), dim3(256), 0, s, bufs[op.in0], upsum,
+                                           WT(op.w_idx), WT(op.b_idx), planes, P, op.hin, op.win, op.cin, op.cout);
+                    }
+                    upsum.n = 0;
+                    if (lowres)
+                        SA_HIP(hipMemcpyAsync(lowres, planes, (size_t)P * op.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    break;
+                }
                 case SA_DET_INPUT: {
                     const long P = (long)B * op.hin * op.win;
                     if (pixels_u8) {

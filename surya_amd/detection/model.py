@@ -29,7 +29,11 @@ class HipDetModel:
         self.height, self.width, self.max_batch = height, width, max_batch
         torch.cuda.set_device(self.device)
         plan = build_det_plan(cfg, state_dict, height, width)
-        self.flops_per_image = plan.flops_per_image
+        # algorithmic FLOPs per page = the reference's own op order; the folded decode head executes fewer
+        self.flops_per_image = plan.reference_flops_per_image
+        self.executed_flops_per_image = plan.flops_per_image
+        from .plan import OP_LITEMLA, OP_UPSUM_SRC
+        self.launches_per_forward = sum(2 if o["type"] == OP_LITEMLA else (0 if o["type"] == OP_UPSUM_SRC else 1) for o in plan.ops)
         self.weights = [w.to(device=self.device, dtype=dtype).contiguous() for w in plan.weights]
         if broadcast_weights:             # every rank planned the op list (shapes); the folded weights used are rank 0's
             from .. import dist as sdist

@@ -17,7 +17,7 @@ import torch
 
 from ..config import DetConfig
 
-(OP_INPUT, OP_CONV, OP_DWCONV, OP_GROUPED1X1, OP_LITEMLA, OP_UPCAT, OP_CLASSIFY, OP_UPSAMPLE_OUT) = range(8)
+(OP_INPUT, OP_CONV, OP_DWCONV, OP_GROUPED1X1, OP_LITEMLA, OP_UPCAT, OP_CLASSIFY, OP_UPSAMPLE_OUT, OP_UPSUM_SRC, OP_UPSUM_CLASSIFY) = range(10)
 ACT_NONE, ACT_HSWISH, ACT_RELU = 0, 1, 2
 
 
@@ -30,7 +30,8 @@ class DetPlan:
     ops: List[dict] = field(default_factory=list)
     weights: List[torch.Tensor] = field(default_factory=list)      # fp32 CPU, kernel layout
     buf_elems: List[int] = field(default_factory=list)             # per image
-    flops_per_image: float = 0.0
+    flops_per_image: float = 0.0                                   # of the ops as listed (what the device executes)
+    reference_flops_per_image: float = 0.0                         # of the reference's own op order (the algorithmic figure of SURVEY 8(d))
 
     def new_buf(self, elems: int) -> int:
         self.buf_elems.append(int(elems))
@@ -53,7 +54,12 @@ def _fold(sd, p, eps):
     return w, b
 
 
-def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, width: int) -> DetPlan:
+def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, width: int, folded_head: bool | None = None) -> DetPlan:
+    """folded_head (default: on unless DETECTOR_HEAD_UNFOLDED=1): the decode head as sum_s up(A_s x_s) + c (see the head below);
+    False keeps the reference's op order (linear_c, upsample, concat, linear_fuse) -- the checker of tests/test_gpu_det.py."""
+    if folded_head is None:
+        from ..settings import settings
+        folded_head = not settings.DETECTOR_HEAD_UNFOLDED
     pl = DetPlan()
     eps = cfg.layer_norm_eps
     CP = 8                                                   # input channels padded 3 -> 8 (16-byte NHWC pixels)
@@ -136,21 +142,52 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
     nst = len(feats)
     h0, w0 = feats[0][1]
     dl = cfg.decoder_layer_hidden_size
-    cat = pl.new_buf(h0 * w0 * dl * nst)
-    for i, (fb, fhw, fc) in enumerate(feats):
-        wl = sd[f"decode_head.linear_c.{i}.proj.weight"].float().reshape(dl, fc, 1, 1)
-        y, _, _ = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(wl, sd[f"decode_head.linear_c.{i}.proj.bias"].float()))
-        pl.ops.append(dict(type=OP_UPCAT, in0=y, in1=-1, out=cat, res=-1, cin=dl, cout=dl * nst, k=0, stride=0, act=0, hin=fhw[0],
-                           win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=(nst - 1 - i) * dl, p1=0))   # cat(...[::-1]) :715
     wf = sd["decode_head.linear_fuse.weight"].float()
     scale = sd["decode_head.batch_norm.weight"].float() / torch.sqrt(sd["decode_head.batch_norm.running_var"].float() + 1e-5)
     bf = sd["decode_head.batch_norm.bias"].float() - sd["decode_head.batch_norm.running_mean"].float() * scale
-    y, _, ch = conv(cat, (h0, w0), dl * nst, None, 1, 1, ACT_RELU, wb=(wf * scale.view(-1, 1, 1, 1), bf))
+    # what the reference's order costs (the algorithmic FLOPs of the head, whichever form runs)
+    head_ref_flops = sum(2.0 * fhw[0] * fhw[1] * dl * fc for _, fhw, fc in feats) + 2.0 * h0 * w0 * wf.shape[0] * dl * nst
+    flops_before_head = pl.flops_per_image
+    folded = folded_head and 1 <= nst <= 4 and all(fhw == (h0, w0) for _, fhw, _ in feats[:1])
+    if folded:
+        # Everything between the stage outputs and the ReLU is linear, and a 1x1 convolution commutes with a bilinear resize (its taps
+        # sum to 1, so constants pass through): linear_fuse(cat_s(up(W_s x_s + b_s))) = sum_s up(A_s x_s) + c with
+        #   A_s = (bn_scale * W_fuse[:, block of stage s]) W_s   [decoder_hidden, C_s],   c = bn_shift + sum_s (bn_scale * W_fuse_s) b_s.
+        # cat(...[::-1]) (:715) puts stage i into channel block nst - 1 - i. One 1x1 conv per stage at the stage's OWN resolution, then
+        # one pass over the full-resolution stage adds the resized others, applies ReLU + classifier + sigmoid (OP_UPSUM_CLASSIFY).
+        # The [h0, w0, 4 x 128] concat and the K = 512 GEMM over it are gone; fp32 results agree with the reference order to
+        # re-association (tests: <= 1e-4 on the [0, 1] maps against the oracle, which keeps the reference's order).
+        wfs = (wf * scale.view(-1, 1, 1, 1)).reshape(wf.shape[0], nst, dl)
+        c_all = bf.clone()
+        zs = []
+        for i, (fb, fhw, fc) in enumerate(feats):
+            blk = wfs[:, nst - 1 - i, :]                                               # [ch, dl]
+            a_s = blk @ sd[f"decode_head.linear_c.{i}.proj.weight"].float().reshape(dl, fc)
+            c_all = c_all + blk @ sd[f"decode_head.linear_c.{i}.proj.bias"].float()
+            zs.append((a_s, fb, fhw, fc))
+        z_bufs = []
+        for i, (a_s, fb, fhw, fc) in enumerate(zs):
+            z, _, ch = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(a_s.reshape(a_s.shape[0], fc, 1, 1), c_all if i == 0 else None))
+            z_bufs.append((z, fhw))
+        for z, fhw in z_bufs[1:]:
+            pl.ops.append(dict(type=OP_UPSUM_SRC, in0=z, in1=-1, out=-1, res=-1, cin=ch, cout=ch, k=0, stride=0, act=0, hin=fhw[0],
+                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=0, p1=0))
+        y = z_bufs[0][0]
+        pl.flops_per_image += sum(8.0 * h0 * w0 * ch for _ in z_bufs[1:])                # 4 taps, multiply-add, per addend
+    else:
+        cat = pl.new_buf(h0 * w0 * dl * nst)
+        for i, (fb, fhw, fc) in enumerate(feats):
+            wl = sd[f"decode_head.linear_c.{i}.proj.weight"].float().reshape(dl, fc, 1, 1)
+            y, _, _ = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(wl, sd[f"decode_head.linear_c.{i}.proj.bias"].float()))
+            pl.ops.append(dict(type=OP_UPCAT, in0=y, in1=-1, out=cat, res=-1, cin=dl, cout=dl * nst, k=0, stride=0, act=0, hin=fhw[0],
+                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=(nst - 1 - i) * dl, p1=0))   # cat(...[::-1]) :715
+        y, _, ch = conv(cat, (h0, w0), dl * nst, None, 1, 1, ACT_RELU, wb=(wf * scale.view(-1, 1, 1, 1), bf))
     L = cfg.num_labels
-    pl.ops.append(dict(type=OP_CLASSIFY, in0=y, in1=-1, out=-1, res=-1, cin=ch, cout=L, k=1, stride=1, act=0, hin=h0, win=w0,
+    pl.ops.append(dict(type=OP_UPSUM_CLASSIFY if folded else OP_CLASSIFY, in0=y, in1=-1, out=-1, res=-1, cin=ch, cout=L, k=1, stride=1, act=0, hin=h0, win=w0,
                        hout=h0, wout=w0, w_idx=pl.add_weight(sd["decode_head.classifier.weight"].float().reshape(L, ch)),
                        b_idx=pl.add_weight(sd["decode_head.classifier.bias"].float()), p0=0, p1=0))
     pl.flops_per_image += 2.0 * h0 * w0 * ch * L
+    pl.reference_flops_per_image = flops_before_head + head_ref_flops + 2.0 * h0 * w0 * ch * L
     pl.ops.append(dict(type=OP_UPSAMPLE_OUT, in0=-1, in1=-1, out=-1, res=-1, cin=0, cout=L, k=0, stride=0, act=0, hin=h0, win=w0,
                        hout=height, wout=width, w_idx=-1, b_idx=-1, p0=0, p1=0))
     return pl

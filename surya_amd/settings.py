@@ -37,6 +37,9 @@ class Settings:
         self.DETECTOR_MIN_PARALLEL_THRESH: int = _env("DETECTOR_MIN_PARALLEL_THRESH", int, 3)
         self.DETECTOR_POSTPROCESS_HOST: bool = _env("DETECTOR_POSTPROCESS_HOST", bool, False)   # this implementation only
         self.DETECTOR_RESIZE_HOST: bool = _env("DETECTOR_RESIZE_HOST", bool, False)   # this implementation only
+        # keep the decode head in the reference's op order (linear_c, upsample, concat, linear_fuse) instead of the folded form
+        # (detection/plan.py): the checker of the folded head in tests/test_gpu_det.py
+        self.DETECTOR_HEAD_UNFOLDED: bool = _env("DETECTOR_HEAD_UNFOLDED", bool, False)   # this implementation only
         self.DETECTOR_BOX_Y_EXPAND_MARGIN: float = _env("DETECTOR_BOX_Y_EXPAND_MARGIN", float, 0.05)
         # recognition (settings.py:77-94)
         self.RECOGNITION_MAX_TOKENS: Optional[int] = _env("RECOGNITION_MAX_TOKENS", int, None)

@@ -60,6 +60,50 @@ def test_det_bf16_vs_oracle(hip_lib, name, size, n):
     assert err.mean().item() <= max(4e-3, 2 * ref_err.mean().item())
 
 
+@pytest.mark.parametrize("name,size,n,dtype", [("DET-TINY", 256, 2, torch.float32), ("DET-DEFAULT", 256, 1, torch.float32),
+                                               ("DET-DEFAULT", 256, 1, torch.bfloat16), ("DET-TINY", 160, 2, torch.bfloat16)])
+def test_det_folded_head_vs_reference_order(hip_lib, name, size, n, dtype):
+    """The decode head as sum_s up(A_s x_s) + c (detection/plan.py; SA_DET_UPSUM_CLASSIFY) against the SAME engine running the
+    reference's op order (linear_c -> upsample -> concat -> linear_fuse, DETECTOR_HEAD_UNFOLDED=1) and against the oracle: the two
+    forms agree to fp32 re-association in reference mode, and in bf16 the folded form is no further from the fp32 oracle than the
+    unfolded one (it has fewer rounding points)."""
+    from surya_amd.settings import settings
+    x = do.normalise_pages(make_pages(n, size, seed=77))
+    ref = do.heatmaps(sd := make_det_weights(det_config(name), 0), det_config(name), x)
+    maps = {}
+    for unfolded in (True, False):
+        settings.DETECTOR_HEAD_UNFOLDED = unfolded
+        try:
+            cfg, _, m = build(name, size, dtype)
+        finally:
+            settings.DETECTOR_HEAD_UNFOLDED = False
+        from surya_amd.detection.plan import OP_UPCAT, OP_UPSUM_CLASSIFY, build_det_plan
+        types = [o["type"] for o in build_det_plan(cfg, sd, size, size, folded_head=not unfolded).ops]
+        assert (OP_UPCAT in types) == unfolded and (OP_UPSUM_CLASSIFY in types) == (not unfolded)
+        heat, low = m.forward(x.cuda(), want_lowres=True)
+        maps[unfolded] = (heat.cpu(), low.cpu())
+    d_up = (maps[True][0] - maps[False][0]).abs().max().item()
+    d_low = (maps[True][1] - maps[False][1]).abs().max().item()
+    e_f = (maps[False][0] - ref).abs().max().item()
+    e_u = (maps[True][0] - ref).abs().max().item()
+    print(f"{name} {dtype}: folded vs unfolded {d_up:.2e} / {d_low:.2e}; vs oracle folded {e_f:.2e} unfolded {e_u:.2e}")
+    if dtype == torch.float32:
+        assert d_up <= 2e-5 and d_low <= 2e-5 and e_f <= 1e-4
+    else:
+        assert e_f <= max(3e-2, 1.5 * e_u)
+    # the per-pixel form of the sum + classify pass (det_head_blk = 0; also what odd ratios take) against the register-blocked one
+    import ctypes as C
+    from surya_amd import _lib as L
+    L.check(L.lib().surya_set_tuning(b"det_head_blk", C.c_int(0)), "surya_set_tuning")
+    try:
+        heat_px, low_px = m.forward(x.cuda(), want_lowres=True)
+    finally:
+        L.check(L.lib().surya_set_tuning(b"det_head_blk", C.c_int(1)), "surya_set_tuning")
+    d_px = (low_px.cpu() - maps[False][1]).abs().max().item()
+    print(f"   per-pixel vs blocked kernel: {d_px:.2e}")
+    assert d_px <= (2e-6 if dtype == torch.float32 else 8e-3)      # bf16: one rounding of y = T(relu(v)) may flip at a tie of the fp32 sums
+
+
 def test_det_batch_and_capacity(hip_lib):
     cfg, sd, m = build("DET-TINY", 128, torch.float32, max_batch=3)
     x = do.normalise_pages(make_pages(3, 128, seed=7)).cuda()
