@@ -987,9 +987,14 @@ class RecognitionPredictor(BasePredictor):
     stream_detection: bool = settings.RECOGNITION_STREAM_DETECTION
 
     def _can_stream(self, det_predictor) -> bool:
+        """This package's detector on its device post-processing path, one process, and a `__call__` nobody overrode (a subclass that
+        filters or edits the results in `__call__` must keep seeing every page before the first crop is cut: serial path)."""
+        from ..detection.predictor import DetectionPredictor
         return (self.stream_detection and self.device_preprocess and not self.shard_lines
-                and callable(getattr(det_predictor, "iter_detect", None)) and getattr(det_predictor, "device_postprocess", False)
-                and not getattr(det_predictor, "shard_pages", False))
+                and isinstance(det_predictor, DetectionPredictor)
+                and type(det_predictor).__call__ is DetectionPredictor.__call__ and type(det_predictor)._call is DetectionPredictor._call
+                and type(det_predictor).iter_detect is DetectionPredictor.iter_detect
+                and det_predictor.device_postprocess and not det_predictor.shard_pages)
 
     def _call_streamed(self, images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images,
                        sort_lines, math_mode, return_words, drop_repeated_text, stamps, t_call) -> List[OCRResult]:

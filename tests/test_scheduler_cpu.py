@@ -260,3 +260,37 @@ def test_fed_loop_rejects_ids_out_of_sequence_and_oversized_budgets():
     it = iter([prep])
     with pytest.raises(AssertionError, match="overall_max_tokens"):
         pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": 4}, 4, feed=lambda block: next(it))
+
+
+def test_streamed_call_is_only_taken_with_this_packages_unmodified_detector():
+    """_can_stream: the detector must be this package's DetectionPredictor on its device post-processing path in one process, and
+    nobody may have overridden its __call__ / _call / iter_detect (a subclass that edits the results there must keep seeing every
+    page before the first crop is cut). Anything else -- incl. any callable with the reference's contract -- takes the serial path."""
+    from surya_amd.detection.predictor import DetectionPredictor
+    from surya_amd.recognition.predictor import RecognitionPredictor
+    rec = object.__new__(RecognitionPredictor)
+    rec.stream_detection, rec.device_preprocess, rec.shard_lines = True, True, False
+
+    def det(cls=DetectionPredictor, post=True, shard=False):
+        d = object.__new__(cls)
+        d.device_postprocess, d.shard_pages = post, shard
+        return d
+
+    class OnlyModelHook(DetectionPredictor):
+        def batch_heatmaps(self, images, batch_size=None):
+            return super().batch_heatmaps(images, batch_size)
+
+    class EditsResults(DetectionPredictor):
+        def __call__(self, images, batch_size=None, include_maps=False):
+            return super().__call__(images, batch_size, include_maps)[:1]
+
+    assert rec._can_stream(det()) and rec._can_stream(det(OnlyModelHook))
+    assert not rec._can_stream(det(EditsResults))
+    assert not rec._can_stream(det(post=False)) and not rec._can_stream(det(shard=True))
+    assert not rec._can_stream(lambda images, batch_size=None: [])
+    for attr in ("stream_detection", "device_preprocess"):
+        setattr(rec, attr, False)
+        assert not rec._can_stream(det())
+        setattr(rec, attr, True)
+    rec.shard_lines = True
+    assert not rec._can_stream(det())
