@@ -113,3 +113,33 @@ def page_pixels(image) -> np.ndarray:
     except Exception:                                   # multi-block images, exotic builds: fall through to the copying path
         pass
     return np.ascontiguousarray(np.asarray(image, dtype=np.uint8))
+
+
+_COPY_POOL = None
+
+
+def copy_pool():
+    """One small thread pool per process for staging copies and page views (thread start-up costs ~0.7 ms each: never per call)."""
+    global _COPY_POOL
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        _COPY_POOL = ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1)), thread_name_prefix="surya-amd-copy")
+    return _COPY_POOL
+
+
+def parallel_copy(dsts, srcs, min_bytes: int = 4 << 20) -> None:
+    """dsts[i][...] = srcs[i] for numpy arrays of equal shapes. Pages are 3-8 MB each and a call stages 16-128 of them into pinned
+    memory: one memcpy stream moves ~10 GB/s, i.e. 6 ms per 16 RGBX pages at 1024^2 -- as long as the detector's forward pass takes for
+    five of them. numpy releases the GIL inside a contiguous copy, so a few threads run them side by side."""
+    total = sum(int(s_.nbytes) for s_ in srcs)
+    if len(srcs) < 2 or total < min_bytes:
+        for d, s_ in zip(dsts, srcs):
+            d[...] = s_
+        return
+
+    def one(i):
+        dsts[i][...] = srcs[i]
+
+    list(copy_pool().map(one, range(len(srcs))))
+

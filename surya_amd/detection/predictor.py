@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from PIL import Image, ImageOps
 
-from ..common.imageops import page_pixels
+from ..common.imageops import copy_pool, page_pixels, parallel_copy
 from ..common.predictor import BasePredictor, ModelLoader, gc_paused
 from ..config import DetConfig, det_config
 from ..settings import settings
@@ -228,12 +228,20 @@ class DetectionPredictor(BasePredictor):
             if whole:
                 sel = heat if len(whole) == heat.shape[0] else heat[[tiles_of[pg][0] for pg in whole]].contiguous()
                 jobs.append((whole, self._post.launch(sel, tt, lt), [(pw, ph)] * len(whole)))
-            for pg in range(n_pages):                    # tall pages: strips re-assembled on the device (:134-151), one call each
-                if len(tiles_of[pg]) == 1:
-                    continue
-                strips = [heat[t, 0, : split_heights[t]] for t in tiles_of[pg]]
-                full = torch.cat(strips, 0).unsqueeze(0).contiguous()
-                jobs.append(([pg], self._post.launch(full, tt, lt), [(pw, full.shape[1])]))
+            # tall pages: strips re-assembled on the device (:134-151); pages of equal height share ONE post-processing call (a call per
+            # page was 17 launches + a D2H each: 16 letter pages spent 40 of their 77 ms there, tools/hostbench/det_letter_profile.py)
+            by_height = {}
+            for pg in range(n_pages):
+                if len(tiles_of[pg]) > 1:
+                    by_height.setdefault(sum(split_heights[t] for t in tiles_of[pg]), []).append(pg)
+            for hf, pgs in by_height.items():
+                full = torch.empty((len(pgs), hf, pw), dtype=heat.dtype, device=heat.device)
+                for i, pg in enumerate(pgs):
+                    r0 = 0
+                    for t in tiles_of[pg]:
+                        full[i, r0: r0 + split_heights[t]] = heat[t, 0, : split_heights[t]]
+                        r0 += split_heights[t]
+                jobs.append((pgs, self._post.launch(full, tt, lt), [(pw, hf)] * len(pgs)))
             job = (jobs, n_pages, tiles_of, split_heights, sizes, heat, pw)
             if prev is not None:
                 yield finish(prev)
@@ -283,8 +291,10 @@ class DetectionPredictor(BasePredictor):
             # the host path, which works in place, copies for itself in resize_image)
             batch_images = [images[j] if images[j].mode == "RGB" else images[j].convert("RGB") for j in idxs]
             split_index, split_heights, parts = [], [], []
-            for k, im in enumerate(batch_images):
-                ps, hs = split_image(im, ph, copy=False)
+            tall = sum(im.size[1] > settings.DETECTOR_IMAGE_CHUNK_HEIGHT for im in batch_images)
+            cut = (list(copy_pool().map(lambda im: split_image(im, ph, copy=False), batch_images)) if tall > 1     # PIL crop / pad release the GIL
+                   else [split_image(im, ph, copy=False) for im in batch_images])
+            for k, (ps, hs) in enumerate(cut):
                 parts.extend(ps)
                 split_index.extend([k] * len(ps))
                 split_heights.extend(hs)
@@ -294,38 +304,39 @@ class DetectionPredictor(BasePredictor):
             # rescale + normalise happen in the model's first kernel
             pw = self.processor.size["width"]
             plans = [None if not self.device_resize else plan_resize(p_.size[0], p_.size[1], (pw, ph)) for p_ in parts]
-            on_host = [k for k, pl in enumerate(plans) if pl is None]
-            px = [None] * len(parts)
-            if len(on_host) > 4:
-                if getattr(self, "_prep_pool", None) is None:               # one pool per predictor: thread start-up cost ~0.7 ms each
-                    self._prep_pool = ThreadPoolExecutor(8)
-                for k, a in zip(on_host, self._prep_pool.map(self.resize_image, [parts[k] for k in on_host])):   # PIL releases the GIL
-                    px[k] = a
+            pool = copy_pool()
+            # pixels of every part: Pillow's own memory where it can export it (page_pixels), the Pillow double resize for the parts the
+            # device path does not take; both release the GIL in their C loops, so the parts of a batch are prepared side by side
+            if len(parts) > 1:
+                px = list(pool.map(lambda k: self.resize_image(parts[k]) if plans[k] is None else page_pixels(parts[k]), range(len(parts))))
             else:
-                for k in on_host:
-                    px[k] = self.resize_image(parts[k])
-            for k, pl in enumerate(plans):
-                if pl is not None:
-                    px[k] = page_pixels(parts[k])                           # source pixels; resized on the device below
+                px = [self.resize_image(parts[k]) if plans[k] is None else page_pixels(parts[k]) for k in range(len(parts))]
             # RGBX views of PIL's own memory where it can export them (page_pixels), else repacked RGB; one stride per batch
             ready = [k for k, pl in enumerate(plans) if pl is None or not pl]          # already at the processor size
             pix = 4 if all(px[k].shape[2] == 4 for k in ready) else 3
             host = torch.empty((len(parts), ph, pw, pix), dtype=torch.uint8, pin_memory=True)   # caching host allocator
             hv = host.numpy()
-            for k in ready:
-                hv[k] = px[k] if px[k].shape[2] == pix else px[k][..., :3]
+            parallel_copy([hv[k] for k in ready], [px[k] if px[k].shape[2] == pix else px[k][..., :3] for k in ready])
             dev_batch = host.to(self.model.device, non_blocking=True)
-            for k, pl in enumerate(plans):
-                if not pl:
-                    continue
+            todo = [k for k, pl in enumerate(plans) if pl]
+            if todo:
+                # the parts that need the double LANCZOS resize: ONE pinned staging buffer and ONE H2D copy for the batch (a pinned
+                # allocation + copy + transfer per page cost ~4.7 ms of host time each: 210 pages/s on letter pages), then the resize
+                # passes part by part on the device
                 if getattr(self, "_resampler", None) is None:
                     self._resampler = DeviceResampler(self.model.device)
-                a = px[k]
-                stage = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
-                stage.numpy()[...] = a
-                cur = stage.to(self.model.device, non_blocking=True)
-                for i, tgt in enumerate(pl):                                # thumbnail's size, then the processor size
-                    cur = self._resampler.resize(cur, tgt, out=dev_batch[k] if i == len(pl) - 1 else None)
+                sizes_b = [int(px[k].nbytes) for k in todo]
+                offs_b = np.concatenate([[0], np.cumsum([(b + 255) & ~255 for b in sizes_b])]).astype(np.int64)
+                stage = torch.empty(int(offs_b[-1]), dtype=torch.uint8, pin_memory=True)
+                sv = stage.numpy()
+                parallel_copy([sv[int(o): int(o) + b].reshape(px[k].shape) for k, o, b in zip(todo, offs_b[:-1], sizes_b)],
+                              [px[k] for k in todo])
+                dev_stage = stage.to(self.model.device, non_blocking=True)
+                for k, o, b in zip(todo, offs_b[:-1], sizes_b):
+                    cur = dev_stage[int(o): int(o) + b].view(px[k].shape)
+                    pl = plans[k]
+                    for i, tgt in enumerate(pl):                            # thumbnail's size, then the processor size
+                        cur = self._resampler.resize(cur, tgt, out=dev_batch[k] if i == len(pl) - 1 else None)
             heat_parts = []
             for s in range(0, len(parts), self.model.max_batch):            # a single page may exceed max_batch tiles
                 heat_parts.append(self.model.forward_u8(dev_batch[s: s + self.model.max_batch], self.processor.image_mean,
