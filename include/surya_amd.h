@@ -123,7 +123,8 @@ int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, 
  * image embeddings stay inside the handle; a later surya_rec_prefill with tiles == NULL consumes them front to back
  * (its images must be the next ones in the order given here; grid_hw is still required). At most one look-ahead batch is
  * outstanding: SA_ERR_STATE while the previous one has unconsumed images, SA_ERR_SHAPE above max_prefill_tokens image
- * tokens. Enqueue only. */
+ * tokens. n_images == 0 (tiles / grid_hw may be NULL) discards whatever is unconsumed: what a caller does before it starts a
+ * new batch of lines if its previous loop may have ended early. Enqueue only. */
 int surya_rec_encode_ahead(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* stream);
 
 /* Set the list of slots that take part in decode steps (host bookkeeping of batch_prompt_mapping,

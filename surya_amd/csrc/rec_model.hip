@@ -494,6 +494,11 @@ struct RecModel : RecBase {
     // land in emb_ahead in image order; prefill(tiles = NULL, ...) consumes them front to back.
     int encode_ahead(const float* tiles, const int32_t* grid_hw, int n, hipStream_t s) override {
         if (c.enc_out_hidden != c.dec_hidden) return SA_ERR_SHAPE;
+        if (n == 0) {                                                    // discard: a caller whose loop ended early (an exception between
+            ahead_consumed = ahead_tokens = 0;                           // encode_ahead and the prefill that would have consumed it) starts clean;
+            return SA_OK;                                                // emb_ahead is re-used only behind ev_ahead_free / stream order as always
+        }
+        if (n < 0 || !tiles || !grid_hw) return SA_ERR_ARG;
         if (ahead_consumed != ahead_tokens) return SA_ERR_STATE;         // previous look-ahead not fully consumed
         long ntok = 0;
         for (int i = 0; i < n; ++i) ntok += (long)grid_hw[2 * i] * grid_hw[2 * i + 1] / (c.merge * c.merge);
@@ -1168,7 +1173,7 @@ int surya_rec_prefill(surya_rec* h, const float* tiles, const int32_t* grid_hw, 
     return h->impl->prefill(tiles, grid_hw, n_images, input_ids, seq_offsets, slot_ids, n_seqs, (hipStream_t)stream);
 }
 int surya_rec_encode_ahead(surya_rec* h, const float* tiles, const int32_t* grid_hw, int n_images, void* stream) {
-    if (!h || !tiles || !grid_hw || n_images <= 0) return SA_ERR_ARG;
+    if (!h || n_images < 0 || (n_images > 0 && (!tiles || !grid_hw))) return SA_ERR_ARG;      // n_images == 0: discard (see the header)
     return h->impl->encode_ahead(tiles, grid_hw, n_images, (hipStream_t)stream);
 }
 int surya_rec_set_active(surya_rec* h, const int32_t* slots, int n_active, void* stream) {

@@ -164,6 +164,10 @@ class HipRecModel:
         L.check(self.lib.surya_rec_encode_ahead(self.handle, L.ptr(tiles), L.np_ptr(grid), C.c_int(len(grid)), self._stream),
                 "surya_rec_encode_ahead")
 
+    def discard_ahead(self):
+        """Forget look-ahead embeddings nobody consumed (a loop that ended early, e.g. on an exception): the next encode_ahead starts clean."""
+        L.check(self.lib.surya_rec_encode_ahead(self.handle, None, None, C.c_int(0), self._stream), "surya_rec_encode_ahead(discard)")
+
     def set_active(self, slots: Sequence[int]):
         a = np.ascontiguousarray(np.asarray(slots, np.int32))
         L.check(self.lib.surya_rec_set_active(self.handle, L.np_ptr(a), C.c_int(len(a)), self._stream), "surya_rec_set_active")

@@ -433,6 +433,8 @@ class RecognitionPredictor(BasePredictor):
             recognition_batch_size = self.get_batch_size()
         recognition_batch_size = min(recognition_batch_size, self.model.max_slots)
         self.setup_cache(recognition_batch_size)
+        if callable(getattr(self.model, "discard_ahead", None)):
+            self.model.discard_ahead()                         # a previous loop that ended early (exception) must not poison this one
         first = prep if prep is not None else {}
         overall_max_tokens = int(first.get("overall_max_tokens") or max(first["max_tokens"].values()))
         batch_bboxes = np.zeros((0, overall_max_tokens, 6), np.float32)

@@ -227,3 +227,25 @@ def test_kv_prefetch_workgroups_change_nothing(hip_lib):
     tune(kvprefetch=1)
     b = run_steps(m, cfg, [4, 4, 3])
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_unconsumed_look_ahead_can_be_discarded(hip_lib):
+    """surya_rec_encode_ahead(n_images = 0): a second look-ahead batch is refused (SA_ERR_STATE) while the first is unconsumed, accepted
+    after a discard, and the prefill that consumes it gives the tokens of a prefill fed the tiles directly."""
+    cfg, m = build("REC-SMALL", torch.bfloat16)
+    tiles, seqs = make_prompts(cfg, GRIDS)
+    tiles = tiles.cuda()
+    slots = list(range(len(seqs)))
+    m.prefill(tiles, GRIDS, seqs, slots)
+    ref = m.read_outputs(1)[0][0][slots].copy()
+    m.encode_ahead(tiles, GRIDS)
+    with pytest.raises(L.SuryaAmdError):
+        m.encode_ahead(tiles, GRIDS)
+    m.discard_ahead()
+    m.encode_ahead(tiles, GRIDS)
+    m.prefill(None, GRIDS, seqs, slots)
+    got = m.read_outputs(1)[0][0][slots].copy()
+    assert np.array_equal(ref, got)
+    m.discard_ahead()                                    # nothing outstanding: a no-op
+    m.encode_ahead(tiles, GRIDS)
+    m.discard_ahead()

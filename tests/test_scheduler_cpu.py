@@ -54,6 +54,10 @@ class FakeModel:
         self.ahead.extend(int(tiles[off, 0]) for off in np.cumsum([0] + [h * w for h, w in grid_hw])[:-1])
         self.stats["encode_ahead"] += 1
 
+    def discard_ahead(self):
+        self.ahead.clear()
+        self.stats["discards"] = self.stats.get("discards", 0) + 1
+
     def prefill(self, tiles, grid_hw, input_ids, slot_ids):
         assert not self.inflight, "prefill while decode calls are in flight"
         assert len(grid_hw) == len(input_ids) == len(slot_ids) > 0
@@ -294,3 +298,37 @@ def test_streamed_call_is_only_taken_with_this_packages_unmodified_detector():
         setattr(rec, attr, True)
     rec.shard_lines = True
     assert not rec._can_stream(det())
+
+
+def test_a_loop_that_ended_early_does_not_poison_the_next_one():
+    """An exception between encode_ahead and the prefill that would have consumed it (here: the feed fails while look-ahead
+    embeddings of queued lines are outstanding) leaves unconsumed images in the handle; the next generate() discards them first
+    (surya_rec_encode_ahead with n_images = 0) instead of dying on SA_ERR_STATE."""
+    old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD)
+    settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = 4, True
+    try:
+        pred, prep = make(20, 12, 4)
+        first, _ = _chunks(prep, (12,))
+        state = {"n": 0}
+
+        def feed(block):
+            state["n"] += 1
+            if state["n"] == 1:
+                return first
+            if state["n"] < 4:
+                return None
+            raise RuntimeError("producer died")
+
+        with pytest.raises(RuntimeError, match="producer died"):
+            pred.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": 12}, 4, feed=feed)
+        m = pred.model
+        assert m.ahead, "the scenario needs outstanding look-ahead images"
+        m.inflight.clear(); m.ring_busy = [False, False]; m.active = []; m.prefill_out = None      # what surya_rec_* keep per call, not per loop
+        pred2, prep2 = make(9, 10, 4)
+        pred.prompt_queue.extend(prep2["prompts"])                           # stale queue content must not survive either
+        toks, _, _ = pred.generate(prep2, 4)
+        assert m.stats["discards"] >= 2 and not m.ahead
+        for i in range(9):
+            assert toks[i] == expected(i, prep2["max_tokens"][i])
+    finally:
+        settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
