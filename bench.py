@@ -945,10 +945,35 @@ def bench_table(args, local_rank):
     return out
 
 
+_JSON_FD = None
+
+
+def only_json_on_stdout():
+    """The driver reads ONE JSON line from this process's stdout. Libraries write there too -- RCCL prints a version banner through C
+    stdio on every rank of an `nccl` group, flushed at process exit, i.e. AFTER the JSON line (gpurun r04q: five banner lines behind the
+    line of a --force-dist run). So file descriptor 1 is handed to stderr for the life of the process (C stdio, Python prints, child
+    threads alike) and the JSON line goes to a private duplicate of the original descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def print_json(obj) -> None:
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+        return
+    while data:
+        data = data[os.write(_JSON_FD, data):]
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args))
+        raise SystemExit(spawn_ranks(args))             # the ranks write the line themselves (their stdout is this process's)
+    only_json_on_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -981,10 +1006,10 @@ def main():
         k, v = kv.split("=")
         _L.check(_L.lib().surya_set_tuning(k.encode(), int(v)), f"surya_set_tuning({kv})")
     if args.det_only:
-        print(json.dumps(bench_det(args, local_rank, world, rank, lambda: None)), flush=True)
+        print_json(bench_det(args, local_rank, world, rank, lambda: None))
         return
     if args.layout_only:
-        print(json.dumps({"layout": bench_layout(args, local_rank), "table_rec": bench_table(args, local_rank)}), flush=True)
+        print_json({"layout": bench_layout(args, local_rank), "table_rec": bench_table(args, local_rank)})
         return
     os.environ["RECOGNITION_MAX_TOKENS"] = str(args.max_tokens)
     if args.steps_per_sync:
@@ -1013,12 +1038,12 @@ def main():
                                  max_patches=65536, max_prefill_tokens=args.batch * 72)
 
     if args.texify_only:
-        print(json.dumps(bench_texify(args, cfg, sd, local_rank)), flush=True)
+        print_json(bench_texify(args, cfg, sd, local_rank))
         return
     RecognitionPredictor.model_loader_cls = Loader
     pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
     if args.e2e_only:
-        print(json.dumps(bench_e2e(args, pred, local_rank, world, rank, lambda: None)), flush=True)
+        print_json(bench_e2e(args, pred, local_rank, world, rank, lambda: None))
         return
     # The workload is ONE list of args.lines x world crops (seed 1234), widest first -- the predictor's own ordering -- dealt round-robin
     # to the ranks exactly as RecognitionPredictor.sharded_prediction_loop deals them (surya_amd.dist.shard_indices): every rank
@@ -1156,7 +1181,7 @@ def main():
                 return
             emitted[0] = True
             if rank == 0:
-                print(json.dumps(out), flush=True)
+                print_json(out)
 
     aux_timeout = args.aux_timeout if args.aux_timeout is not None else (900.0 if world == 1 else 240.0)
 
