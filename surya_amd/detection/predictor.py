@@ -187,9 +187,12 @@ class DetectionPredictor(BasePredictor):
         loop while the detector still works on the later ones. Single process, device post-processing only."""
         if not self.device_postprocess or self.shard_pages:
             raise RuntimeError("iter_detect needs the device post-processing path of one process (no DETECTOR_POSTPROCESS_HOST, no page sharding)")
-        return self._iter_detect_device(images, batch_size, False)
+        return self._iter_detect_device(images, batch_size, False, eager_first=True)
 
-    def _iter_detect_device(self, images, batch_size=None, include_maps=False):
+    def _iter_detect_device(self, images, batch_size=None, include_maps=False, eager_first=False):
+        """eager_first: hand the FIRST batch over as soon as its boxes exist instead of after the second batch has been prepared and
+        launched -- a consumer that starts other device work from it (the streamed recognise call) gets going one host preparation
+        (~10 ms per 16 pages) earlier, at the price of that much overlap inside the detector."""
         if getattr(self, "_post", None) is None:
             self._post = HipDetPost(self.model.device)
         tt, lt = settings.DETECTOR_TEXT_THRESHOLD, settings.DETECTOR_BLANK_THRESHOLD
@@ -246,6 +249,10 @@ class DetectionPredictor(BasePredictor):
             if prev is not None:
                 yield finish(prev)
             prev = job
+            if eager_first:
+                eager_first = False
+                yield finish(prev)
+                prev = None
         if prev is not None:
             yield finish(prev)
 
