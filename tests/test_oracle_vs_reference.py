@@ -1205,3 +1205,35 @@ def test_live_layout_and_table_checkpoint_directories_written_by_the_reference(t
     assert np.allclose(p.image_processor.image_mean, [0.4, 0.5, 0.6]) and np.allclose(p.image_processor.image_std, [0.2, 0.25, 0.3])
     assert p.image_processor.max_size == {"height": 128, "width": 128}
     assert os.path.exists(os.path.join(tpath, "preprocessor_config.json"))
+
+
+@pytest.mark.parametrize("name,size", [("DET-TINY", 160), ("DET-DEFAULT", 64)])
+def test_live_detector_op_list_incl_folded_head_against_the_reference_module(name, size):
+    """The op list the HIP interpreter executes (surya_amd/detection/plan.py), run in plain PyTorch (tests/det_plan_interp.py), against
+    the REAL EfficientViTForSemanticSegmentation on the same pixels -- for the decode head in its folded form (one 1x1 conv per stage
+    with merged weights + sum / ReLU / classifier, the default) and in the reference's own op order. What is pinned here without a GPU:
+    the BatchNorm folding, the NHWC weight layouts and the algebra of the fold; the GPU tests pin the kernels to the same numbers."""
+    import torch.nn.functional as F
+    ref_shim.install()
+    from surya.detection.model.config import EfficientViTConfig
+    from surya.detection.model.encoderdecoder import EfficientViTForSemanticSegmentation
+    from oracle.det_oracle import normalise_pages
+    from surya_amd.config import det_config
+    from surya_amd.detection.plan import build_det_plan
+    from surya_amd.synth import make_det_weights, make_pages
+    from det_plan_interp import run_plan
+    c = det_config(name)
+    rc = EfficientViTConfig(widths=c.widths, depths=c.depths, head_dim=c.head_dim, decoder_layer_hidden_size=c.decoder_layer_hidden_size,
+                            decoder_hidden_size=c.decoder_hidden_size, num_labels=c.num_labels)
+    m = EfficientViTForSemanticSegmentation(rc).eval()
+    sd = make_det_weights(c, 3)
+    m.load_state_dict(sd, strict=True)
+    x = normalise_pages(make_pages(2, size, seed=31))
+    with torch.inference_mode():
+        ref_low = m(pixel_values=x).logits                                                        # the module applies the sigmoid itself (:747)
+        ref_up = F.interpolate(ref_low, size=(size, size), mode="bilinear", align_corners=False)   # :121-129
+        for folded in (True, False):
+            low, up = run_plan(build_det_plan(c, sd, size, size, folded_head=folded), x)
+            assert (low - ref_low).abs().max().item() <= 2e-5, (folded, (low - ref_low).abs().max().item())
+            assert (up - ref_up).abs().max().item() <= 2e-5
+    assert ref_low.std().item() > 0.02
