@@ -332,3 +332,116 @@ def test_a_loop_that_ended_early_does_not_poison_the_next_one():
             assert toks[i] == expected(i, prep2["max_tokens"][i])
     finally:
         settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD = old
+
+
+# ---------------------------------------------------------------------------------------------- the streamed call, without a GPU
+def _key(poly):
+    """A line's identity for the fake model: taken from its polygon, so the expected stream does not depend on admission order."""
+    return (int(poly[0][1]) * 131 + int(poly[0][0])) % 997
+
+
+class StreamFakeModel(FakeModel):
+    """FakeModel whose scripted stream is chosen by the line KEY carried in the tiles / the prompt (not by the loop's line id)."""
+    def __init__(self, max_slots):
+        super().__init__(max_slots)
+        self.cfg = SimpleNamespace(encoder=SimpleNamespace(spatial_merge_size=2), bbox_size=1024)
+        self.device = "cpu"
+
+
+def _streamed_predictor(slots, fail_after=None):
+    from PIL import Image
+    from surya_amd.recognition.predictor import RecognitionPredictor, TaskNames
+    from surya_amd.recognition.schema import TextLine
+    pred = object.__new__(RecognitionPredictor)
+    pred.prompt_queue, pred.batch_prompt_mapping = deque(), None
+    pred.model = StreamFakeModel(slots)
+    pred.processor = SimpleNamespace(eos_token_id=EOS, pad_token_id=PAD, no_output_token=NOP)
+    pred.last_timing = {}
+    calls = {"prep": 0}
+
+    def fake_preprocess(prompts, pages):
+        calls["prep"] += 1
+        if fail_after is not None and calls["prep"] > fail_after:
+            raise RuntimeError("pre-processing failed in the producer")
+        grids = [(2, 2 + 2 * (_key(p.image.poly) % 3)) for p in prompts]
+        offs = np.cumsum([0] + [h * w for h, w in grids])
+        tiles = np.zeros((offs[-1], 3), np.float32)
+        for i, p in enumerate(prompts):
+            assert 0 <= p.image.page < len(pages)                      # references are local to the chunk's own pages
+            tiles[offs[i]:offs[i + 1], 0] = _key(p.image.poly)
+        return tiles, offs, grids, [[1000 + _key(p.image.poly), 5, 6] for p in prompts]
+
+    def fake_assemble(flat, items, drop_repeated_text, return_words, bbox_size):
+        out = []
+        for sorted_pos, orig, tokens, sc, rows in items:
+            assert flat["slices"][sorted_pos].poly == tuple(tuple(pt) for pt in flat["polygons"][orig])   # id <-> original position
+            out.append(TextLine(text=",".join(map(str, tokens)), polygon=flat["polygons"][orig], confidence=1.0, chars=[]))
+        return out
+
+    pred.preprocess_prompts_device = fake_preprocess
+    pred._assemble_batch = fake_assemble
+    return pred, calls, Image, TaskNames
+
+
+def _fake_detector(boxes_per_page, batch):
+    class Det:
+        def iter_detect(self, images, batch_size=None):
+            for a in range(0, len(images), batch):
+                yield [SimpleNamespace(bboxes=[SimpleNamespace(polygon=pl) for pl in boxes_per_page[i]])
+                       for i in range(a, min(a + batch, len(images)))]
+    return Det()
+
+
+def _page_polys(n_pages, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for pg in range(n_pages):
+        n = int(rng.integers(0, 7)) if pg % 4 != 2 else 0               # some pages have no lines at all
+        polys = []
+        for k in range(n):
+            x0, y0 = int(rng.integers(0, 40)), 10 + 17 * k + pg
+            w = int(rng.integers(8, 60))
+            polys.append([[x0, y0], [x0 + w, y0], [x0 + w, y0 + 9], [x0, y0 + 9]])
+        out.append(polys)
+    return out
+
+
+@pytest.mark.parametrize("n_pages,det_batch,slots", [(9, 2, 4), (5, 5, 3), (12, 4, 32)])
+def test_streamed_call_orchestration_on_fakes(n_pages, det_batch, slots):
+    """_call_streamed with a fake detector and the contract-checking fake model: producer thread, queue, chunk-local page indices,
+    width sort inside a chunk, admission while decoding, results put back by ORIGINAL position (pages without lines included)."""
+    old = (settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS)
+    settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS = 4, True, 12
+    try:
+        pred, calls, Image, TaskNames = _streamed_predictor(slots)
+        polys = _page_polys(n_pages, seed=n_pages)
+        images = [Image.new("RGB", (64, 160)) for _ in range(n_pages)]
+        tasks = [TaskNames.ocr_with_boxes] * n_pages
+        res = pred._call_streamed(images, tasks, _fake_detector(polys, det_batch), None, slots, [None] * n_pages, False, True, False,
+                                  False, pred.last_timing, 0.0)
+        if sum(len(p) for p in polys) == 0:
+            assert res == []
+            return
+        assert len(res) == n_pages and pred.last_timing["streamed"] == 1.0
+        for page, r in zip(polys, res):
+            assert [ln.polygon for ln in r.text_lines] == [[[float(v) for v in pt] for pt in pl] for pl in page]
+            for ln, pl in zip(r.text_lines, page):
+                assert ln.text == ",".join(map(str, expected(_key(pl), 12)))
+        assert calls["prep"] == sum(1 for a in range(0, n_pages, det_batch) if any(polys[a:a + det_batch]))
+        assert not pred.model.inflight and not pred.model.ahead
+    finally:
+        settings.RECOGNITION_STEPS_PER_SYNC, settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS = old
+
+
+def test_streamed_call_surfaces_a_producer_failure():
+    old = (settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS)
+    settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS = True, 12
+    try:
+        pred, calls, Image, TaskNames = _streamed_predictor(4, fail_after=1)
+        polys = [[[[1, 10 + 20 * k], [30, 10 + 20 * k], [30, 19 + 20 * k], [1, 19 + 20 * k]] for k in range(3)] for _ in range(6)]
+        images = [Image.new("RGB", (64, 160)) for _ in range(6)]
+        with pytest.raises(RuntimeError, match="pre-processing failed in the producer"):
+            pred._call_streamed(images, [TaskNames.ocr_with_boxes] * 6, _fake_detector(polys, 2), None, 4, [None] * 6, False, True, False,
+                                False, pred.last_timing, 0.0)
+    finally:
+        settings.RECOGNITION_ENCODE_AHEAD, settings.RECOGNITION_MAX_TOKENS = old
