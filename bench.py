@@ -1077,11 +1077,12 @@ def main():
             b = boxes.numpy()
             if b.shape[1] < args.max_tokens:
                 b = np.pad(b, ((0, 0), (0, args.max_tokens - b.shape[1]), (0, 0)))
-            all_toks, _, _ = sdist.gather_line_outputs(toks, scores, b, mine, n_global, args.max_tokens, device=coll_dev)
-            assert len(all_toks) == n_global and all(len(t) for t in all_toks)
-            if world == 1:                              # forced one-rank group: the gathered records must be this rank's own
-                assert all(list(a_) == list(b_) for a_, b_ in zip(all_toks, toks)), "all_gather_into_tensor returned different tokens"
+            ptoks, pscores = pred.last_packed            # generate()'s dense bookkeeping, as sharded_prediction_loop passes it
+            all_toks, _, _ = sdist.gather_line_outputs(ptoks, pscores, b, mine, n_global, args.max_tokens, device=coll_dev)
+            assert len(all_toks) == n_global and int(all_toks.lens.min()) > 0
             gather_s[0] += time.perf_counter() - tg
+            if world == 1:                              # forced one-rank group: the gathered records must be this rank's own (untimed check)
+                assert all_toks == toks, "all_gather_into_tensor returned different tokens"
         return toks
 
     total_tokens = 0

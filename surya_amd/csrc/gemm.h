@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         // whole super-tiles including the clipped ones, and with N = 1280 (10 tile columns = one full + one quarter
         // super-column) the odd XCDs drew only quarter super-tiles and the launch ran at 63 % (r01 microbench).
         const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 ? GLDS : 2) > 80 * 1024) ? 32 : 64;     // workgroups resident on one XCD (32 CUs x 1 or 2, by LDS)
+        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 && GLDS != 8 ? GLDS : 2) > 80 * 1024) ? 32 : 64;     // workgroups resident on one XCD (32 CUs x 1 or 2, by LDS)
         const int idx = ((j / GRP) * 8 + x) * GRP + (j % GRP);
         const int tiles_m = (p.M + BM - 1) / BM;
         if (idx >= tiles_m * tiles_n) return;
@@ -319,7 +319,139 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
             (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, W_AUX);        \
     }
-        if constexpr (GLDS == 2) {
+        if constexpr (GLDS == 8) {
+            // ---- 8-phase schedule (round 5) for the 256x256 bf16 tile: 8 waves = 4 (M) x 2 (N), 64 x 128 per wave, 2 waves per SIMD.
+            // The 2-stage loop below issues a K-tile, multiplies a whole K-tile, then drains vmcnt(0) behind a full barrier: every wave
+            // of the CU stalls once per K-tile for the youngest load (r04: 50 % matrix-pipe occupancy inside the loop). Here
+            //   * a K-tile is split in FOUR half-tiles of 16 KiB -- X0 / X1 = the first / second 32 rows of every wave row (4 x 32 rows),
+            //     W0 / W1 = the first / second 64 columns of every wave column (2 x 64 rows of W) -- and a PHASE multiplies one 32 x 64
+            //     quadrant of every wave's output over the K-tile: 8 MFMAs (256 matrix-pipe cycles) from 4 X fragments and 8 W fragments;
+            //   * the two waves of a SIMD (wave w and w + 4) run ONE barrier apart: while one multiplies a quadrant, the other reads the
+            //     next quadrant's fragments from LDS and issues one half-tile of global_load_lds; raw s_barrier on both sides of the
+            //     MFMA block, nothing drains;
+            //   * LDS holds 8 half-tile slots (2 K-tiles, 128 KiB); the half-tile read in phase P + 5 is requested in phase P (4 half-tiles
+            //     = 64 KiB in flight per CU, ~4 phases ~ 2000 cycles of latency cover) and the counted s_waitcnt vmcnt(8) of phase P only
+            //     asks for the half-tile that phase P + 1 reads -- requested four phases ago.
+            // Half-tile sequence h = 4 t + u, u: 0 = X0, 1 = W0, 2 = X1, 3 = W1 of K-tile t; read in phase h - 1, requested in phase h - 6:
+            //   phase (t, 0): read W0(t)                  multiply (X0, W0)   request X1(t+1)
+            //   phase (t, 1): read X1(t)                  multiply (X1, W0)   request W1(t+1)
+            //   phase (t, 2): read W1(t)                  multiply (X1, W1)   request X0(t+2)
+            //   phase (t, 3): read X0(t+1) (other regs)   multiply (X0, W1)   request W0(t+2)
+            // Ordering (MI355X: nothing orders a ds_read behind a pending LDS-DMA but the issuer's vmcnt + a barrier the reader passed):
+            //   RAW  the issuer waits in the load segment of phase R - 1 (before that phase's first barrier), readers read in phase R:
+            //        at least one barrier between, also across the one-barrier stagger of the two wave groups.
+            //   WAR  a slot is re-requested three phases after its last read (>= 5 barriers; the reads retire at the first MFMA).
+            // K order, MFMA and accumulator assignment are the 2-stage loop's: results are bit-identical (tools/microbench/bigtile_ab.py 1 3).
+            static_assert(BM == 256 && BN == 256 && WM == 4 && WN == 2 && !SPLIT && !CONV && sizeof(TI) == 2 && !LEAN, "8-phase schedule: the 256x256 bf16 tile");
+            constexpr int HT = 16384;                                    // bytes of a half-tile slot; slot (b, u) at b * 4 * HT + u * HT
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            // request side: instruction i of wave wv fills local rows (wv * 2 + i) * 8 + (lane >> 3) of a half-tile. Addresses are a
+            // wave-uniform base (tile origin + K offset: scalar registers, advanced on the SALU) + a 32-bit lane offset (tile-local row
+            // x row pitch + swizzled chunk), so a request is one global_load_lds with an SGPR base and costs no VALU.
+            const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.X + (long)m0 * p.ldx);
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W + (long)n0 * p.ldw);
+            unsigned xq[2][2], wq[2][2];                                  // [half][i]
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int lr = (wv * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((lr >> 1) & 7);
+                    const int xr = (lr >> 5) * 64 + hh * 32 + (lr & 31), wr_ = (lr >> 6) * 128 + hh * 64 + (lr & 63);
+                    xq[hh][i] = (unsigned)(min(xr, p.M - 1 - m0) * (int)(p.ldx * sizeof(TI)) + c * 16);
+                    wq[hh][i] = (unsigned)(min(wr_, p.N - 1 - n0) * (int)(p.ldw * sizeof(TI)) + c * 16);
+                }
+#define SA8_REQ(BASE, OFFS, SLOT, KT)                                                                             \
+    {                                                                                                             \
+        const unsigned char* b_ = (BASE) + (long)(KT) * 128;                                                      \
+        asm volatile("" : "+s"(b_));      /* keeps (uniform base) + zext(lane offset) visible to instruction selection: */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                        \
+            unsigned o_ = OFFS[i_];       /* left alone, hipcc hoists base + offset as 64-bit VGPR pairs and adds K on the VALU */ \
+            asm volatile("" : "+v"(o_));                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_ + o_), (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
+        }                                                                                                         \
+    }
+            // read side: lane offsets inside a half-tile (the XOR swizzle depends on the fragment row only)
+            int fo[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fo[kk] = frow * 128 + (((kk * 2 + fch) ^ ((frow >> 1) & 7)) << 4);
+            // ds_read offsets are 16-bit immediates: one address set per K-tile buffer (64 KiB each), slot / fragment offsets folded
+            int xl0[4], wl0[4], xl1[4], wl1[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                xl0[kk] = wm * 32 * 128 + fo[kk];              // + u * HT
+                wl0[kk] = wn * 64 * 128 + fo[kk];              // + u * HT + j * 32 * 128
+                xl1[kk] = xl0[kk] + 4 * HT;
+                wl1[kk] = wl0[kk] + 4 * HT;
+            }
+            u32x4 xa[4], xb[4], wf[2][4];
+#define SA8_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : xl1[kk_]) + ((SLOT) & 3) * HT); }
+#define SA8_RW(SLOT)                                                                                              \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                   \
+                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : wl1[kk_]) + ((SLOT) & 3) * HT + j_ * 4096); \
+    }
+#define SA8_MMA(XR, JH, I)                                                                                        \
+    {                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                       \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) Mfma<TI>::run(acc[(JH) * 2 + j_][I], wf[j_][kk_], XR[kk_]); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    }
+#define SA8_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+            // one phase: READ; REQ; counted wait | barrier | 8 MFMAs | barrier
+#define SA8_PHASE(READ, REQ, VMN, XR, JH, I)          \
+    {                                                 \
+        READ;                                         \
+        __builtin_amdgcn_sched_barrier(0);            \
+        REQ;                                          \
+        if constexpr ((VMN) >= 0) SA8_VM((VMN) < 0 ? 0 : (VMN)); \
+        __builtin_amdgcn_sched_barrier(0);            \
+        __builtin_amdgcn_s_barrier();                 \
+        __builtin_amdgcn_sched_barrier(0);            \
+        SA8_MMA(XR, JH, I);                           \
+        __builtin_amdgcn_sched_barrier(0);            \
+        __builtin_amdgcn_s_barrier();                 \
+        __builtin_amdgcn_sched_barrier(0);            \
+    }
+            // slots: buffer 0 = 0..3, buffer 1 = 4..7; u: 0 X0, 1 W0, 2 X1, 3 W1
+            SA8_REQ(xbase, xq[0], 0, 0); SA8_REQ(wbase, wq[0], 1, 0); SA8_REQ(xbase, xq[1], 2, 0); SA8_REQ(wbase, wq[1], 3, 0);
+            SA8_REQ(xbase, xq[0], 4, 1); SA8_REQ(wbase, wq[0], 5, 1);
+            SA8_VM(8);                                                   // X0(0), W0(0) of this wave have landed
+            __builtin_amdgcn_s_barrier();
+            if (wv >= 4) __builtin_amdgcn_s_barrier();                   // the second wave of every SIMD runs one barrier behind
+            __builtin_amdgcn_sched_barrier(0);
+            SA8_RX(xa, 0);
+            for (int pi = 0; pi < pairs - 1; ++pi) {
+                const int t = 2 * pi;
+                SA8_PHASE(SA8_RW(1),     SA8_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0);
+                SA8_PHASE(SA8_RX(xb, 2), SA8_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1);
+                SA8_PHASE(SA8_RW(3),     SA8_REQ(xbase, xq[0], 0, t + 2), 8, xb, 1, 1);
+                SA8_PHASE(SA8_RX(xb, 4), SA8_REQ(wbase, wq[0], 1, t + 2), 8, xa, 1, 0);
+                SA8_PHASE(SA8_RW(5),     SA8_REQ(xbase, xq[1], 2, t + 2), 8, xb, 0, 0);
+                SA8_PHASE(SA8_RX(xa, 6), SA8_REQ(wbase, wq[1], 3, t + 2), 8, xa, 0, 1);
+                SA8_PHASE(SA8_RW(7),     SA8_REQ(xbase, xq[0], 4, t + 3), 8, xa, 1, 1);
+                SA8_PHASE(SA8_RX(xa, 0), SA8_REQ(wbase, wq[0], 5, t + 3), 8, xb, 1, 0);
+            }
+            {   // last two K-tiles: nothing left to request after W1(nk - 1); the counted waits shrink with what is still in flight
+                const int t = nk - 2;
+                SA8_PHASE(SA8_RW(1),     SA8_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0);
+                SA8_PHASE(SA8_RX(xb, 2), SA8_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1);
+                SA8_PHASE(SA8_RW(3),     {},                       6, xb, 1, 1);
+                SA8_PHASE(SA8_RX(xb, 4), {},                       4, xa, 1, 0);
+                SA8_PHASE(SA8_RW(5),     {},                       2, xb, 0, 0);
+                SA8_PHASE(SA8_RX(xa, 6), {},                       0, xa, 0, 1);
+                SA8_PHASE(SA8_RW(7),     {},                      -1, xa, 1, 1);
+                SA8_PHASE({},            {},                      -1, xb, 1, 0);
+            }
+            if (wv < 4) __builtin_amdgcn_s_barrier();                    // the leading half meets the trailing half's last barrier
+#undef SA8_PHASE
+#undef SA8_VM
+#undef SA8_MMA
+#undef SA8_RW
+#undef SA8_RX
+#undef SA8_REQ
+        } else if constexpr (GLDS == 2) {
             // Two buffers, loop unrolled over both so every LDS offset is an immediate. Tile kt+1 streams into the other
             // buffer while tile kt is multiplied; the vmcnt(0) + barrier at the end of the iteration both publishes tile
             // kt+1 and retires every wave's reads of tile kt before its buffer is refilled. Big tiles run best this way:
@@ -999,7 +1131,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     GemmArgs<TI, TO> aa = a;
     if (!SPLIT && BM >= 128 && BN >= 128) {          // XCD-aware super-tiles for the large-tile configurations
         const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
-        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 ? GLDS : 2) > 80 * 1024) ? 32 : 64;
+        constexpr int GRP = ((BM + BN) * 128 * (GLDS > 2 && GLDS != 8 ? GLDS : 2) > 80 * 1024) ? 32 : 64;
         if (tm * tn >= 8 * GRP) {
             aa.swz_n = cdiv(tn, cdiv(tn, 8));                 // equal-width super-columns of <= 8 tile columns
             aa.swz_m = std::max(1, GRP / aa.swz_n);
@@ -1008,7 +1140,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     }
     constexpr size_t out_w = ((EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT) ? BN / 2 : BN;
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
-    constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 ? GLDS : 2);
+    constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 && GLDS != 8 ? GLDS : 2);
     constexpr bool argmax_direct = (EPI == EPI_ARGMAX) && ((size_t)BM * BN * 4 > 160 * 1024);     // partials straight from the accumulators
     constexpr size_t lds = (argmax_direct || stage_bytes > out_bytes) ? stage_bytes : out_bytes;   // staging buffers are reused for the output tile
     auto kern = gemm_nt_kernel<TI, TO, BM, BN, WM, WN, EPI, SPLIT, GLDS, CONV, WAUX>;
@@ -1130,7 +1262,7 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         // (r03: 256 x 128 tiles with a 3-stage ring -- 144 KB, deeper prefetch, 1.37x the L2 bytes per flop -- lost 5-15 % on every
         // encoder / prefill shape and on 8k^3 (1212 -> 1026 TF/s, profiles/r03_sweeps.txt): the big-tile loop is bound by L2 -> LDS bytes
         // per flop, not by prefetch depth.)
-        if (bigtile && a.K >= tuning().bigtile_min_k && t256 >= 256 && cost256 <= cost128) {
+        if (bigtile && a.K >= tuning().bigtile_min_k && ((t256 >= 256 && cost256 <= cost128) || tuning().bigtile_any)) {
             if constexpr (EPI != EPI_ARGMAX) {
                 const int nk = a.K / Ty<TI>::KE;
                 if (tuning().persist && nk >= 2 && nk % 2 == 0) return launch_gemm_persist<TI, TO, EPI>(a, s);
@@ -1141,6 +1273,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             // A/B: tools/microbench/bigtile_ab.py 1 2.
             if constexpr (sizeof(TI) == 2 && EPI != EPI_ARGMAX) {
                 if (bigtile == 2) return launch_gemm_cfg<TI, TO, 256, 256, 2, 2, EPI, false, 2>(a, s);
+                // bigtile = 3: the 8-phase schedule (half-tile ring, counted vmcnt, two wave groups one barrier apart); even K-tile counts
+                if (bigtile == 3 && (a.K / Ty<TI>::KE) % 2 == 0) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(a, s);
             }
             return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
         }

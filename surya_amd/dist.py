@@ -75,54 +75,113 @@ def shard_indices(n: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n, world))
 
 
-def gather_line_outputs(tokens: Sequence[Sequence[int]], scores: Sequence[Sequence[float]], bboxes: np.ndarray,
-                        local_idx: Sequence[int], n_total: int, max_tokens: int, device="cpu", group=None):
+class PackedLines(Sequence):
+    """Ragged per-line values (token ids or scores) as ONE dense array [n, T] + lengths [n]; behaves like the list of lists the
+    reference's prediction_loop returns (`lines[i]` is a Python list of line i's values) but converts a line only when somebody
+    asks for it. The gather below hands every rank ALL lines of the call: unpacking them eagerly into Python lists on every rank
+    was 10 us per line inside the timed step (22 ms at 8 x 256 lines) for a consumer that reads each line once."""
+
+    __slots__ = ("data", "lens")
+
+    def __init__(self, data: np.ndarray, lens: np.ndarray):
+        self.data, self.lens = data, np.asarray(lens, np.int64)
+
+    @classmethod
+    def from_lists(cls, rows: Sequence[Sequence], width: int, dtype) -> "PackedLines":
+        n = len(rows)
+        lens = np.fromiter((min(len(r), width) for r in rows), np.int64, n)
+        data = np.zeros((n, width), dtype)
+        if n and int(lens.sum()):
+            mask = np.arange(width)[None, :] < lens[:, None]
+            data[mask] = np.fromiter((x for r, L in zip(rows, lens) for x in r[:L]), dtype, int(lens.sum()))
+        return cls(data, lens)
+
+    def __len__(self) -> int:
+        return len(self.lens)
+
+    def row(self, i: int) -> np.ndarray:
+        """Line i as an array view (no conversion)."""
+        return self.data[i, : int(self.lens[i])]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self.data[i, : int(self.lens[i])].tolist()
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.data[i, : int(self.lens[i])].tolist()
+
+    def __eq__(self, other):
+        if isinstance(other, PackedLines):
+            other = list(other)
+        return list(self) == other
+
+    def tolists(self) -> list:
+        return list(self)
+
+
+def gather_line_outputs(tokens, scores, bboxes: np.ndarray, local_idx: Sequence[int], n_total: int, max_tokens: int,
+                        device="cpu", group=None):
     """All ranks contribute the outputs of their shard; every rank gets all n_total lines back in global order.
-    bboxes: [n_local, max_tokens, 6]. Returns (tokens list, scores list, bboxes [n_total, max_tokens, 6]).
-    ONE collective: a rank's record is int32 [per_rank][max_tokens + 1][8] -- per token (id, score bits, 6 bbox ints), and in the
-    extra last row of a line (global index + 1, length); 0 = padding line. Packing and unpacking are whole-array numpy
-    operations (the per-line Python of the first version cost ~30 us per line on EVERY rank for ALL lines: 60 ms at 8 x 256
-    lines, two thirds of a recognition step)."""
+    tokens / scores: lists of per-line lists, or PackedLines (the continuous-batching loop's own dense bookkeeping,
+    RecognitionPredictor.last_packed -- no per-token Python on the way in). bboxes: [n_local, max_tokens, 6].
+    Returns (tokens PackedLines, scores PackedLines, bboxes [n_total, max_tokens, 6]).
+    ONE collective: a rank's record is a flat int32 buffer of four planes -- meta [per_rank, 2] (global index + 1, length; 0 =
+    padding line), token ids [per_rank, T], score bits [per_rank, T], bbox ints [per_rank, T, 6]; entries past a line's length are
+    zero. Planes, not an array of per-token structs: packing and unpacking are then contiguous whole-array copies (the [.., 8]
+    struct layout of round 4 spent 5 ms of strided numpy writes at 2048 lines); nothing here is per line."""
     import torch.distributed as dist
     rank, world = world_info(group)
     per_rank = (n_total + world - 1) // world
     T = max_tokens
-    rec = np.zeros((per_rank, T + 1, 8), np.int32)
+    o_tok, o_sc, o_bb, rec_len = 2 * per_rank, (2 + T) * per_rank, (2 + 2 * T) * per_rank, (2 + 8 * T) * per_rank
+    rec = np.zeros(rec_len, np.int32)
     n_local = len(local_idx)
     if n_local:
-        lens = np.fromiter((min(len(t), T) for t in tokens), np.int64, n_local)
-        rec[:n_local, T, 0] = np.asarray(local_idx, np.int64) + 1
-        rec[:n_local, T, 1] = lens
+        pt = tokens if isinstance(tokens, PackedLines) else PackedLines.from_lists(tokens, T, np.int32)
+        ps = scores if isinstance(scores, PackedLines) else PackedLines.from_lists(scores, T, np.float32)
+        assert len(pt) == n_local and len(ps) == n_local
+        lens = np.minimum(pt.lens, T)
+        w = min(T, pt.data.shape[1], ps.data.shape[1])
+        meta = rec[:o_tok].reshape(per_rank, 2)
+        meta[:n_local, 0] = np.asarray(local_idx, np.int64) + 1
+        meta[:n_local, 1] = lens
         mask = np.arange(T)[None, :] < lens[:, None]                       # [n_local, T]
-        flat_t = np.fromiter((x for t, L in zip(tokens, lens) for x in t[:L]), np.int32, int(lens.sum()))
-        flat_s = np.fromiter((x for t, L in zip(scores, lens) for x in t[:L]), np.float32, int(lens.sum()))
-        body = rec[:n_local, :T]
-        body[..., 0][mask] = flat_t
-        body[..., 1][mask] = flat_s.view(np.int32)                         # bit-cast, lossless
-        bb = np.ascontiguousarray(bboxes[:, :T]).astype(np.int32)
-        body[..., 2:8] = np.where(mask[..., None], bb, 0)
+        tok_p = rec[o_tok:o_sc].reshape(per_rank, T)
+        sc_p = rec[o_sc:o_bb].reshape(per_rank, T).view(np.float32)         # bit-cast, lossless
+        bb_p = rec[o_bb:].reshape(per_rank, T, 6)
+        np.multiply(pt.data[:, :w], mask[:, :w], out=tok_p[:n_local, :w], casting="unsafe")
+        np.copyto(sc_p[:n_local, :w], ps.data[:, :w], casting="unsafe")
+        sc_p[:n_local][~mask] = 0
+        np.copyto(bb_p[:n_local], bboxes[:, :T], casting="unsafe")         # float box coordinates are whole numbers (bbox bins)
+        bb_p[:n_local][~mask] = 0
     if not collectives_on(group):
         allr = rec[None]
     else:
         mine = torch.from_numpy(rec).to(device)
-        out = torch.empty((world * per_rank, T + 1, 8), dtype=mine.dtype, device=mine.device)    # concatenated along dim 0
+        out = torch.empty((world * rec_len,), dtype=mine.dtype, device=mine.device)    # concatenated along dim 0
         dist.all_gather_into_tensor(out, mine, group=group)
-        allr = out.cpu().numpy()
-    allr = allr.reshape(world * per_rank, T + 1, 8)
-    gi = allr[:, T, 0].astype(np.int64) - 1
-    ln = allr[:, T, 1].astype(np.int64)
-    rows = np.nonzero(gi >= 0)[0]
+        allr = out.cpu().numpy().reshape(world, rec_len)
+    W = allr.shape[0]
+    meta = allr[:, :o_tok].reshape(W * per_rank, 2)
+    rows = np.flatnonzero(meta[:, 0] > 0)
+    g = meta[rows, 0].astype(np.int64) - 1
+    dense = len(rows) == W * per_rank                                      # no padding lines: plain permutations
+    def plane(lo, hi, shape):
+        a = allr[:, lo:hi].reshape((W * per_rank,) + shape)
+        return a if dense else a[rows]
+    out_tok = np.zeros((n_total, T), np.int32)
+    out_sc = np.zeros((n_total, T), np.float32)
     out_bb = np.zeros((n_total, T, 6), np.float32)
-    out_bb[gi[rows]] = allr[rows, :T, 2:8]
-    tok_rows = allr[:, :T, 0].tolist()                                      # one conversion for everything, then list slices
-    sc_rows = np.ascontiguousarray(allr[:, :T, 1]).view(np.float32).tolist()
-    out_tok: List[List[int]] = [[] for _ in range(n_total)]
-    out_sc: List[List[float]] = [[] for _ in range(n_total)]
-    for r in rows.tolist():
-        g, L = int(gi[r]), int(ln[r])
-        out_tok[g] = tok_rows[r][:L]
-        out_sc[g] = sc_rows[r][:L]
-    return out_tok, out_sc, out_bb
+    out_len = np.zeros(n_total, np.int64)
+    out_tok[g] = plane(o_tok, o_sc, (T,))
+    out_sc[g] = plane(o_sc, o_bb, (T,)).view(np.float32)
+    out_bb[g] = plane(o_bb, rec_len, (T, 6))
+    out_len[g] = meta[rows, 1]
+    return PackedLines(out_tok, out_len), PackedLines(out_sc, out_len), out_bb
 
 
 def gather_objects(local: list, local_idx: Sequence[int], n_total: int, group=None) -> list:

@@ -100,9 +100,12 @@ def layout_config(name: str) -> LayoutConfig:
 # gated MLP; bias-free attention projections; Swin with qkv bias, exact GELU, no absolute position embedding). A checkpoint that says
 # otherwise would load and silently compute something else -- so a key that is present must carry the assumed value.
 _ASSUMED_ENCODER = {"qkv_bias": True, "hidden_act": "gelu", "use_absolute_embeddings": False}     # (dropout / drop-path rates are inference no-ops)
-_ASSUMED_DECODER = {"hidden_activation": "gelu_pytorch_tanh", "attention_bias": False, "causal": True, "block_types": ("attention",),
-                    "aux_heads": 0, "tie_word_embeddings": False, "max_pause_tokens": 0}
-_ALL_LAYERS = ("cross_attn_layers", "encoder_cross_attn_layers", "self_attn_layers", "global_attn_layers")
+# Only switches the reference's FORWARD PASS reads are hard checks. Keys its config class merely stores (aux_heads, max_pause_tokens,
+# block_types, encoder_cross_attn_layers: no use outside surya/layout/model/config.py; tie_word_embeddings: overwritten with False by
+# encoderdecoder.py:35-36) cannot change what the reference computes, so a checkpoint that carries other values there loads and runs
+# identically in the reference -- refusing it here would not be drop-in behaviour.
+_ASSUMED_DECODER = {"hidden_activation": "gelu_pytorch_tanh", "attention_bias": False, "causal": True}
+_ALL_LAYERS = ("cross_attn_layers", "self_attn_layers", "global_attn_layers")
 
 
 def _norm(v):

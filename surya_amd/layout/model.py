@@ -339,7 +339,11 @@ class FedRuns:
         self.ring ^= 1
         return run
 
-    def step(self, nxt: np.ndarray):
+    def step(self, nxt: np.ndarray, live: np.ndarray | None = None):
+        """`live` (optional bool [rows]): the rows whose stream the host still follows. A finished row keeps being decoded (the batch
+        is dense) and the device keeps applying its token rule to it, while the host -- like the reference, which `continue`s on done
+        rows before the PageHeader / PageFooter rule (surya/layout/__init__.py:150-157) -- feeds it the raw class. The two tokens of
+        such a row may differ and nobody reads either: rows are independent sequences, so only live rows are compared."""
         nxt = np.ascontiguousarray(nxt, np.int32)
         if self.buf is None or self.cur >= self.buf[0].shape[0]:
             if self.buf is None:                                  # the first step: fed from the host
@@ -351,8 +355,13 @@ class FedRuns:
             self.pending = self._enqueue(None)                    # keep the device busy while the host works through `run`
             self.buf = self.m.wait_steps(run[1], run[0])
             self.cur = 0
-        if self.fed is not None and not np.array_equal(self.fed, nxt):
-            bad = np.argwhere(self.fed != nxt)[0]
+        diff = None
+        if self.fed is not None:
+            diff = self.fed != nxt
+            if live is not None:
+                diff = diff & np.asarray(live, bool).reshape((-1,) + (1,) * (diff.ndim - 1))
+        if diff is not None and diff.any():
+            bad = np.argwhere(diff)[0]
             raise L.SuryaAmdError(f"device-fed token differs from the host's rule at row {int(bad[0])}, component {int(bad[1])}: "
                                   f"device {self.fed[bad[0]].tolist()} vs host {nxt[bad[0]].tolist()}")
         cls, box, tok = self.buf

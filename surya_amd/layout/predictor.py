@@ -173,7 +173,9 @@ class LayoutPredictor(BasePredictor):
         from .model import FedRuns
         n = len(chunk)
         px = torch.from_numpy(np.stack(self.processor(chunk)["pixel_values"]))
-        self.model.encode(px.pin_memory().to(self.model.device, non_blocking=True).contiguous())
+        if torch.device(self.model.device).type == "cuda":          # (a host stand-in model of the CPU tests takes the tensor as it is)
+            px = px.pin_memory().to(self.model.device, non_blocking=True)
+        self.model.encode(px.contiguous())
         assert dcfg.pause_token_count == 0, "pause tokens in the decoder prompt are not built"
         sizes = np.asarray(orig_sizes, np.int64).reshape(n, 2)
         self.model.set_feedback(sizes)
@@ -185,7 +187,7 @@ class LayoutPredictor(BasePredictor):
         sp = dcfg.special_token_count
         header_footer = [k + sp for k, v in ID_TO_LABEL.items() if v in ("PageHeader", "PageFooter")]
         for position in range(LAYOUT_MAX_BOXES):
-            cls, box = runs.step(boxes)
+            cls, box = runs.step(boxes, ~all_done)           # finished pages: the device's rule keeps running, the host's does not
             class_preds = cls.argmax(-1)
             box_preds = box * dcfg.bbox_size
             if mdtype == "bfloat16":

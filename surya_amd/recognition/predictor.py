@@ -642,6 +642,10 @@ class RecognitionPredictor(BasePredictor):
                 if inflight:
                     absorb(inflight)
                 inflight = nxt
+        # the loop's own dense bookkeeping (ids [n, cap], scores [n, cap], lengths): what the sharded loop packs for its all_gather
+        # without walking the per-line lists again
+        from ..dist import PackedLines
+        self.last_packed = (PackedLines(tok_mat, line_len), PackedLines(sc_mat, line_len))
         return predicted_tokens, torch.from_numpy(batch_bboxes), scores
 
     def prediction_loop(self, flat: dict, recognition_batch_size: int | None = None, math_mode: bool = True) -> tuple:
@@ -676,6 +680,9 @@ class RecognitionPredictor(BasePredictor):
         max_tokens = max(settings.RECOGNITION_MAX_TOKENS or self.tasks[t]["max_tokens"] for t in flat["task_names"])
         if mine:
             toks, boxes, scores = self.prediction_loop(local, recognition_batch_size, math_mode)
+            packed = getattr(self, "last_packed", None)
+            if packed is not None and len(packed[0]) == len(toks):      # generate()'s dense arrays: no per-token Python in the pack
+                toks, scores = packed
             boxes = boxes.numpy()
             if boxes.shape[1] < max_tokens:
                 boxes = np.pad(boxes, ((0, 0), (0, max_tokens - boxes.shape[1]), (0, 0)))

@@ -213,6 +213,11 @@ def test_config_json_architecture_switches_are_checked_not_dropped():
         bad[where][key] = value
         with pytest.raises(ValueError, match=key):
             layout_config_from_reference_json(bad)
+    # keys the reference's config class stores but its forward pass never reads: a checkpoint carrying other values there
+    # runs identically in the reference, so it must load here too
+    stored_only = {"encoder": dict(ok["encoder"]), "decoder": {**ok["decoder"], "aux_heads": 2, "max_pause_tokens": 3, "tie_word_embeddings": True,
+                                                               "block_types": ["attention", "recurrent"], "encoder_cross_attn_layers": [0]}}
+    assert dataclasses.replace(layout_config_from_reference_json(stored_only), name=cfg.name) == cfg
     no_len = {"encoder": {k: v for k, v in enc.items() if k != "encoder_length"}, "decoder": dec}
     with pytest.raises(ValueError, match="encoder_length"):
         layout_config_from_reference_json(no_len)

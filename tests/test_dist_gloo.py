@@ -82,6 +82,63 @@ def test_two_ranks_equal_one_rank():
         assert w[0] == [[1.0] * 3] * 5 and w[1] == list(range(7)) and w[2] == [9.0, 9.0]     # rank 0's weights everywhere
 
 
+def _run_world(world, max_tokens=12):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, max_tokens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("world", [5, 8])
+def test_many_ranks_equal_one_rank(world):
+    """World sizes the driver's node will run (8) and one that divides nothing (5): per_rank rounding with padding lines on the last
+    ranks (NS = 7, 16, 1 lines over 5 / 8 ranks -> ranks with 0 lines), the fingerprint gather with > 2 entries, the bucketed
+    broadcast with 4 / 7 receivers, the manifest broadcast, the object gather."""
+    max_tokens = 12
+    results = _run_world(world, max_tokens)
+    assert sorted(r[0] for r in results) == list(range(world))
+    for rank, out, w in results:
+        for n, (tok, sc, bb) in zip(NS, out):
+            ref = [_fake_line(i, max_tokens) for i in range(n)]
+            assert tok == [r[0] for r in ref]
+            assert sc == [r[1] for r in ref]
+            assert np.array_equal(bb, np.stack([r[2] for r in ref]))
+        assert w[0] == [[1.0] * 3] * 5 and w[1] == list(range(7)) and w[2] == [9.0, 9.0]
+
+
+def test_packed_lines_behave_like_lists_and_gather_cost_is_bounded():
+    """The gather's result is a PackedLines: list-of-lists semantics (index, slice, iterate, ==) without eager conversion; packing
+    from the loop's dense arrays and unpacking 2048 lines must stay whole-array work (the per-line unpack cost 22 ms)."""
+    import time
+    rng = np.random.default_rng(3)
+    n, T = 2048, 48
+    lens = rng.integers(0, T + 1, n)
+    toks = [rng.integers(0, 70000, L).tolist() for L in lens]
+    scs = [rng.random(L).astype(np.float32).tolist() for L in lens]
+    bb = np.zeros((n, T, 6), np.float32)
+    for i, L in enumerate(lens):
+        bb[i, :L] = rng.integers(0, 1025, (L, 6))
+    pt, ps = sd.PackedLines.from_lists(toks, T + 1, np.int64), sd.PackedLines.from_lists(scs, T + 1, np.float32)   # the loop's shapes
+    assert pt == toks and ps == scs and pt[3] == toks[3] and pt[-1] == toks[-1] and pt[5:9] == toks[5:9] and len(pt) == n
+    assert [len(t) for t in pt] == lens.tolist() and np.array_equal(pt.row(7), np.asarray(toks[7]))
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        a, b, c = sd.gather_line_outputs(pt, ps, bb, list(range(n)), n, T)
+        best = min(best, time.perf_counter() - t0)
+    assert a == toks and b == scs and np.array_equal(c, bb)
+    assert best < 0.02, f"pack + unpack of 2048 lines took {best * 1e3:.1f} ms"      # ~3 ms here; the per-line version took 25-30
+
+
 def test_shard_is_a_partition():
     for n in (0, 1, 5, 256):
         for world in (1, 2, 4, 8):

@@ -18,7 +18,7 @@ else:
     variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 shapes = [(46460, 6912, 1280, 3, "enc gate|up"), (46460, 3840, 1280, 0, "enc qkv"), (46460, 1280, 1280, 1, "enc proj"),
           (46460, 1280, 3456, 1, "enc down"), (15360, 10240, 1280, 3, "dec prefill gate|up"), (15360, 1280, 5120, 1, "dec prefill down"),
-          (15360, 1792, 1280, 0, "dec prefill qkv"), (8192, 8192, 8192, 0, "square 8k")]
+          (15360, 1792, 1280, 0, "dec prefill qkv"), (8192, 8192, 8192, 0, "square 8k"), (4096, 4096, 4096, 0, "square 4k")]
 for M, N, K, epi, name in shapes:
     torch.manual_seed(0)
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
