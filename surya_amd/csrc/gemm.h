@@ -47,6 +47,7 @@ struct GemmArgs {
     int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
     int swz_m = 0, swz_n = 0;    // > 0: XCD-aware rasterisation in super-tiles of swz_m x swz_n output tiles (set by the launcher)
+    int stagger = 0;             // experiment (8-phase tile): workgroups of the first round start (blockIdx / 8 % 4) * stagger shader cycles late
     // EPI_ARGMAX (TO = float): C is not written; instead one float4 {max, bits of the first argmax column, sum exp(v - max), 0}
     // per (row, tile column) goes to amax[m * cdiv(N, bn_used) + tile_n]; the launcher reports the tile width it chose.
     float4* amax = nullptr;
@@ -343,6 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             //   WAR  a slot is re-requested three phases after its last read (>= 5 barriers; the reads retire at the first MFMA).
             // K order, MFMA and accumulator assignment are the 2-stage loop's: results are bit-identical (tools/microbench/bigtile_ab.py 1 3).
             static_assert(BM == 256 && BN == 256 && WM == 4 && WN == 2 && !SPLIT && !CONV && sizeof(TI) == 2 && !LEAN, "8-phase schedule: the 256x256 bf16 tile");
+            if (p.stagger > 0 && blockIdx.x < 256) {
+                const long wait_ = (long)((blockIdx.x >> 3) & 3) * p.stagger, t0_ = (long)__builtin_readcyclecounter();
+                while ((long)__builtin_readcyclecounter() - t0_ < wait_) __builtin_amdgcn_s_sleep(8);
+            }
             constexpr int HT = 16384;                                    // bytes of a half-tile slot; slot (b, u) at b * 4 * HT + u * HT
             const int wv = __builtin_amdgcn_readfirstlane(wave);
             // request side: instruction i of wave wv fills local rows (wv * 2 + i) * 8 + (lane >> 3) of a half-tile. Addresses are a
@@ -595,6 +600,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
     // clamped addresses, one wait per batch. Round 2 loaded them where they were used, under `if (p.bias)` / `if (n < rope_cols)` /
     // loop-`continue` conditions: hipcc then branches around every load and waits vmcnt(0) behind each -- 32 dependent L2 round
     // trips for the bias of a 256x256 tile and 16 for its residual (r03 ISA), ~15-20 us of a ~50 us tile at K = 1280.
+#ifndef SA_ABL
+#define SA_ABL 0      // ablation builds of the 8-phase tile (tools/microbench): 1 = epilogue without its global stores, 2 = no epilogue at all
+#endif
+    if constexpr (SA_ABL == 2 && GLDS == 8) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(acc[j][i]));
+        return;
+    }
     __syncthreads();
     // Greedy-head partials straight from the accumulators, for tiles whose fp32 image does not fit LDS (the 256x320 lm_head tile):
     // a lane holds, for each of its FM rows, FN x 16 of the wave's columns in ascending order (the other FN x 16 sit in lane ^ 32),
@@ -833,6 +848,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         const int m = m0 + row, n = n0_out + c * EPC;
         if (id >= BM * CPR || m >= p.M || n >= n_out) continue;              // stores only: nothing below waits on memory
         u32x4 raw = *reinterpret_cast<const u32x4*>(smem + row * ROWB + ((c ^ (row & XM)) << 4));
+        if constexpr (SA_ABL == 1 && GLDS == 8) { asm volatile("" ::"v"(raw)); continue; }
         if constexpr (SPLIT) {
             *reinterpret_cast<u32x4*>(p.part + ((long)ks * p.M + m) * p.N + n) = raw;
         } else {
@@ -1274,7 +1290,13 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if constexpr (sizeof(TI) == 2 && EPI != EPI_ARGMAX) {
                 if (bigtile == 2) return launch_gemm_cfg<TI, TO, 256, 256, 2, 2, EPI, false, 2>(a, s);
                 // bigtile = 3: the 8-phase schedule (half-tile ring, counted vmcnt, two wave groups one barrier apart); even K-tile counts
-                if (bigtile == 3 && (a.K / Ty<TI>::KE) % 2 == 0) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(a, s);
+                if (bigtile == 3 && (a.K / Ty<TI>::KE) % 2 == 0) {
+                    GemmArgs<TI, TO> b = a;
+                    b.stagger = tuning().p8_stagger;
+                    const int rc = launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(b, s);
+                    a.bn_used = b.bn_used;
+                    return rc;
+                }
             }
             return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
         }

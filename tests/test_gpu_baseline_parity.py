@@ -123,8 +123,8 @@ def _teacher_forced_bf16(cfg, m, g, tiles, grids, seqs, steps, dev_per_step):
     """Teacher-forced bf16 logits within 2 x (the reference's own bf16 deviation) + 1e-2 x max|logit|. VERDICT r03: on the default
     synthetic weights that deviation is 12-21 % of max|logit| -- a tolerance of ~35 % accepts almost anything. The fixture, not the
     kernel, is then unfit for a parity claim: where the recorded deviation exceeds DEV_CAP x max|logit| the check degrades to an
-    ENVELOPE (stated as such in the printed result: finite logits, inside the reference's own rounding envelope) and the test is
-    reported as SKIPPED with that reason; the bf16 parity claim lives in tests/test_gpu_bf16_parity.py (conditioned weights, same shapes,
+    ENVELOPE (stated as such in the printed result and in the test's name: finite logits, inside the reference's own rounding
+    envelope); the bf16 parity claim lives in tests/test_gpu_bf16_parity.py (conditioned weights, same shapes,
     deviation <= 1.8 %, enforced there with the same cap)."""
     unfit = float(max(float(dev_per_step[s_]) / float(g["logits_absmax"][s_].max()) for s_ in range(steps)))
     n = len(seqs)
@@ -153,8 +153,10 @@ def _teacher_forced_bf16(cfg, m, g, tiles, grids, seqs, steps, dev_per_step):
             m.decode(1)
     assert mism == 0, (mism, checked)
     if unfit > DEV_CAP:
-        pytest.skip(f"envelope only, no parity claim: the reference's own bf16 run deviates {unfit:.1%} of max|logit| on this weight set "
-                    f"(cap {DEV_CAP:.0%}); HIP bf16 worst {worst:.4f} stayed inside 2 x that + 1 %. Parity of the bf16 path: tests/test_gpu_bf16_parity.py")
+        # the assertions above RAN and held; what they prove on this weight set is an envelope, not parity -- said in the test's name
+        # (`..._envelope`) and in its printed line, not by a skip (a skip after the assertions reads as "did not run")
+        print(f"ENVELOPE ONLY, no parity claim: the reference's own bf16 run deviates {unfit:.1%} of max|logit| on this weight set "
+              f"(cap {DEV_CAP:.0%}); HIP bf16 worst {worst:.4f} stayed inside 2 x that + 1 %. Parity of the bf16 path: tests/test_gpu_bf16_parity.py")
     return worst, worst_ref, checked
 
 
@@ -168,7 +170,7 @@ def test_rec_full_bench8_fp32_bit_exact(full_fp32, bench_inputs):
           f"{worst:.2e} x max, {flips} bbox truncation flips, {alive} lines alive at the end")
 
 
-def test_rec_full_bench8_bf16_teacher_forced(full_bf16, bench_inputs):
+def test_rec_full_bench8_bf16_teacher_forced_envelope(full_bf16, bench_inputs):
     g = torch.load(os.path.join(GOLD, "rec_full_bench8.pt"))
     cfg, m = full_bf16
     tiles, grids, seqs = _subset(bench_inputs, g["pick"])
@@ -188,7 +190,7 @@ def test_rec_full_bench256_fp32_bit_exact(full_fp32, bench_inputs):
           f"{worst:.2e} x max, {flips} bbox truncation flips")
 
 
-def test_rec_full_bench256_bf16_teacher_forced(full_bf16, bench_inputs):
+def test_rec_full_bench256_bf16_teacher_forced_envelope(full_bf16, bench_inputs):
     g = torch.load(os.path.join(GOLD, "rec_full_bench256.pt"))
     g8 = torch.load(os.path.join(GOLD, "rec_full_bench8.pt"))
     cfg, m = full_bf16

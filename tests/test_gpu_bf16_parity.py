@@ -103,10 +103,10 @@ def test_cond8_bf16_teacher_forced_logits_and_argmax(cond_bf16, bench_inputs):
     assert mism == 0, (mism, checked)
 
 
-def test_cond8_bf16_free_running_tokens(cond_bf16, bench_inputs):
-    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
-    cfg, m = cond_bf16
-    tiles, grids, seqs = _subset(bench_inputs, g["pick"])
+def _free_running(m, g, tiles, grids, seqs):
+    """bf16 greedy decoding, free-running, against the reference's fp32 stream of the fixture: a line may leave that stream only at a
+    near-tie (top-2 margin of the reference <= 2 x tol at the first difference, and onto the reference's runner-up). Returns
+    (lines identical, first difference per line, tokens [steps, n])."""
     n, steps = len(seqs), g["tokens"].shape[0]
     slots = list(range(n))
     tol, _ = _tols(g, g["bf16_dev"].amax(-1))
@@ -138,10 +138,39 @@ def test_cond8_bf16_free_running_tokens(cond_bf16, bench_inputs):
         # the prefix is identical, so the fixture's logits of step s are the reference's for exactly this context
         assert margin <= 2 * float(tol[s]), f"line {i} leaves the reference stream at step {s} where its top-2 margin is {margin:.3f} > 2 tol {2 * float(tol[s]):.3f}"
         assert int(got[s, i]) == int(idx[1]), f"line {i} step {s}: token {got[s, i]} is not the reference's runner-up {int(idx[1])}"
+    return identical, first, got
+
+
+def test_cond8_bf16_free_running_tokens(cond_bf16, bench_inputs):
+    g = torch.load(os.path.join(GOLD, "rec_full_cond8.pt"))
+    cfg, m = cond_bf16
+    tiles, grids, seqs = _subset(bench_inputs, g["pick"])
+    n, steps = len(seqs), g["tokens"].shape[0]
+    identical, first, _ = _free_running(m, g, tiles, grids, seqs)
     ref_same = int((g["bf16_free_tokens"] == g["tokens"]).all(0).sum())
     print(f"REC-FULL conditioned bf16 free-running: {identical}/{n} lines token-identical to the reference's fp32 stream over {steps} tokens "
           f"(first differences at steps {first}; the reference's own bf16 run: {ref_same}/{n}); every difference is a near-tie")
     assert identical >= n // 2, (identical, first)
+
+
+def test_cond256_bf16_free_running_tokens(cond_bf16, bench_inputs):
+    """The headline configuration over its full extent (256 lines x 48 tokens, VERDICT r04 'missing' #3): the bf16 path, free-running,
+    against the reference's fp32 stream -- and, line by line, against the reference's OWN bf16 stream, which is the yardstick for how
+    far bf16 token agreement can go at all (the reference rounds lm_logits to bf16 before its argmax; the HIP path takes the argmax
+    from the fp32 accumulators, so it is expected to follow the fp32 stream at least as long)."""
+    g = torch.load(os.path.join(GOLD, "rec_full_cond256.pt"))
+    cfg, m = cond_bf16
+    tiles, grids, seqs = bench_inputs
+    n, steps = len(seqs), g["tokens"].shape[0]
+    assert steps >= 48 and n == 256
+    identical, first, got = _free_running(m, g, tiles, grids, seqs)
+    ref_bf16 = g["bf16_free_tokens"].numpy()
+    ref_same = int((ref_bf16 == g["tokens"].numpy()).all(0).sum())
+    vs_ref_bf16 = int((got == ref_bf16).all(0).sum())
+    print(f"REC-FULL conditioned bf16 free-running, 256 lines x {steps} tokens: {identical}/256 lines identical to the reference's fp32 stream "
+          f"({int((got == g['tokens'].numpy()).sum())}/{got.size} tokens; the reference's own bf16 run: {ref_same}/256), {vs_ref_bf16}/256 identical to the "
+          f"reference's bf16 stream; every first difference is a near-tie onto the reference's runner-up")
+    assert identical >= int(0.9 * ref_same), (identical, ref_same)
 
 
 def test_cond8_fp32_bit_exact(cond_fp32, bench_inputs):
@@ -170,4 +199,5 @@ def test_cond256_fp32_bit_exact(cond_fp32, bench_inputs):
     cfg, m = cond_fp32
     tiles, grids, seqs = bench_inputs
     worst, flips, alive = _free_run_fp32(cfg, m, g, tiles, grids, seqs, g["tokens"].shape[0], 8)
-    print(f"REC-FULL conditioned fp32 mode, 256 lines: tokens bit-exact, worst logit err {worst:.2e} x max, {flips} bbox flips")
+    assert g["tokens"].shape[0] >= 48                          # the full extent of the headline configuration (round 5 fixture)
+    print(f"REC-FULL conditioned fp32 mode, 256 lines x {g['tokens'].shape[0]} tokens: tokens bit-exact, worst logit err {worst:.2e} x max, {flips} bbox flips")
