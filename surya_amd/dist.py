@@ -124,16 +124,18 @@ class PackedLines(Sequence):
 
 
 def gather_line_outputs(tokens, scores, bboxes: np.ndarray, local_idx: Sequence[int], n_total: int, max_tokens: int,
-                        device="cpu", group=None):
+                        device="cpu", group=None, stats: dict | None = None):
     """All ranks contribute the outputs of their shard; every rank gets all n_total lines back in global order.
     tokens / scores: lists of per-line lists, or PackedLines (the continuous-batching loop's own dense bookkeeping,
     RecognitionPredictor.last_packed -- no per-token Python on the way in). bboxes: [n_local, max_tokens, 6].
-    Returns (tokens PackedLines, scores PackedLines, bboxes [n_total, max_tokens, 6]).
+    Returns (tokens PackedLines, scores PackedLines, bboxes [n_total, max_tokens, 6]). `stats` (optional dict) accumulates host seconds.
     ONE collective: a rank's record is a flat int32 buffer of four planes -- meta [per_rank, 2] (global index + 1, length; 0 =
     padding line), token ids [per_rank, T], score bits [per_rank, T], bbox ints [per_rank, T, 6]; entries past a line's length are
     zero. Planes, not an array of per-token structs: packing and unpacking are then contiguous whole-array copies (the [.., 8]
     struct layout of round 4 spent 5 ms of strided numpy writes at 2048 lines); nothing here is per line."""
+    import time
     import torch.distributed as dist
+    t_start = time.perf_counter()
     rank, world = world_info(group)
     per_rank = (n_total + world - 1) // world
     T = max_tokens
@@ -158,6 +160,7 @@ def gather_line_outputs(tokens, scores, bboxes: np.ndarray, local_idx: Sequence[
         sc_p[:n_local][~mask] = 0
         np.copyto(bb_p[:n_local], bboxes[:, :T], casting="unsafe")         # float box coordinates are whole numbers (bbox bins)
         bb_p[:n_local][~mask] = 0
+    t_packed = time.perf_counter()
     if not collectives_on(group):
         allr = rec[None]
     else:
@@ -165,6 +168,7 @@ def gather_line_outputs(tokens, scores, bboxes: np.ndarray, local_idx: Sequence[
         out = torch.empty((world * rec_len,), dtype=mine.dtype, device=mine.device)    # concatenated along dim 0
         dist.all_gather_into_tensor(out, mine, group=group)
         allr = out.cpu().numpy().reshape(world, rec_len)
+    t_gathered = time.perf_counter()
     W = allr.shape[0]
     meta = allr[:, :o_tok].reshape(W * per_rank, 2)
     rows = np.flatnonzero(meta[:, 0] > 0)
@@ -181,6 +185,9 @@ def gather_line_outputs(tokens, scores, bboxes: np.ndarray, local_idx: Sequence[
     out_sc[g] = plane(o_sc, o_bb, (T,)).view(np.float32)
     out_bb[g] = plane(o_bb, rec_len, (T, 6))
     out_len[g] = meta[rows, 1]
+    if stats is not None:                  # host seconds: pack + unpack (whole-array numpy) apart from the collective (H2D, all_gather, D2H)
+        stats["pack_unpack_s"] = stats.get("pack_unpack_s", 0.0) + (t_packed - t_start) + (time.perf_counter() - t_gathered)
+        stats["collective_s"] = stats.get("collective_s", 0.0) + (t_gathered - t_packed)
     return PackedLines(out_tok, out_len), PackedLines(out_sc, out_len), out_bb
 
 

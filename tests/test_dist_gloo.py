@@ -315,3 +315,81 @@ def test_forced_one_rank_group_takes_the_collective_branch():
     assert q.get(timeout=120) == "ok"
     p.join(timeout=60)
     assert p.exitcode == 0
+
+
+# ------------------------------------------------------------------ whole pages per rank (RecognitionPredictor.shard_pages)
+def _page_worker(rank, world, port, q):
+    """_call_page_sharded on `world` ranks: the orchestration (fingerprint, page deal, the rank's own single-rank call, the gather) with
+    the single-rank call replaced by a stand-in that derives a page's OCRResult from its pixels."""
+    import torch.distributed as dist
+    from PIL import Image
+    from surya_amd.recognition.predictor import RecognitionPredictor
+    from surya_amd.recognition.schema import OCRResult, TextLine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Model:
+        device = torch.device("cpu")
+
+    class Det:
+        shard_pages = True                   # must be switched off inside the rank's own call and restored afterwards
+
+    calls = []
+    pred = object.__new__(RecognitionPredictor)
+    pred.model, pred.process_group = Model(), None
+    pred.shard_pages, pred.shard_lines = True, False
+
+    def fake_call(images, task_names, det_predictor, dbs, rbs, highres, bboxes, polygons, input_text, sort_lines, math_mode, return_words, drop):
+        assert not pred.shard_pages and not pred.shard_lines and not det_predictor.shard_pages      # a plain single-rank call
+        calls.append(len(images))
+        out = []
+        for im in images:
+            v = int(np.asarray(im)[0, 0, 0])
+            lines = [TextLine(text=f"page {v} line {k}", polygon=[[0, 0], [9, 0], [9, 9], [0, 9]], chars=[], confidence=0.5, words=[])
+                     for k in range(v % 4)]
+            out.append(OCRResult(text_lines=lines, image_bbox=[0, 0, im.size[0], im.size[1]]))
+        return out
+
+    real_call = RecognitionPredictor._call
+    pred._call = lambda *a: real_call(pred, *a) if pred.shard_pages else fake_call(*a)     # the outer call is the product's, the rank's own call the stand-in
+    pred.tasks = {"ocr_with_boxes": {}}
+    pages = [Image.fromarray(np.full((20 + i, 30, 3), 10 + i, np.uint8)) for i in range(7)]
+    det = Det()
+    full = pred(pages, det_predictor=det)
+    assert det.shard_pages and pred.shard_pages
+    pred.gather_page_results = False
+    part = pred(pages, det_predictor=det)
+    summary = list(pred.last_page_summary)
+    try:
+        pred(pages[:3] if rank == 0 else pages[:4], det_predictor=det)
+        err = "no error"
+    except Exception as e:
+        err = "raised " + type(e).__name__
+    q.put((rank, [r.model_dump() for r in full], [None if r is None else r.model_dump() for r in part], summary, calls, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_page_sharded_call(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_page_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect_lines = [(10 + i) % 4 for i in range(7)]
+    for rank, full, part, summary, calls, err in got:
+        assert [len(r["text_lines"]) for r in full] == expect_lines            # every rank holds every page, in page order
+        assert full == got[0][1]
+        mine = list(range(rank, 7, world))
+        assert [i for i, r in enumerate(part) if r is not None] == mine         # partitioned: own pages only ...
+        assert all(part[i] == full[i] for i in mine)
+        assert [s_[0] for s_ in summary] == expect_lines                        # ... and a record of every page on every rank
+        assert calls == [len(mine), len(mine)] and err.startswith("raised")
