@@ -301,6 +301,7 @@ static inline int launch_conv_on_gemm(const ConvArgs<T>& a, hipStream_t s) {
     g.conv_in = a.in; g.conv_zero = a.zero;
     g.cH = a.H; g.cW = a.W; g.cCin = a.Cin; g.cHo = a.Ho; g.cWo = a.Wo; g.cKW = a.KW; g.cStride = a.stride; g.cPad = a.pad;
     g.cTaps = a.KH * a.KW;
+    g.conv_lean = tuning().conv_lean;
     if (tuning().bigtile && a.Kpad >= tuning().bigtile_min_k && a.Cout >= 256 && cdivl(M, 256) * cdiv(a.Cout, 256) >= 256)
         return launch_gemm_cfg<T, T, 256, 256, 4, 2, EPI, false, 2, true>(g, s);
     if (a.Cout >= 128) return launch_gemm_cfg<T, T, 128, 128, 2, 2, EPI, false, 2, true>(g, s);

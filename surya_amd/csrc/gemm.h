@@ -47,7 +47,6 @@ struct GemmArgs {
     int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
     int swz_m = 0, swz_n = 0;    // > 0: XCD-aware rasterisation in super-tiles of swz_m x swz_n output tiles (set by the launcher)
-    int stagger = 0;             // experiment (8-phase tile): workgroups of the first round start (blockIdx / 8 % 4) * stagger shader cycles late
     // EPI_ARGMAX (TO = float): C is not written; instead one float4 {max, bits of the first argmax column, sum exp(v - max), 0}
     // per (row, tile column) goes to amax[m * cdiv(N, bn_used) + tile_n]; the launcher reports the tile width it chose.
     float4* amax = nullptr;
@@ -66,6 +65,7 @@ struct GemmArgs {
     const TI* conv_in = nullptr;
     const TI* conv_zero = nullptr;
     int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKW = 0, cStride = 0, cPad = 0, cTaps = 0;
+    int conv_lean = 1;           // 1: per-(row, tap) gather state precomputed once per workgroup when K-tiles align with taps (0 = round-4 gather, for A/B)
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -263,6 +263,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         const unsigned char* wg[WI];
         [[maybe_unused]] long cbase[XI];                     // CONV: element offset of image b of the lane's row
         [[maybe_unused]] int ciy[XI], cix[XI], cch[XI];      // CONV: top-left input coordinates of the row's window, the lane's K offset
+        // CONV, K-tiles aligned with filter taps (round 5): everything about a (row, tap) pair that does not depend on the K-tile is
+        // computed ONCE per workgroup -- the byte address of the window's top-left pixel (+ the lane's channel chunk) and one validity
+        // bit per tap -- so a request costs a bit test, one 64-bit add and the select against the zero page (~5 VALU) instead of the
+        // window arithmetic, five compares and a 64-bit multiply-add per request (~20: r04 counters, VALU issue 47 % beside MFMA 26 %).
+        // (they take the place of cbase / ciy in that case: both sets live side by side cost four spills)
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int row = (wave * XI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
@@ -279,7 +284,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             }
         }
         // K-tiles aligned with filter taps (Cin a multiple of the K-tile): the tap of a K-tile is a scalar
-        [[maybe_unused]] const bool conv_uniform = CONV && (p.cCin % KE == 0);
+        [[maybe_unused]] const bool conv_uniform = CONV && (p.cCin % KE == 0) && p.cTaps <= 32 && p.conv_lean;
+        if constexpr (CONV) {
+            if (conv_uniform) {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    unsigned m_ = 0;
+                    for (int t_ = 0; t_ < p.cTaps; ++t_) {
+                        const int iy_ = ciy[i] + t_ / p.cKW, ix_ = cix[i] + t_ % p.cKW;
+                        m_ |= (unsigned)((iy_ >= 0) & (iy_ < p.cH) & (ix_ >= 0) & (ix_ < p.cW)) << t_;
+                    }
+                    cbase[i] = (cbase[i] + ((long)ciy[i] * p.cW + cix[i]) * p.cCin + cch[i]) * (long)sizeof(TI);   // now: BYTE offset of the window's corner + chunk
+                    ciy[i] = (int)m_;                                                                               // now: validity bit per tap
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
@@ -303,6 +322,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             const int kb_ = (KT) * KE;                                                                                  \
             int tap_u_ = 0, ci_u_ = 0;                                                                                  \
             if (conv_uniform) { tap_u_ = kb_ / p.cCin; ci_u_ = kb_ - tap_u_ * p.cCin; }                                 \
+            if (conv_uniform) {                                                                                         \
+                const int ky_ = tap_u_ / p.cKW, kx_ = tap_u_ - ky_ * p.cKW;                                             \
+                const long toff_ = (((long)ky_ * p.cW + kx_) * p.cCin + ci_u_) * (long)sizeof(TI);   /* scalar */       \
+                const unsigned bit_ = tap_u_ < 32 ? 1u << tap_u_ : 0u;                                                  \
+                _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                        \
+                    const unsigned char* src_ = ((unsigned)ciy[i] & bit_) ? reinterpret_cast<const unsigned char*>(p.conv_in) + cbase[i] + toff_ \
+                                                                          : reinterpret_cast<const unsigned char*>(p.conv_zero); \
+                    __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0); \
+                }                                                                                                       \
+            } else                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                            \
                 int tap_, ci_;                                                                                          \
                 if (conv_uniform) { tap_ = tap_u_; ci_ = ci_u_ + cch[i]; }                                              \
@@ -344,10 +373,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             //   WAR  a slot is re-requested three phases after its last read (>= 5 barriers; the reads retire at the first MFMA).
             // K order, MFMA and accumulator assignment are the 2-stage loop's: results are bit-identical (tools/microbench/bigtile_ab.py 1 3).
             static_assert(BM == 256 && BN == 256 && WM == 4 && WN == 2 && !SPLIT && !CONV && sizeof(TI) == 2 && !LEAN, "8-phase schedule: the 256x256 bf16 tile");
-            if (p.stagger > 0 && blockIdx.x < 256) {
-                const long wait_ = (long)((blockIdx.x >> 3) & 3) * p.stagger, t0_ = (long)__builtin_readcyclecounter();
-                while ((long)__builtin_readcyclecounter() - t0_ < wait_) __builtin_amdgcn_s_sleep(8);
-            }
             constexpr int HT = 16384;                                    // bytes of a half-tile slot; slot (b, u) at b * 4 * HT + u * HT
             const int wv = __builtin_amdgcn_readfirstlane(wave);
             // request side: instruction i of wave wv fills local rows (wv * 2 + i) * 8 + (lane >> 3) of a half-tile. Addresses are a
@@ -868,37 +893,38 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Persistent 256x256 tile loop (round 4). The one-tile-per-workgroup kernel above spends 7-15 us of a 42-50 us K = 1280 tile
-// outside its main loop: the first K-tile's round trip (every CU starts together and asks for 64 KB at once) and an epilogue that
-// needs the staging LDS back, so nothing of the next tile can be in flight while it runs. Here one workgroup per CU walks the
-// XCD-swizzled tile order (virtual block id = blockIdx.x + round * gridDim.x through the same super-tile map, so an XCD still works
-// on a compact patch of the output) and keeps the operand pipeline alive across tiles:
-//   * the next tile's K-tile 0 is issued into buffer 0 in place of "K-tile nk" during the current tile's last pair;
-//   * the epilogue stages the output through buffer 1 only, in two passes of 128 rows (64 KB), so buffer 0 keeps receiving;
-//   * as soon as the second pass has read its rows back, the next tile's K-tile 1 goes into buffer 1 (its global stores drain behind
-//     the first MFMAs of the next tile).
-// K order, MFMA order and every epilogue formula are the one-tile kernel's: results are bit-identical (tests/test_gpu_ops.py).
-// Requires an even K-tile count (buffer roles stay fixed) and a 2-byte output type (a 128-row pass must fit 64 KB).
+// Persistent 8-phase tile loop (round 5; replaces round 4's persistent 2-stage loop, which was bit-identical and not faster).
+// A 256x256 tile of K = 1280 spends ~28 us in the 8-phase K loop above and ~9 us outside it (tools/microbench/p8_abl.py,
+// profiles/r05_c_*): workgroup launch, the first half-tiles' round trip, an epilogue that needs the operand LDS back (two
+// __syncthreads, nothing of the next tile in flight) and the drain of its stores before the CU takes the next workgroup. Here ONE
+// workgroup per CU walks the XCD-swizzled tile order and never leaves the K-loop's schedule:
+//   * the half-tile ring runs on ACROSS tiles: the last six phases of a tile request the first six half-tiles of the next tile
+//     (same slots, same distances, same counted waits), the last phase reads the next tile's first X fragments;
+//   * the epilogue is wave-private: each wave stages its 64 x 128 results block by block (32 rows x 64 columns = 4 KiB) through its
+//     own 4 KiB of the 32 KiB of LDS the ring leaves free, so it needs no workgroup barrier and no operand slot, and the two wave
+//     groups keep their one-barrier stagger through it;
+//   * vmcnt counts stores as well as loads: every load in flight is retired (one vmcnt(0)) before a wave's first store, the first four
+//     phases of the next tile run without a counted wait (everything they need was requested before the stores and has been retired),
+//     and the counted waits resume at phase 4 -- about 1 us after the last store was issued;
+//   * the accumulators restart from the MFMA's zero C operand in the first K-tile (no 128-register clear);
+//   * the bias slice of a wave (128 columns) rides in ONE register per lane, fetched at the top of the tile, and reaches the lanes that
+//     need it through ds_bpermute (no LDS bytes, no load behind the request stream at epilogue time).
+// K order, MFMA, accumulator assignment and every epilogue formula are the one-tile kernel's: bit-identical (tests/test_gpu_round4.py).
+// Requires an even K-tile count >= 4 and a 2-byte output type.
 template <typename TI, typename TO, int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmArgs<TI, TO> p) {
-    constexpr int BM = 256, BN = 256, WM = 4, WN = 2, NT = 512, GRP = 32;
-    constexpr int KE = Ty<TI>::KE;
-    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
-    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
-    constexpr bool LEAN = false;
-    static_assert(sizeof(TO) == 2 && EPI != EPI_ARGMAX && FM == 2 && FN == 4, "persistent tile loop: 2-byte outputs, 256x256 tiles");
+__global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
+    constexpr int BM = 256, BN = 256, GRP = 32, KE = Ty<TI>::KE, HT = 16384;
+    static_assert(sizeof(TI) == 2 && sizeof(TO) == 2 && EPI != EPI_ARGMAX, "persistent 8-phase loop: bf16 operands, 2-byte outputs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, total = tiles_m * tiles_n;
-    const int padded = ((total + 8 * GRP - 1) / (8 * GRP)) * (8 * GRP);
-    const int nk = p.K / KE, last = nk - 1, pairs = nk >> 1;
-    const int frow = lane & 31, fch = lane >> 5;
-    constexpr int NW = WM * WN, XI = BM / 8 / NW, WI = BN / 8 / NW;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, total = tiles_m * tiles_n;
+    const int padded = ((total + 8 * GRP - 1) / (8 * GRP)) * (8 * GRP);
+    const int nk = p.K / KE, pairs = nk >> 1;
 
-    // virtual block id -> output tile (the one-tile kernel's super-tile order)
+    // virtual block id -> output tile (the one-tile kernel's XCD-aware super-tile order)
     auto map_tile = [&](int vb, int& tile_m, int& tile_n) -> bool {
         const int x = vb & 7, j = vb >> 3;
         const int idx = ((j / GRP) * 8 + x) * GRP + (j % GRP);
@@ -921,122 +947,210 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmArgs<TI, TO> p
         }
         return false;
     };
-    const unsigned char* xg[XI];
-    const unsigned char* wg[WI];
-    auto set_ptrs = [&](int tile_m, int tile_n) {
+
+    // The lane id, recomputed where it is needed (v_mbcnt on an opaque zero: hipcc can neither hoist nor merge it). Left to a register
+    // that lives across the tile loop it is spilled beside the 128 accumulators, and a scratch reload waits vmcnt(0): it drains the
+    // request stream -- or, at the top of a tile, waits for the previous tile's stores.
+    auto fresh_lane = []() -> int {
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    };
+    // ---- request side (see the 8-phase loop of gemm_nt_kernel): scalar tile base + 32-bit lane offset
+    const unsigned char* xbase;
+    const unsigned char* wbase;
+    unsigned xq[2][2], wq[2][2];
+    auto set_req = [&](int tile_m, int tile_n) {
+        // (the lane id is made opaque per call: left visible, hipcc hoists the lane-dependent halves of these eight offsets out of the tile
+        // loop, keeps them live beside 128 accumulators and spills -- and every scratch reload waits vmcnt(0), i.e. drains the request stream)
+        const int lane = fresh_lane();
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        xbase = reinterpret_cast<const unsigned char*>(p.X + (long)m0 * p.ldx);
+        wbase = reinterpret_cast<const unsigned char*>(p.W + (long)n0 * p.ldw);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int row = (wave * XI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-            xg[i] = reinterpret_cast<const unsigned char*>(p.X + (long)min(tile_m * BM + row, p.M - 1) * p.ldx) + c * 16;
-        }
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = (wave * WI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-            wg[i] = reinterpret_cast<const unsigned char*>(p.W + (long)min(tile_n * BN + row, p.N - 1) * p.ldw) + c * 16;
+            for (int i = 0; i < 2; ++i) {
+                const int lr = (wv * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((lr >> 1) & 7);
+                const int xr = (lr >> 5) * 64 + hh * 32 + (lr & 31), wr_ = (lr >> 6) * 128 + hh * 64 + (lr & 63);
+                xq[hh][i] = (unsigned)(min(xr, p.M - 1 - m0) * (int)(p.ldx * sizeof(TI)) + c * 16);
+                wq[hh][i] = (unsigned)(min(wr_, p.N - 1 - n0) * (int)(p.ldw * sizeof(TI)) + c * 16);
+            }
+    };
+#define SP_REQ(BASE, OFFS, SLOT, KT)                                                                              \
+    {                                                                                                             \
+        const unsigned char* b_ = (BASE) + (long)(KT) * 128;                                                      \
+        asm volatile("" : "+s"(b_));                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                        \
+            unsigned o_ = OFFS[i_];                                                                               \
+            asm volatile("" : "+v"(o_));                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_ + o_), (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
+        }                                                                                                         \
+    }
+    // ---- read side: fragment offsets (set per tile, from a fresh lane id: sixteen registers that do not live across the epilogue)
+    int xl0[4], wl0[4], xl1[4], wl1[4];
+    auto set_read = [&]() {
+        const int ln = fresh_lane(), frow = ln & 31, fch = ln >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int fo = frow * 128 + (((kk * 2 + fch) ^ ((frow >> 1) & 7)) << 4);
+            xl0[kk] = wm * 32 * 128 + fo;
+            wl0[kk] = wn * 64 * 128 + fo;
+            xl1[kk] = xl0[kk] + 4 * HT;
+            wl1[kk] = wl0[kk] + 4 * HT;
         }
     };
-#define SA_PISSUE(BUFOFF, KT)                                                                                           \
-    {                                                                                                                   \
-        const long koff_ = (long)(KT) * 128;                                                                            \
-        _Pragma("unroll") for (int i = 0; i < XI; ++i) __builtin_amdgcn_global_load_lds(                                \
-            (gptr_t)(xg[i] + koff_), (lptr_t)(smem + (BUFOFF) + (wave * XI + i) * 1024), 16, 0, 0);                     \
-        _Pragma("unroll") for (int i = 0; i < WI; ++i) __builtin_amdgcn_global_load_lds(                                \
-            (gptr_t)(wg[i] + koff_), (lptr_t)(smem + (BUFOFF) + XBYTES + (wave * WI + i) * 1024), 16, 0, 0);            \
+    u32x4 xa[4], xb[4], wf[2][4];
+    f32x16 acc[4][2];
+#define SP_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : xl1[kk_]) + ((SLOT) & 3) * HT); }
+#define SP_RW(SLOT)                                                                                               \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                   \
+                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : wl1[kk_]) + ((SLOT) & 3) * HT + j_ * 4096); \
     }
-#define SA_PLANDED()                                     \
-    {                                                    \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        __syncthreads();                                 \
+    // ZERO: the quadrant's first MFMAs of the tile take the constant-zero C operand (0 * anything + 0: same bits as a cleared register)
+#define SP_MMA(XR, JH, I, ZERO)                                                                                   \
+    {                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                       \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                    \
+                if ((ZERO) && kk_ == 0) {                                                                         \
+                    f32x16 z_;                                                                                    \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) z_[r_] = 0.f;                               \
+                    acc[(JH) * 2 + j_][I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[j_][kk_]), __builtin_bit_cast(bf16x8, XR[kk_]), z_, 0, 0, 0); \
+                } else {                                                                                          \
+                    Mfma<TI>::run(acc[(JH) * 2 + j_][I], wf[j_][kk_], XR[kk_]);                                   \
+                }                                                                                                 \
+            }                                                                                                     \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
     }
+#define SP_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define SP_PHASE(READ, REQ, VMN, XR, JH, I, ZERO)     \
+    {                                                 \
+        READ;                                         \
+        __builtin_amdgcn_sched_barrier(0);            \
+        REQ;                                          \
+        if constexpr ((VMN) >= 0) SP_VM((VMN) < 0 ? 0 : (VMN)); \
+        __builtin_amdgcn_sched_barrier(0);            \
+        __builtin_amdgcn_s_barrier();                 \
+        __builtin_amdgcn_sched_barrier(0);            \
+        SP_MMA(XR, JH, I, ZERO);                      \
+        __builtin_amdgcn_sched_barrier(0);            \
+        __builtin_amdgcn_s_barrier();                 \
+        __builtin_amdgcn_sched_barrier(0);            \
+    }
+
     int tile_m = 0, tile_n = 0;
     if (!next_tile(tile_m, tile_n)) return;
-    set_ptrs(tile_m, tile_n);
-    SA_PISSUE(0, 0);
-    SA_PLANDED();
-    SA_PISSUE(BUF, 1);                                  // nk >= 2
+    set_req(tile_m, tile_n);
+    SP_REQ(xbase, xq[0], 0, 0); SP_REQ(wbase, wq[0], 1, 0); SP_REQ(xbase, xq[1], 2, 0); SP_REQ(wbase, wq[1], 3, 0);
+    SP_REQ(xbase, xq[0], 4, 1); SP_REQ(wbase, wq[0], 5, 1);
+    SP_VM(0);                                                    // the first pair's early phases run without counted waits (below)
+    __builtin_amdgcn_s_barrier();
+    if (wv >= 4) __builtin_amdgcn_s_barrier();                   // the second wave of every SIMD runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned char* stage = smem + 8 * HT + wv * 4096;            // this wave's private 4 KiB
     for (;;) {
-        // here: K-tile 0 of (tile_m, tile_n) has landed in buffer 0 and every wave has passed a barrier behind it; K-tile 1 is on
-        // its way into buffer 1
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         int nt_m = 0, nt_n = 0;
         const bool have_next = next_tile(nt_m, nt_n);
-        f32x16 acc[FN][FM];
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-        for (int pi = 0; pi < pairs; ++pi) {
-            const int kt = 2 * pi;
-            __builtin_amdgcn_sched_barrier(0);
-            SA_COMPUTE(smem);
-            __builtin_amdgcn_sched_barrier(0);
-            SA_PLANDED();                               // K-tile kt + 1 is in buffer 1; buffer 0 is free
-            if (kt + 2 <= last) {
-                SA_PISSUE(0, kt + 2);
-            } else if (have_next) {                     // last pair: buffer 0 takes the NEXT tile's first K-tile
-                set_ptrs(nt_m, nt_n);
-                SA_PISSUE(0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            SA_COMPUTE(smem + BUF);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 3 <= last) {
-                SA_PLANDED();                           // K-tile kt + 2 is in buffer 0; buffer 1 is free
-                SA_PISSUE(BUF, kt + 3);
-            }
+        set_req(tile_m, tile_n);                                 // (again, although the previous tile's tail already set them for its six look-ahead requests:
+        set_read();                                              //  recomputed, the offsets are not live across the epilogue -- which needs the registers)
+        // this wave's bias slice: lane l holds columns wn * 128 + 2 l, + 1 (packed bf16 pair)
+        // Branch-free on "no bias": a null bias reads a valid dummy address and is masked to zero (a named bool or a branch on it lived as
+        // a 0/1 VGPR across the tile loop and was spilled; its reload at the top of a tile waited vmcnt(0) = for the previous tile's
+        // stores). Adding +0 is exact here: an accumulator is never -0 (it starts from +0), everything else is unchanged by + 0.
+        const TI* bias_p = p.bias ? p.bias : p.W;
+        const unsigned bias_mask = p.bias ? 0xffffffffu : 0u;
+        // (first used in the epilogue: hipcc's own wait for this load is a vmcnt(0) wherever the first use stands -- a dummy use in phase 5
+        // drained the request stream there -- so it stands where the stream is about to be drained anyway)
+        const unsigned bpack_raw = *reinterpret_cast<const unsigned*>(bias_p + min(n0 + wn * 128 + 2 * fresh_lane(), p.N - 2));
+        {   // first two K-tiles of the tile: everything phases 0..3 read was requested before the previous tile's stores and retired
+            // by the vmcnt(0) in front of them (or by the prologue's) -- no counted wait until phase 4
+            SP_PHASE({ SP_RX(xa, 0); SP_RW(1); }, SP_REQ(xbase, xq[1], 6, 1), -1, xa, 0, 0, true);       // X0(0) is read HERE, not in the previous tile's last phase: 16 registers less across the epilogue
+            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, 1), -1, xb, 0, 1, true);
+            SP_PHASE(SP_RW(3),     SP_REQ(xbase, xq[0], 0, 2), -1, xb, 1, 1, true);
+            SP_PHASE(SP_RX(xb, 4), SP_REQ(wbase, wq[0], 1, 2), -1, xa, 1, 0, true);
+            SP_PHASE(SP_RW(5),     SP_REQ(xbase, xq[1], 2, 2),  8, xb, 0, 0, false);
+            SP_PHASE(SP_RX(xa, 6), SP_REQ(wbase, wq[1], 3, 2),  8, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, 3),  8, xa, 1, 1, false);
+            SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, 3),  8, xb, 1, 0, false);
+        }
+        for (int pi = 1; pi < pairs - 1; ++pi) {
+            const int t = 2 * pi;
+            SP_PHASE(SP_RW(1),     SP_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0, false);
+            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1, false);
+            SP_PHASE(SP_RW(3),     SP_REQ(xbase, xq[0], 0, t + 2), 8, xb, 1, 1, false);
+            SP_PHASE(SP_RX(xb, 4), SP_REQ(wbase, wq[0], 1, t + 2), 8, xa, 1, 0, false);
+            SP_PHASE(SP_RW(5),     SP_REQ(xbase, xq[1], 2, t + 2), 8, xb, 0, 0, false);
+            SP_PHASE(SP_RX(xa, 6), SP_REQ(wbase, wq[1], 3, t + 2), 8, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, t + 3), 8, xa, 1, 1, false);
+            SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, t + 3), 8, xb, 1, 0, false);
+        }
+        {   // last two K-tiles. With another tile behind them its first six half-tiles take the ring's next six requests (same slots, same
+            // distances, same counted waits); without, nothing is requested after
+            // W1(nk - 1) and the counted waits shrink with what is still in flight. ONE code path (the branches are wave-uniform and
+            // enclose requests and waits only): two copies of the phases, each redefining all accumulators, made hipcc spill them.
+            const int t = nk - 2;
+            SP_PHASE(SP_RW(1),     SP_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0, false);
+            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1, false);
+            if (have_next) set_req(nt_m, nt_n);
+            SP_PHASE(SP_RW(3),     { if (have_next) { SP_REQ(xbase, xq[0], 0, 0); SP_VM(8); } else { SP_VM(6); } }, -1, xb, 1, 1, false);
+            SP_PHASE(SP_RX(xb, 4), { if (have_next) { SP_REQ(wbase, wq[0], 1, 0); SP_VM(8); } else { SP_VM(4); } }, -1, xa, 1, 0, false);
+            SP_PHASE(SP_RW(5),     { if (have_next) { SP_REQ(xbase, xq[1], 2, 0); SP_VM(8); } else { SP_VM(2); } }, -1, xb, 0, 0, false);
+            SP_PHASE(SP_RX(xa, 6), { if (have_next) { SP_REQ(wbase, wq[1], 3, 0); SP_VM(8); } else { SP_VM(0); } }, -1, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     { if (have_next) { SP_REQ(xbase, xq[0], 4, 1); SP_VM(8); } },                    -1, xa, 1, 1, false);
+            SP_PHASE({},           { if (have_next) { SP_REQ(wbase, wq[0], 5, 1); SP_VM(8); } },                    -1, xb, 1, 0, false);
+            if (!have_next && wv < 4) __builtin_amdgcn_s_barrier();   // the leading half meets the trailing half's last barrier
         }
 
-        // ---- epilogue: two passes of 128 rows (the i-th 32-row block of every wave row) through buffer 1
-        // The epilogue's addresses are functions of the lane and thread ids only; left visible, hipcc hoists all of them out of the
-        // tile loop and keeps them in scratch beside the 128 accumulator registers -- and every scratch reload in the store loop waits
-        // vmcnt(0), i.e. for the previous store's acknowledgement (r04 ISA). The ids are made opaque once per tile instead.
-        int lane_e = lane, tid_e = tid;
-        asm volatile("" : "+v"(lane_e), "+v"(tid_e));
+        // ---- wave-private epilogue. Accumulator (j, i), register 4 g + r = output row wm * 64 + i * 32 + (lane & 31), column
+        // wn * 128 + j * 32 + g * 8 + (lane >> 5) * 4 + r.
+        // vmcnt retires loads AND stores in issue order, so a load issued behind a store cannot be waited for without waiting for that
+        // store's acknowledgement. The epilogue therefore runs in two passes: (1) registers only -- bias, activation / rotary (its table
+        // loads), rounding, packed in place; then the residual rows of the whole 64 x 128 block; ONE vmcnt(0) (which also retires the next
+        // tile's first half-tiles); (2) LDS staging + stores only, block by block (32 rows x 64 output columns = 4 KiB), no load behind
+        // the first store.
         constexpr bool GLU = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU);
-        constexpr int OW = GLU ? BN / 2 : BN;
-        constexpr int ROWB = OW * (int)sizeof(TO), CPR = ROWB / 16, XM = 7;
-        constexpr int PITERS = 128 * CPR / NT;                                // 16-byte chunks per thread per pass (8, or 4 for gated outputs)
-        constexpr int EPC = 16 / (int)sizeof(TO);
-        unsigned char* stage = smem + BUF;
-        const bool has_bias = p.bias != nullptr;
-        float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF);             // [BN] this tile's bias in fp32, beside the two operand buffers
-        if (tid_e < BN / 4) {
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (has_bias) load4(p.bias + min(n0 + tid_e * 4, p.N - 4), b);
-            *reinterpret_cast<float4*>(bias_s + tid_e * 4) = make_float4(b[0], b[1], b[2], b[3]);
-        }
         const int n_out = GLU ? p.N / 2 : p.N, n0_out = GLU ? n0 / 2 : n0;
-        // every wave: its own loads (the next tile's K-tile 0 among them) have landed; all waves: done reading buffer 1
-        SA_PLANDED();
+        const int lane_e = fresh_lane();                         // the epilogue's addresses are functions of the lane id only: not hoistable either
+        const int srow = lane_e & 31, lhi = lane_e >> 5;
+        // read-back geometry of a block: iteration `it` covers rows it * 8 + (lane >> 3), 16-byte chunk lane & 7
+        constexpr int NBLK = GLU ? 2 : 4;                        // GLU: a block spans all four j of an i (128 accumulator columns -> 64 outputs)
+        const int rrow = lane_e >> 3, rc = lane_e & 7;
+        [[maybe_unused]] u32x4 res[NBLK][4];                     // the residual rows of the wave's whole 64 x 128 block, requested FIRST: pass 1 covers their latency
+        // global addresses of the epilogue: scalar tile origin + 32-bit lane offset (tile-local row x pitch + column), like the requests
+        [[maybe_unused]] const unsigned char* r_tile = reinterpret_cast<const unsigned char*>(p.R + (long)m0 * p.ldr + n0_out);
+        unsigned char* c_tile = reinterpret_cast<unsigned char*>(p.C + (long)m0 * p.ldc + n0_out);
+        const int rows_left = p.M - m0, cols_left = n_out - n0_out;           // valid rows / output columns from the tile origin
+        if constexpr (EPI == EPI_RESIDUAL) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int srow = wm * 32 + (lane_e & 31);                           // staged row of this lane in pass i
-            constexpr int JG = 2;                                             // rotary entries are fetched for JG column blocks at a time (8 x 16 bytes)
-            [[maybe_unused]] float4 rope_v[JG][4];
+            for (int blk = 0; blk < NBLK; ++blk)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (EPI == EPI_ROPE) {
-                    if (j % JG == 0) {
-                        const int m = min(m0 + wm * WTM + i * 32 + (lane_e & 31), p.M - 1), half = p.rope_D >> 1;
-#pragma unroll
-                        for (int jj = 0; jj < JG; ++jj)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int n = min(min(n0 + wn * WTN + (j + jj) * 32 + g * 8 + (lane_e >> 5) * 4, p.N - 4), p.rope_cols - 4);
-                                rope_v[jj][g] = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((n % p.rope_D) >> 1));
-                            }
-                    }
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = min(wm * 64 + (blk >> 1) * 32 + it * 8 + rrow, rows_left - 1), cl = min(wn * 128 + (blk & 1) * 64 + rc * 8, cols_left - 8);
+                    res[blk][it] = *reinterpret_cast<const u32x4*>(r_tile + (unsigned)(rl * (int)(p.ldr * sizeof(TO)) + cl * (int)sizeof(TO)));
                 }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));       // (native vector type: arrays of HIP's uint2 struct are demoted to scratch)
+        using Pk = typename std::conditional<GLU, unsigned, u32x2>::type;     // the lane's 4 (GLU: 2) output values of one (j, i, g), packed
+        const unsigned bpack = bpack_raw & bias_mask;
+        Pk pk[4][2][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ncol = wn * WTN + j * 32 + g * 8 + (lane_e >> 5) * 4;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int wcol = j * 32 + g * 8 + lhi * 4;           // column inside the wave's 128
+                // (ds_bpermute directly: __shfl adds `lane & ~63`, a lane-id term hipcc hoists out of the tile loop and spills)
+                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((wcol >> 1) << 2, (int)bpack), hi = (unsigned)__builtin_amdgcn_ds_bpermute(((wcol >> 1) + 1) << 2, (int)bpack);
+                const float b4[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
                     float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                    if (has_bias) {                                           // (adding the staged zeros of a null bias would turn -0 into +0)
-                        const float4 b4 = *reinterpret_cast<const float4*>(bias_s + ncol);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b4[r];
                     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
@@ -1048,69 +1162,76 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmArgs<TI, TO> p
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
                     if constexpr (EPI == EPI_ROPE) {
-                        const int n = min(n0 + ncol, p.N - 4);
+                        const int n = min(n0 + wn * 128 + wcol, p.N - 4);
                         if (n < p.rope_cols) {
-                            const float4 cs = rope_v[j % JG][g];
+                            // reference order (encoder/__init__.py:188-199), products and sums pinned as in gemm_nt_kernel's epilogue
+                            const int m = min(m0 + wm * 64 + i * 32 + srow, p.M - 1), half = p.rope_D >> 1;
+                            const float4 cs = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((min(n, p.rope_cols - 4) % p.rope_D) >> 1));
                             const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
                             v[0] = __fmaf_rn(x0, cs.x, -__fmul_rn(x1, cs.y)); v[1] = __fmaf_rn(x1, cs.x, __fmul_rn(x0, cs.y));
                             v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
                         }
                     }
                     if constexpr (GLU) {
-                        const int boff = (ncol >> 1) * (int)sizeof(TO);
-                        TO* dst = reinterpret_cast<TO*>(stage + srow * ROWB + ((((boff >> 4) ^ (srow & XM)) << 4) | (boff & 15)));
                         if constexpr (EPI == EPI_GEGLU) {
                             const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
-                            store2(dst, g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
+                            pk[j][i][g] = pack2(g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
                         } else {
-                            store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                            pk[j][i][g] = pack2(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
                         }
                     } else {
-                        const int boff = ncol * (int)sizeof(TO);
-                        TO* dst = reinterpret_cast<TO*>(stage + srow * ROWB + ((((boff >> 4) ^ (srow & XM)) << 4) | (boff & 15)));
-                        store4(dst, v[0], v[1], v[2], v[3]);
+                        pk[j][i][g] = Pk{pack2(v[0], v[1]), pack2(v[2], v[3])};
                     }
                 }
             }
-            // This pass's residual rows: one batch of loads, issued once the pass's accumulators are staged and dead (at the top of
-            // the pass the 32 registers do not fit beside 128 accumulators: r04 ISA, 45 spills with reloads between the stores).
-            [[maybe_unused]] u32x4 res[PITERS];
-            if constexpr (EPI == EPI_RESIDUAL) {
-                __builtin_amdgcn_sched_barrier(0);
+        SP_VM(0);                                                // every load in flight has landed; from here on this wave issues only LDS traffic and stores
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int it = 0; it < PITERS; ++it) {
-                    const int id = tid_e + it * NT, sr = id / CPR, c = id % CPR;
-                    const int m = min(m0 + (sr >> 5) * WTM + i * 32 + (sr & 31), p.M - 1), n = min(n0_out + c * EPC, n_out - EPC);
-                    res[it] = *reinterpret_cast<const u32x4*>(p.R + (long)m * p.ldr + n);
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int i = GLU ? blk : blk >> 1, jh = GLU ? 0 : blk & 1;
+            const int cl = wn * (GLU ? 64 : 128) + jh * 64 + rc * 8;          // tile-local output column of this lane's chunk
+#pragma unroll
+            for (int j2 = 0; j2 < (GLU ? 4 : 2); ++j2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ocol = GLU ? (j2 * 32 + g * 8 + lhi * 4) >> 1 : j2 * 32 + g * 8 + lhi * 4;     // output column inside the block
+                    const int boff = ocol * (int)sizeof(TO);
+                    *reinterpret_cast<Pk*>(stage + srow * 128 + ((((boff >> 4) ^ (srow & 7)) << 4) | (boff & 15))) = pk[jh * 2 + j2][i][g];
                 }
-            }
-            __syncthreads();
+            // read the block back as whole 16-byte chunks of contiguous rows (this wave's own LDS writes: the LDS executes a wave's
+            // operations in order, no barrier)
+            u32x4 raw[4];
 #pragma unroll
-            for (int it = 0; it < PITERS; ++it) {
-                const int id = tid_e + it * NT, sr = id / CPR, c = id % CPR;
-                const int m = m0 + (sr >> 5) * WTM + i * 32 + (sr & 31), n = n0_out + c * EPC;
-                if (m >= p.M || n >= n_out) continue;                         // stores only: nothing below waits on memory
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(stage + sr * ROWB + ((c ^ (sr & XM)) << 4));
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + rrow;
+                raw[it] = *reinterpret_cast<const u32x4*>(stage + r * 128 + ((rc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = wm * 64 + i * 32 + it * 8 + rrow;
+                if (rl >= rows_left || cl >= cols_left) continue;
+                TO* dst = reinterpret_cast<TO*>(c_tile + (unsigned)(rl * (int)(p.ldc * sizeof(TO)) + cl * (int)sizeof(TO)));
                 if constexpr (EPI == EPI_RESIDUAL) {
-                    float a[EPC], r[EPC];
-                    unpack16(make_uint4(raw[0], raw[1], raw[2], raw[3]), a, (TO*)nullptr);
-                    unpack16(make_uint4(res[it][0], res[it][1], res[it][2], res[it][3]), r, (TO*)nullptr);
-                    TO* dst = p.C + (long)m * p.ldc + n;
+                    float a[8], r8[8];
+                    unpack16(make_uint4(raw[it][0], raw[it][1], raw[it][2], raw[it][3]), a, (TO*)nullptr);
+                    unpack16(make_uint4(res[blk][it][0], res[blk][it][1], res[blk][it][2], res[blk][it][3]), r8, (TO*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < EPC; e += 4) store4(dst + e, a[e] + r[e], a[e + 1] + r[e + 1], a[e + 2] + r[e + 2], a[e + 3] + r[e + 3]);
-                    __builtin_amdgcn_sched_barrier(0);                        // one chunk at a time: interleaved, the 8 unpacked chunks spill
+                    for (int e = 0; e < 8; e += 4) store4(dst + e, a[e] + r8[e], a[e + 1] + r8[e + 1], a[e + 2] + r8[e + 2], a[e + 3] + r8[e + 3]);
+                    __builtin_amdgcn_sched_barrier(0);           // one chunk at a time: interleaved, the unpacked chunks of a block spill (and a reload behind a store waits for that store)
                 } else {
-                    *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = raw;
+                    *reinterpret_cast<u32x4*>(dst) = raw[it];
                 }
             }
-            __syncthreads();                                                  // the staged rows have been read: buffer 1 is free again
         }
-        if (have_next) SA_PISSUE(BUF, 1);                                     // the next tile's K-tile 1 (set_ptrs ran in the last pair)
         if (!have_next) return;
         tile_m = nt_m; tile_n = nt_n;
     }
-#undef SA_PISSUE
-#undef SA_PLANDED
+#undef SP_PHASE
+#undef SP_VM
+#undef SP_MMA
+#undef SP_RW
+#undef SP_RX
+#undef SP_REQ
 }
 #undef SA_COMPUTE
 #undef SA_COMPUTE_FULL
@@ -1183,7 +1304,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// Launch of the persistent 256x256 tile loop: one workgroup per CU (128 KB of LDS each), XCD-aware super-tiles as in launch_gemm_cfg.
+// Launch of the persistent 8-phase tile loop: one workgroup per CU (160 KB of LDS each), XCD-aware super-tiles as in launch_gemm_cfg.
 template <typename TI, typename TO, int EPI>
 static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr int BM = 256, BN = 256, GRP = 32;
@@ -1201,8 +1322,8 @@ static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) 
         n_cu = (n_cu / 8) * 8;                              // whole XCD rounds: virtual block b stays on XCD b % 8 in every round
     }
     const int grid = std::min(padded, n_cu);
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 128 + BN * sizeof(float);
-    auto kern = gemm_nt_persist_kernel<TI, TO, EPI>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 128 + 8 * 4096;      // the half-tile ring + 4 KiB of epilogue staging per wave
+    auto kern = gemm_nt_p8p_kernel<TI, TO, EPI>;
     static AttrOnce attr;
     attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
@@ -1281,7 +1402,8 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         if (bigtile && a.K >= tuning().bigtile_min_k && ((t256 >= 256 && cost256 <= cost128) || tuning().bigtile_any)) {
             if constexpr (EPI != EPI_ARGMAX) {
                 const int nk = a.K / Ty<TI>::KE;
-                if (tuning().persist && nk >= 2 && nk % 2 == 0) return launch_gemm_persist<TI, TO, EPI>(a, s);
+                if constexpr (sizeof(TI) == 2)
+                    if (tuning().persist && nk >= 4 && nk % 2 == 0 && a.N % 8 == 0) return launch_gemm_persist<TI, TO, EPI>(a, s);
             }
             // bigtile = 2: the same tile on FOUR waves (128 x 128 per wave, 256 accumulator registers in AGPRs, one wave per SIMD):
             // two thirds of the LDS fragment bytes per MFMA of the 8-wave layout (32 KB per 64 MFMAs instead of 24 KB per 32). A third
@@ -1290,13 +1412,7 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             if constexpr (sizeof(TI) == 2 && EPI != EPI_ARGMAX) {
                 if (bigtile == 2) return launch_gemm_cfg<TI, TO, 256, 256, 2, 2, EPI, false, 2>(a, s);
                 // bigtile = 3: the 8-phase schedule (half-tile ring, counted vmcnt, two wave groups one barrier apart); even K-tile counts
-                if (bigtile == 3 && (a.K / Ty<TI>::KE) % 2 == 0) {
-                    GemmArgs<TI, TO> b = a;
-                    b.stagger = tuning().p8_stagger;
-                    const int rc = launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(b, s);
-                    a.bn_used = b.bn_used;
-                    return rc;
-                }
+                if (bigtile == 3 && (a.K / Ty<TI>::KE) % 2 == 0) return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(a, s);
             }
             return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 2>(a, s);
         }

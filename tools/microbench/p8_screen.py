@@ -4,7 +4,7 @@ Same K order, same MFMA, same accumulator assignment -> outputs must be BIT-iden
 rare wrong tiles that come and go with shape and memory load, so every shape is run `REPS` times against fresh operands, with a
 bandwidth hog on a second stream for half of the runs (DMA landing order changes under load).
 
-    python tools/microbench/p8_screen.py [reps]
+    python tools/microbench/p8_screen.py [reps] [persist]       (persist: screen the PERSISTENT 8-phase loop, sa::Tuning persist = 1, instead)
 """
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,8 +13,9 @@ from surya_amd import _lib as L
 
 lib = L.lib()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+PERSIST = len(sys.argv) > 2 and sys.argv[2] == "persist"
 # (M, N, K, epi): small / ragged / one round / several rounds; K-tile counts 2, 4, 6, 20, 54, 64; epilogues bias, residual, gelu, swiglu
-shapes = [(512, 512, 128, 0), (512, 512, 256, 1), (300, 264, 384, 0), (777, 1280, 1280, 1), (4096, 4096, 4096, 0), (2048, 6912, 1280, 3),
+shapes = [(512, 512, 128, 0), (512, 512, 256, 1), (300, 264, 384, 0), (1024, 512, 256, 3), (70000, 256, 512, 1), (777, 1280, 1280, 1), (4096, 4096, 4096, 0), (2048, 6912, 1280, 3),
           (46460, 1280, 1280, 1), (15360, 1792, 1280, 0), (8192, 1280, 3456, 2), (46460, 3840, 1280, 0)]
 L.check(lib.surya_set_tuning(b"bigtile_any", C.c_int(1)), "tuning")
 hog_stream = torch.cuda.Stream()
@@ -33,6 +34,7 @@ for M, N, K, epi in shapes:
         outs = {}
         for v in (1, 3):
             L.check(lib.surya_set_tuning(b"bigtile", C.c_int(v)), "tuning")
+            L.check(lib.surya_set_tuning(b"persist", C.c_int(1 if (PERSIST and v == 3) else 0)), "tuning")
             c = torch.full((M, No), float("nan"), device="cuda", dtype=torch.bfloat16)
             torch.cuda.synchronize()
             if rep % 2 == 1:
@@ -55,6 +57,7 @@ for M, N, K, epi in shapes:
     bad += mism
     print(f"M={M:6d} N={N:5d} K={K:5d} epi={epi}: {REPS} runs, mismatching elements {mism}", flush=True)
 L.check(lib.surya_set_tuning(b"bigtile_any", C.c_int(0)), "tuning")
-L.check(lib.surya_set_tuning(b"bigtile", C.c_int(1)), "tuning")
-print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} elements)")
+L.check(lib.surya_set_tuning(b"bigtile", C.c_int(3)), "tuning")
+L.check(lib.surya_set_tuning(b"persist", C.c_int(0)), "tuning")
+print("RACE SCREEN (persistent loop)" if PERSIST else "RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} elements)")
 sys.exit(0 if bad == 0 else 1)
