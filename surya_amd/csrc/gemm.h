@@ -1375,6 +1375,13 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             // else 64x64, direct-to-LDS. Larger gate|up tiles (128x64: +26 us/step, 128x128: +69), a 256x128 lm_head tile (+30) and
             // 3- / 4-stage rings for lm_head (+25) all lost in r02 (profiles/r02_decode_sweeps.md).
             if (a.N >= 64 * 512) return launch_gemm_cfg<TI, TO, 128, 128, 2, 2, EPI, false, 2>(a, s);
+            if constexpr (EPI == EPI_SWIGLU && sizeof(TI) == 2) {
+                // decode gate|up (M = 256, N = 10240, K = 1280): 4 MFMAs per wave and K-tile against a ~700-cycle L2 round trip -- with two
+                // stages a workgroup's 20 K-tiles are 20 serial round trips. Round 5 A/B: a 3- / 4-stage ring (the split-K tiles' loop) keeps
+                // 2 / 3 K-tiles in flight per workgroup; 48 KiB keeps all 640 workgroups resident (3 per CU), 64 KiB only 512.
+                if (tuning().gateup_ring == 3) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 3>(a, s);
+                if (tuning().gateup_ring == 4) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 4>(a, s);
+            }
             return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI, false, 2>(a, s);
         }
         if (a.M > 64) {

@@ -57,7 +57,7 @@ def main():
         for k, v in kw.items():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
-    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8, dattn=4, rnorm=2, ghead=2, fuse_embed=1, lmhead=1, kvprefetch=0)
+    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8, dattn=4, rnorm=2, ghead=2, fuse_embed=1, lmhead=1, kvprefetch=0, gateup_ring=2)
     if args.configs == "base":
         variants = [dict()]
     elif args.configs == "fewer":        # fewer, longer split-K slices for the bf16 path
@@ -66,6 +66,8 @@ def main():
     elif args.configs == "r4":           # round 4: every new decode-step kernel against the round-3 kernel it replaces, one at a time
         variants = [dict(), dict(dattn=3), dict(rnorm=1), dict(ghead=1, fuse_embed=0), dict(fuse_embed=0), dict(lmhead=0), dict(lmhead=2),
                     dict(dattn=3, rnorm=1, ghead=1, fuse_embed=0, lmhead=0), dict(graph=1), dict()]
+    elif args.configs == "r5":           # round 5: LDS stages of the decode gate|up loop (2 = unrolled pair, 3 / 4 = ring with counted vmcnt), interleaved
+        variants = [dict(), dict(gateup_ring=3), dict(gateup_ring=4), dict(), dict(gateup_ring=3), dict(gateup_ring=4)]
     elif args.configs == "pf":           # K/V prefetch workgroups in the reduce kernels, on / off, interleaved
         variants = [dict(kvprefetch=1), dict(), dict(kvprefetch=1), dict(), dict(lmhead=2, kvprefetch=1), dict(lmhead=2)]
     elif args.configs == "fp8only":
