@@ -173,7 +173,7 @@ struct Tuning {
                              // Measured slower (gpurun r04d, 256 slots: 1165 us per step on vs 1100 off): the extra workgroups delay the reduce rows more than the warm L2 saves
     int lmhead = 1;          // lm_head (N >= 32768, M <= 256): 1 = one round of 256x320 tiles with the greedy partials taken from the accumulators, 0 = 128x128 tiles
     int dattn_db = 0;        // bf16 decode attention with two K/V tile buffers (decode_attn_flash2_kernel<.., true>: next tile's fetch overlaps this tile's
-                             // compute): 0 = when some active slot's context exceeds one 128-key tile (host bound), 1 = always, -1 = never
+                             // compute): 0 = when some active slot's context exceeds one 128-key tile (host bound; eager launches only -- under graph replay, `graph` = 1, the single-buffer kernel runs and the bound is not advanced), 1 = always, -1 = never
     int lay_ln = 1;          // layout / table encoder LayerNorm (bf16): 1 = rows held in registers by C / 8 lanes (layernorm_rows_bf16_kernel), 0 = a wave per row
     int det_head_blk = 1;    // detector's folded decode head: 1 = register-blocked sum + classify (4 x 2 pixel blocks), 0 = per-pixel kernel
     int persist = 0;         // 256x256 bf16 GEMMs as a persistent tile loop (next tile's K-tiles in flight during the epilogue): 1 = on. Measured

@@ -1059,6 +1059,10 @@ class RecognitionPredictor(BasePredictor):
                 and isinstance(det_predictor, DetectionPredictor)
                 and type(det_predictor).__call__ is DetectionPredictor.__call__ and type(det_predictor)._call is DetectionPredictor._call
                 and type(det_predictor).iter_detect is DetectionPredictor.iter_detect
+                # ... nor the pieces iter_detect is made of: a subclass that customises them for __call__ would be silently bypassed
+                and type(det_predictor)._detect is DetectionPredictor._detect
+                and type(det_predictor)._detect_device is DetectionPredictor._detect_device
+                and type(det_predictor)._iter_detect_device is DetectionPredictor._iter_detect_device
                 and det_predictor.device_postprocess and not det_predictor.shard_pages)
 
     def _call_streamed(self, images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images,
@@ -1161,8 +1165,9 @@ class RecognitionPredictor(BasePredictor):
                     self.generate({"prompts": [], "max_tokens": {}, "overall_max_tokens": overall_max_tokens}, recognition_batch_size,
                                   on_done=on_done, on_flush=on_flush, feed=feed)
                 except BaseException:
-                    stop.set()                         # the producer ends after the batch it is working on
-                    raise
+                    stop.set()                         # the producer ends after the batch it is working on ...
+                    producer.join(timeout=30.0)        # ... and is waited for: it launches detector and pre-processing work on this predictor's
+                    raise                              # objects and stream, and a retry of the call must not run beside it
                 producer.join()                        # it has put FEED_END: nothing left to run
                 on_flush()
                 t2 = time.perf_counter()
