@@ -142,6 +142,15 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU inside the bf16 GEMM epilogues (EPI_SWIGLU): the reciprocal instruction (v_rcp_f32, 1 ulp) instead of an IEEE division (~10
+// instructions; 64 of them per lane and 256 x 256 tile: the SiLU arithmetic was ~5k of a 58k-cycle tile, tools/microbench/p8_timing.hip).
+// The result is rounded to bf16 right after, and EVERY bf16 tile shape uses this one function, so a row's value still does not depend on the
+// tile that computed it; fp32 reference mode keeps the division.
+template <typename TI>
+__device__ __forceinline__ float silu_epi(float x) {
+    if constexpr (sizeof(TI) == 2) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    else return silu_f(x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU, tanh approximation (torch gelu(approximate="tanh") / transformers gelu_pytorch_tanh)
 __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
@@ -176,9 +185,9 @@ struct Tuning {
                              // compute): 0 = when some active slot's context exceeds one 128-key tile (host bound; eager launches only -- under graph replay, `graph` = 1, the single-buffer kernel runs and the bound is not advanced), 1 = always, -1 = never
     int lay_ln = 1;          // layout / table encoder LayerNorm (bf16): 1 = rows held in registers by C / 8 lanes (layernorm_rows_bf16_kernel), 0 = a wave per row
     int det_head_blk = 1;    // detector's folded decode head: 1 = register-blocked sum + classify (4 x 2 pixel blocks), 0 = per-pixel kernel
-    int persist = 0;         // 256x256 bf16 GEMMs as a persistent tile loop (next tile's K-tiles in flight during the epilogue): 1 = on. Measured
-                             // bit-identical and NOT faster (r04b: -1.5 ... +1.5 % per encoder / prefill shape, prefill of 256 lines 33.8 vs 33.4 ms):
-                             // the hidden first-K-tile round trip is paid back in the two-pass epilogue and the per-tile tile-map arithmetic
+    int persist = 1;         // 256x256 bf16 GEMMs (>= 4 even K-tiles) as the PERSISTENT 8-phase loop (gemm_nt_p8p_kernel: the half-tile ring runs on across
+                             // tiles, wave-private epilogue): 1 = on (round 5: +3...10 % per encoder / prefill shape once the two wave groups were
+                             // re-aligned around the epilogue, +0.9 % on the bench's recognition leg); 0 = one tile per workgroup
 };
 inline Tuning& tuning() { static Tuning t; return t; }
 inline int& tuning_epoch() { static int e = 0; return e; }   // bumped by surya_set_tuning whenever a knob changes value

@@ -66,6 +66,12 @@ struct GemmArgs {
     const TI* conv_zero = nullptr;
     int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKW = 0, cStride = 0, cPad = 0, cTaps = 0;
     int conv_lean = 1;           // 1: per-(row, tap) gather state precomputed once per workgroup when K-tiles align with taps (0 = round-4 gather, for A/B)
+#ifndef SA_P8_TIMING
+#define SA_P8_TIMING 0                // tools/microbench/p8_timing.hip: s_memtime stamps of the persistent 8-phase loop's segments into `dbg`
+#endif
+#if SA_P8_TIMING
+    long long* dbg = nullptr;        // [workgroup][2 waves (0, 4)][SA_P8_TIMING_TILES][12] cycle stamps
+#endif
 };
 
 // 32x32 MFMA tiles: per flop they need half the LDS fragment traffic of 16x16 tiles (the 16x16 version of this kernel
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                         const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
                         store2(dst, g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
                     } else {
-                        store2(dst, silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+                        store2(dst, silu_epi<TI>(v[0]) * v[1], silu_epi<TI>(v[2]) * v[3]);
                     }
                 } else {
                     const int boff = ncol * (int)sizeof(TS);
@@ -1041,6 +1047,18 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         __builtin_amdgcn_sched_barrier(0);            \
     }
 
+#if SA_P8_TIMING
+    int dbg_tile = 0;
+#define SP_STAMP(IDX)                                                                                                       \
+    {                                                                                                                       \
+        if ((wv == 0 || wv == 4) && dbg_tile < 24 && p.dbg) {                                                                \
+            const long long t_ = (long long)__builtin_readcyclecounter();                                                    \
+            if (fresh_lane() == 0) p.dbg[(((long)blockIdx.x * 2 + (wv >> 2)) * 24 + dbg_tile) * 12 + (IDX)] = t_;             \
+        }                                                                                                                   \
+    }
+#else
+#define SP_STAMP(IDX) {}
+#endif
     int tile_m = 0, tile_n = 0;
     if (!next_tile(tile_m, tile_n)) return;
     set_req(tile_m, tile_n);
@@ -1048,7 +1066,6 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     SP_REQ(xbase, xq[0], 4, 1); SP_REQ(wbase, wq[0], 5, 1);
     SP_VM(0);                                                    // the first pair's early phases run without counted waits (below)
     __builtin_amdgcn_s_barrier();
-    if (wv >= 4) __builtin_amdgcn_s_barrier();                   // the second wave of every SIMD runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
     unsigned char* stage = smem + 8 * HT + wv * 4096;            // this wave's private 4 KiB
     for (;;) {
@@ -1057,26 +1074,27 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         const bool have_next = next_tile(nt_m, nt_n);
         set_req(tile_m, tile_n);                                 // (again, although the previous tile's tail already set them for its six look-ahead requests:
         set_read();                                              //  recomputed, the offsets are not live across the epilogue -- which needs the registers)
-        // this wave's bias slice: lane l holds columns wn * 128 + 2 l, + 1 (packed bf16 pair)
-        // Branch-free on "no bias": a null bias reads a valid dummy address and is masked to zero (a named bool or a branch on it lived as
-        // a 0/1 VGPR across the tile loop and was spilled; its reload at the top of a tile waited vmcnt(0) = for the previous tile's
-        // stores). Adding +0 is exact here: an accumulator is never -0 (it starts from +0), everything else is unchanged by + 0.
-        const TI* bias_p = p.bias ? p.bias : p.W;
-        const unsigned bias_mask = p.bias ? 0xffffffffu : 0u;
-        // (first used in the epilogue: hipcc's own wait for this load is a vmcnt(0) wherever the first use stands -- a dummy use in phase 5
-        // drained the request stream there -- so it stands where the stream is about to be drained anyway)
-        const unsigned bpack_raw = *reinterpret_cast<const unsigned*>(bias_p + min(n0 + wn * 128 + 2 * fresh_lane(), p.N - 2));
+        // The second wave of every SIMD runs one barrier behind the first -- INSIDE a tile's K loop only. The two groups are re-aligned
+        // behind the last phase (below) and staggered again here: with the stagger carried through the epilogue, the trailing group waited
+        // at its last barrier for the leading group's whole epilogue and the leading group then waited in phase 0 for the trailing group's
+        // (tools/microbench/p8_timing.hip: 2 x 9.3k of a 63.7k-cycle tile at K = 1280 -- the two epilogues ran one after the other).
+        if (wv >= 4) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        SP_STAMP(0);
         {   // first two K-tiles of the tile: everything phases 0..3 read was requested before the previous tile's stores and retired
             // by the vmcnt(0) in front of them (or by the prologue's) -- no counted wait until phase 4
             SP_PHASE({ SP_RX(xa, 0); SP_RW(1); }, SP_REQ(xbase, xq[1], 6, 1), -1, xa, 0, 0, true);       // X0(0) is read HERE, not in the previous tile's last phase: 16 registers less across the epilogue
             SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, 1), -1, xb, 0, 1, true);
             SP_PHASE(SP_RW(3),     SP_REQ(xbase, xq[0], 0, 2), -1, xb, 1, 1, true);
             SP_PHASE(SP_RX(xb, 4), SP_REQ(wbase, wq[0], 1, 2), -1, xa, 1, 0, true);
+            SP_STAMP(1);
             SP_PHASE(SP_RW(5),     SP_REQ(xbase, xq[1], 2, 2),  8, xb, 0, 0, false);
+            SP_STAMP(2);
             SP_PHASE(SP_RX(xa, 6), SP_REQ(wbase, wq[1], 3, 2),  8, xa, 0, 1, false);
             SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, 3),  8, xa, 1, 1, false);
             SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, 3),  8, xb, 1, 0, false);
         }
+        SP_STAMP(3);
         for (int pi = 1; pi < pairs - 1; ++pi) {
             const int t = 2 * pi;
             SP_PHASE(SP_RW(1),     SP_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0, false);
@@ -1088,6 +1106,8 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, t + 3), 8, xa, 1, 1, false);
             SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, t + 3), 8, xb, 1, 0, false);
         }
+        SP_STAMP(4);
+        unsigned bpack_raw = 0, bias_mask = 0;
         {   // last two K-tiles. With another tile behind them its first six half-tiles take the ring's next six requests (same slots, same
             // distances, same counted waits); without, nothing is requested after
             // W1(nk - 1) and the counted waits shrink with what is still in flight. ONE code path (the branches are wave-uniform and
@@ -1101,10 +1121,21 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             SP_PHASE(SP_RW(5),     { if (have_next) { SP_REQ(xbase, xq[1], 2, 0); SP_VM(8); } else { SP_VM(2); } }, -1, xb, 0, 0, false);
             SP_PHASE(SP_RX(xa, 6), { if (have_next) { SP_REQ(wbase, wq[1], 3, 0); SP_VM(8); } else { SP_VM(0); } }, -1, xa, 0, 1, false);
             SP_PHASE(SP_RW(7),     { if (have_next) { SP_REQ(xbase, xq[0], 4, 1); SP_VM(8); } },                    -1, xa, 1, 1, false);
+            // this wave's bias slice: lane l holds columns wn * 128 + 2 l, + 1 (packed bf16 pair). Requested in the tile's LAST phase: one
+            // register for one phase (at the top of the tile it lived through the whole K loop and the RoPE instantiation spilled it behind
+            // a vmcnt(0) -- at the top of a tile that waits for the previous tile's stores); one more op in the request stream, older than
+            // this phase's request, so the counted wait still retires the half-tile it is for.
+            // Branch-free on "no bias": a null bias reads a valid dummy address and is masked to zero (a named bool or a branch on it lived as
+            // a 0/1 VGPR across the tile loop and was spilled; its reload at the top of a tile waited vmcnt(0) = for the previous tile's
+            // stores). Adding +0 is exact here: an accumulator is never -0 (it starts from +0), everything else is unchanged by + 0.
+            const TI* bias_p = p.bias ? p.bias : p.W;
+            bias_mask = p.bias ? 0xffffffffu : 0u;
+            bpack_raw = *reinterpret_cast<const unsigned*>(bias_p + min(n0 + wn * 128 + 2 * fresh_lane(), p.N - 2));
             SP_PHASE({},           { if (have_next) { SP_REQ(wbase, wq[0], 5, 1); SP_VM(8); } },                    -1, xb, 1, 0, false);
-            if (!have_next && wv < 4) __builtin_amdgcn_s_barrier();   // the leading half meets the trailing half's last barrier
+            if (wv < 4) __builtin_amdgcn_s_barrier();             // the leading half meets the trailing half's last barrier: both enter the epilogue together
         }
 
+        SP_STAMP(5);
         // ---- wave-private epilogue. Accumulator (j, i), register 4 g + r = output row wm * 64 + i * 32 + (lane & 31), column
         // wn * 128 + j * 32 + g * 8 + (lane >> 5) * 4 + r.
         // vmcnt retires loads AND stores in issue order, so a load issued behind a store cannot be waited for without waiting for that
@@ -1139,65 +1170,97 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         const unsigned bpack = bpack_raw & bias_mask;
         Pk pk[4][2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int wcol = j * 32 + g * 8 + lhi * 4;           // column inside the wave's 128
-                // (ds_bpermute directly: __shfl adds `lane & ~63`, a lane-id term hipcc hoists out of the tile loop and spills)
-                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((wcol >> 1) << 2, (int)bpack), hi = (unsigned)__builtin_amdgcn_ds_bpermute(((wcol >> 1) + 1) << 2, (int)bpack);
-                const float b4[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+            for (int i = 0; i < 2; ++i) {
+                // rotary table entries of this (row block, column-block pair): ONE batch of eight 16-byte loads, then the arithmetic (loaded
+                // where they are used, each load is followed by its own vmcnt(0): 32 serial L2 round trips per tile in the first ISA)
+                [[maybe_unused]] float4 rope_v[2][4];
+                if constexpr (EPI == EPI_ROPE) {
+                    const int m = min(m0 + wm * 64 + i * 32 + srow, p.M - 1), half = p.rope_D >> 1;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                    for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += b4[r];
-                    if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-                    } else if constexpr (EPI == EPI_HARDSWISH) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
-                    } else if constexpr (EPI == EPI_RELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    if constexpr (EPI == EPI_ROPE) {
-                        const int n = min(n0 + wn * 128 + wcol, p.N - 4);
-                        if (n < p.rope_cols) {
-                            // reference order (encoder/__init__.py:188-199), products and sums pinned as in gemm_nt_kernel's epilogue
-                            const int m = min(m0 + wm * 64 + i * 32 + srow, p.M - 1), half = p.rope_D >> 1;
-                            const float4 cs = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((min(n, p.rope_cols - 4) % p.rope_D) >> 1));
-                            const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
-                            v[0] = __fmaf_rn(x0, cs.x, -__fmul_rn(x1, cs.y)); v[1] = __fmaf_rn(x1, cs.x, __fmul_rn(x0, cs.y));
-                            v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = min(min(n0 + wn * 128 + (jp * 2 + j2) * 32 + g * 8 + lhi * 4, p.N - 4), p.rope_cols - 4);
+                            rope_v[j2][g] = *reinterpret_cast<const float4*>(p.rope + (long)m * half + ((n % p.rope_D) >> 1));
                         }
-                    }
-                    if constexpr (GLU) {
-                        if constexpr (EPI == EPI_GEGLU) {
-                            const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
-                            pk[j][i][g] = pack2(g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
-                        } else {
-                            pk[j][i][g] = pack2(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
-                        }
-                    } else {
-                        pk[j][i][g] = Pk{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                    }
                 }
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int j = jp * 2 + j2;
+                        const int wcol = j * 32 + g * 8 + lhi * 4;           // column inside the wave's 128
+                        // (ds_bpermute directly: __shfl adds `lane & ~63`, a lane-id term hipcc hoists out of the tile loop and spills)
+                        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((wcol >> 1) << 2, (int)bpack), hi = (unsigned)__builtin_amdgcn_ds_bpermute(((wcol >> 1) + 1) << 2, (int)bpack);
+                        float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                        v[0] += __uint_as_float(lo << 16); v[1] += __uint_as_float(lo & 0xffff0000u);
+                        v[2] += __uint_as_float(hi << 16); v[3] += __uint_as_float(hi & 0xffff0000u);
+                        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                        } else if constexpr (EPI == EPI_HARDSWISH) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
+                        } else if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        if constexpr (EPI == EPI_ROPE) {
+                            const int n = min(n0 + wn * 128 + wcol, p.N - 4);
+                            if (n < p.rope_cols) {
+                                // reference order (encoder/__init__.py:188-199), products and sums pinned as in gemm_nt_kernel's epilogue
+                                const float4 cs = rope_v[j2][g];
+                                const float x0 = Ty<TO>::rnd(v[0]), x1 = Ty<TO>::rnd(v[1]), x2 = Ty<TO>::rnd(v[2]), x3 = Ty<TO>::rnd(v[3]);
+                                v[0] = __fmaf_rn(x0, cs.x, -__fmul_rn(x1, cs.y)); v[1] = __fmaf_rn(x1, cs.x, __fmul_rn(x0, cs.y));
+                                v[2] = __fmaf_rn(x2, cs.z, -__fmul_rn(x3, cs.w)); v[3] = __fmaf_rn(x3, cs.z, __fmul_rn(x2, cs.w));
+                            }
+                        }
+                        if constexpr (GLU) {
+                            if constexpr (EPI == EPI_GEGLU) {
+                                const float g0 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[0]))), g1 = Ty<TO>::rnd(gelu_tanh_f(Ty<TO>::rnd(v[2])));
+                                pk[j][i][g] = pack2(g0 * Ty<TO>::rnd(v[1]), g1 * Ty<TO>::rnd(v[3]));
+                            } else {
+                                pk[j][i][g] = pack2(silu_epi<TI>(v[0]) * v[1], silu_epi<TI>(v[2]) * v[3]);
+                            }
+                        } else {
+                            pk[j][i][g] = Pk{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                        }
+                    }
             }
+        __builtin_amdgcn_sched_barrier(0);                       // pass 1's arithmetic stays in front of the drain (it covers the look-ahead requests' landing)
+        SP_STAMP(6);
         SP_VM(0);                                                // every load in flight has landed; from here on this wave issues only LDS traffic and stores
+        SP_STAMP(7);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int blk = 0; blk < NBLK; ++blk) {
             const int i = GLU ? blk : blk >> 1, jh = GLU ? 0 : blk & 1;
             const int cl = wn * (GLU ? 64 : 128) + jh * 64 + rc * 8;          // tile-local output column of this lane's chunk
+            if constexpr (GLU) {
+                // a lane holds 2 outputs per (j, g): columns j * 16 + g * 4 + lhi * 2, + 1 -- 4-byte LDS writes, 16 per block, 4-way bank
+                // conflicts (7.3k cycles per tile against 3.7k for a plain epilogue, tools/microbench/p8_timing.hip). v_permlane32_swap trades
+                // the halves of a (g, g + 1) pair between lane l and l + 32 (same row): afterwards each lane owns FOUR consecutive outputs
+                // (lhi = 0: those of g, lhi = 1: those of g + 1) and writes 8 bytes, as the plain epilogues do.
 #pragma unroll
-            for (int j2 = 0; j2 < (GLU ? 4 : 2); ++j2)
+                for (int j2 = 0; j2 < 4; ++j2)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ocol = GLU ? (j2 * 32 + g * 8 + lhi * 4) >> 1 : j2 * 32 + g * 8 + lhi * 4;     // output column inside the block
-                    const int boff = ocol * (int)sizeof(TO);
-                    *reinterpret_cast<Pk*>(stage + srow * 128 + ((((boff >> 4) ^ (srow & 7)) << 4) | (boff & 15))) = pk[jh * 2 + j2][i][g];
-                }
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(pk[j2][i][2 * gp], pk[j2][i][2 * gp + 1], false, false);
+                        const int boff = (j2 * 16 + gp * 8 + lhi * 4) * (int)sizeof(TO);
+                        typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2s*>(stage + srow * 128 + ((((boff >> 4) ^ (srow & 7)) << 4) | (boff & 15))) = u32x2s{sw[0], sw[1]};
+                    }
+            } else {
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int boff = (j2 * 32 + g * 8 + lhi * 4) * (int)sizeof(TO);       // output column inside the block, in bytes
+                        *reinterpret_cast<Pk*>(stage + srow * 128 + ((((boff >> 4) ^ (srow & 7)) << 4) | (boff & 15))) = pk[jh * 2 + j2][i][g];
+                    }
+            }
             // read the block back as whole 16-byte chunks of contiguous rows (this wave's own LDS writes: the LDS executes a wave's
             // operations in order, no barrier)
             u32x4 raw[4];
@@ -1223,9 +1286,14 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
                 }
             }
         }
+        SP_STAMP(8);
+#if SA_P8_TIMING
+        ++dbg_tile;
+#endif
         if (!have_next) return;
         tile_m = nt_m; tile_n = nt_n;
     }
+#undef SP_STAMP
 #undef SP_PHASE
 #undef SP_VM
 #undef SP_MMA

@@ -23,7 +23,7 @@ from util import make_prompts
 pytestmark = pytest.mark.gpu
 
 GRIDS = [(6, 38), (10, 18), (8, 24), (6, 10), (12, 12), (2, 30)]
-DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=0, lmhead=1, kvprefetch=0, dattn_db=0)
+DEFAULTS = dict(graph=0, dattn=4, rnorm=2, ghead=2, fuse_embed=1, persist=1, lmhead=1, kvprefetch=0, dattn_db=0)
 
 
 def tune(**kw):

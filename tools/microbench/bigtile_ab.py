@@ -15,6 +15,7 @@ KNOB = b"bigtile"
 if len(sys.argv) > 1 and sys.argv[1] == "persist":
     KNOB, variants = b"persist", [0, 1]
 else:
+    L.check(lib.surya_set_tuning(b"persist", C.c_int(0)), "tuning")          # the bigtile variants are compared one tile per workgroup
     variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 shapes = [(46460, 6912, 1280, 3, "enc gate|up"), (46460, 3840, 1280, 0, "enc qkv"), (46460, 1280, 1280, 1, "enc proj"),
           (46460, 1280, 3456, 1, "enc down"), (15360, 10240, 1280, 3, "dec prefill gate|up"), (15360, 1280, 5120, 1, "dec prefill down"),
@@ -50,4 +51,4 @@ for M, N, K, epi, name in shapes:
     for v in variants:
         ms = sorted(times[v])[len(times[v]) // 2]
         print(f"{name:22s} M={M:6d} N={N:6d} K={K:5d} {KNOB.decode()}={v}: {ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s  (min {min(times[v])*1e3:.1f})  identical={same[v]}", flush=True)
-L.check(lib.surya_set_tuning(KNOB, C.c_int(0 if KNOB == b"persist" else 1)), "tuning")
+L.check(lib.surya_set_tuning(KNOB, C.c_int(1 if KNOB == b"persist" else 3)), "tuning")      # back to the defaults

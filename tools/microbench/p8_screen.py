@@ -58,6 +58,6 @@ for M, N, K, epi in shapes:
     print(f"M={M:6d} N={N:5d} K={K:5d} epi={epi}: {REPS} runs, mismatching elements {mism}", flush=True)
 L.check(lib.surya_set_tuning(b"bigtile_any", C.c_int(0)), "tuning")
 L.check(lib.surya_set_tuning(b"bigtile", C.c_int(3)), "tuning")
-L.check(lib.surya_set_tuning(b"persist", C.c_int(0)), "tuning")
+L.check(lib.surya_set_tuning(b"persist", C.c_int(1)), "tuning")
 print("RACE SCREEN (persistent loop)" if PERSIST else "RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} elements)")
 sys.exit(0 if bad == 0 else 1)
