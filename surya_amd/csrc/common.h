@@ -152,6 +152,23 @@ __device__ __forceinline__ float silu_epi(float x) {
     else return silu_f(x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU inside the bf16 GEMM epilogues (EPI_GELU: the Swin MLPs of the layout / table encoders, the recogniser's merger): erff is a
+// ~50-instruction piecewise polynomial, 128 of them per lane and 256 x 256 tile -- more vector-ALU time than a K = 512 tile's whole K loop
+// has matrix time. Abramowitz-Stegun 7.1.26 instead: erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), |error| <
+// 1.5e-7 absolute on erf -- three orders below a bf16 rounding step of the result; x < 0 takes 1 + erf(x) = erfc(|x|) directly (no
+// cancellation). Every bf16 tile shape uses this one function; fp32 reference mode keeps erff.
+template <typename TI>
+__device__ __forceinline__ float gelu_epi(float x) {
+    if constexpr (sizeof(TI) == 2) {
+        const float z = fabsf(x) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+        const float erfc_abs = poly * __expf(-z * z);                       // erfc(|x| / sqrt 2) in (0, 1]
+        return 0.5f * x * (x < 0.f ? erfc_abs : 2.0f - erfc_abs);
+    } else {
+        return gelu_erf_f(x);
+    }
+}
 // GELU, tanh approximation (torch gelu(approximate="tanh") / transformers gelu_pytorch_tanh)
 __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }

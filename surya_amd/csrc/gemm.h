@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
                     }
                     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_epi<TI>(v[r]);
                     } else if constexpr (EPI == EPI_HARDSWISH) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
                         v[2] += __uint_as_float(hi << 16); v[3] += __uint_as_float(hi & 0xffff0000u);
                         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_epi<TI>(v[r]);
                         } else if constexpr (EPI == EPI_HARDSWISH) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = hardswish_f(v[r]);
