@@ -1468,9 +1468,12 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         // which caps it near 64 flop/B x 15 TB/s ~ 0.95 PF/s; doubling both tile edges halves that traffic.
         const int bigtile = tuning().bigtile;
         // pick by whole rounds of resident workgroups (256 x 1 per CU vs 512 x 2 per CU, in units of 128x128 tiles of work);
-        // measured throughput ratio of the two kernels on full rounds ~1.17 (r01 microbench)
+        // measured throughput ratio of the two kernels on full rounds: ~1.17 for the 2-stage 256x256 loop (r01 microbench), ~1.4 for the
+        // persistent 8-phase loop (r05: 1.15-1.2 PF/s against 0.82-0.84 on the shapes where both can be timed). `bigtile_ratio_pct` sets it.
         const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-        const double cost256 = (double)cdivl(t256, 256) * 256 * 4 / 1.17, cost128 = (double)cdivl(big, 512) * 512;
+        const double ratio256 = tuning().bigtile_ratio_pct > 0 ? tuning().bigtile_ratio_pct / 100.0
+                                                                : ((bigtile == 3 && sizeof(TI) == 2) ? 1.4 : 1.17);
+        const double cost256 = (double)cdivl(t256, 256) * 256 * 4 / ratio256, cost128 = (double)cdivl(big, 512) * 512;
         // (r03: 256 x 128 tiles with a 3-stage ring -- 144 KB, deeper prefetch, 1.37x the L2 bytes per flop -- lost 5-15 % on every
         // encoder / prefill shape and on 8k^3 (1212 -> 1026 TF/s, profiles/r03_sweeps.txt): the big-tile loop is bound by L2 -> LDS bytes
         // per flop, not by prefetch depth.)
