@@ -905,16 +905,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 // __syncthreads, nothing of the next tile in flight) and the drain of its stores before the CU takes the next workgroup. Here ONE
 // workgroup per CU walks the XCD-swizzled tile order and never leaves the K-loop's schedule:
 //   * the half-tile ring runs on ACROSS tiles: the last six phases of a tile request the first six half-tiles of the next tile
-//     (same slots, same distances, same counted waits), the last phase reads the next tile's first X fragments;
+//     (same slots, same distances, same counted waits);
 //   * the epilogue is wave-private: each wave stages its 64 x 128 results block by block (32 rows x 64 columns = 4 KiB) through its
-//     own 4 KiB of the 32 KiB of LDS the ring leaves free, so it needs no workgroup barrier and no operand slot, and the two wave
-//     groups keep their one-barrier stagger through it;
+//     own 4 KiB of the 32 KiB of LDS the ring leaves free, so it needs no workgroup barrier and no operand slot. The two wave groups
+//     are re-ALIGNED behind a tile's last phase and staggered again at the top of the next tile: carried through the epilogue, the
+//     stagger made each group wait at a barrier for the other group's whole epilogue (tools/microbench/p8_timing.hip);
 //   * vmcnt counts stores as well as loads: every load in flight is retired (one vmcnt(0)) before a wave's first store, the first four
 //     phases of the next tile run without a counted wait (everything they need was requested before the stores and has been retired),
 //     and the counted waits resume at phase 4 -- about 1 us after the last store was issued;
 //   * the accumulators restart from the MFMA's zero C operand in the first K-tile (no 128-register clear);
-//   * the bias slice of a wave (128 columns) rides in ONE register per lane, fetched at the top of the tile, and reaches the lanes that
-//     need it through ds_bpermute (no LDS bytes, no load behind the request stream at epilogue time).
+//   * the bias slice of a wave (128 columns) is ONE register per lane, requested in the tile's last phase, and reaches the lanes that
+//     need it through ds_bpermute (no LDS bytes).
+// Everything that is a function of the lane id alone (request offsets, fragment offsets, epilogue addresses) is recomputed where it is
+// needed from a fresh v_mbcnt: kept live across the tile loop beside 128 accumulators it is spilled, and a scratch reload waits vmcnt(0).
 // K order, MFMA, accumulator assignment and every epilogue formula are the one-tile kernel's: bit-identical (tests/test_gpu_round4.py).
 // Requires an even K-tile count >= 4 and a 2-byte output type.
 template <typename TI, typename TO, int EPI>

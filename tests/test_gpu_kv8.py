@@ -224,8 +224,12 @@ def test_kv8_switch_restores_bf16_results_and_combines_with_fp8_weights(hip_lib)
     tiles, seqs = make_prompts(cfg, GRIDS)
     slots = list(range(len(seqs)))
 
+    first = []                                                      # the token each run's PREFILL picks (before any decode step)
+
     def run():
         m.prefill(tiles.cuda(), GRIDS, seqs, slots)
+        t0, _, _ = m.read_outputs(1)
+        first.append(t0[0][: len(slots)].copy())
         m.set_active(slots)
         m.decode(6)
         t, s, b = m.read_outputs(6)
@@ -243,8 +247,10 @@ def test_kv8_switch_restores_bf16_results_and_combines_with_fp8_weights(hip_lib)
     assert not np.array_equal(a[1], f[1]) and not np.array_equal(f[1], both[1])
     for r in (f, both):
         assert np.isfinite(r[1]).all() and (r[0] >= 0).all() and (r[0] < cfg.decoder.vocab_size).all()
-    # the first decoded token comes from the prefill logits (bf16 cache in every mode)
-    assert np.array_equal(a[0][0], f[0][0])
+    # the token the prefill picks comes from the prefill logits (bf16 cache in every mode): identical in all four runs. (Round 4 asserted
+    # this on the first DECODE step's token, which already attends over the fp8 rows of the prompt -- equal only while no slot sits on a
+    # near-tie; round 5's cheaper SiLU moved slot 1 onto one.)
+    assert all(np.array_equal(first[0], x) for x in first[1:])
 
 
 def test_scheduler_with_slot_reuse_on_the_fp8_cache(hip_lib):
