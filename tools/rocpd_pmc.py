@@ -32,6 +32,8 @@ def short(name):
 
 def bucket(name):
     """bench.py's profiler buckets (gemm_cfg_id in surya_amd/csrc/gemm.h) from the mangled kernel name."""
+    if "gemm_nt_p8p_kernel" in name or "gemm_nt_persist_kernel" in name:        # the persistent 256x256 loops (round 5 / round 4)
+        return "gemm_nt 128x128 / 256x256 / 256x320 (encoder + prefill GEMMs, lm_head)"
     m = re.search(r"gemm_nt_kernelI..Li(\d+)ELi(\d+)E", name)
     if m:
         bm, bn = int(m.group(1)), int(m.group(2))
