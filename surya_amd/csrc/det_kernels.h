@@ -302,8 +302,21 @@ static inline int launch_conv_on_gemm(const ConvArgs<T>& a, hipStream_t s) {
     g.cH = a.H; g.cW = a.W; g.cCin = a.Cin; g.cHo = a.Ho; g.cWo = a.Wo; g.cKW = a.KW; g.cStride = a.stride; g.cPad = a.pad;
     g.cTaps = a.KH * a.KW;
     g.conv_lean = tuning().conv_lean;
-    if (tuning().bigtile && a.Kpad >= tuning().bigtile_min_k && a.Cout >= 256 && cdivl(M, 256) * cdiv(a.Cout, 256) >= 256)
+    g.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo)); g.fd_wo = make_fastdiv((unsigned)a.Wo);
+    g.cv_m1 = (65536u + (unsigned)(a.Cin / 64) - 1) / (unsigned)std::max(1, a.Cin / 64); g.cv_m2 = (65536u + (unsigned)a.KW - 1) / (unsigned)a.KW;
+    g.cv_rowskip = (a.W - a.KW) * a.Cin * (int)sizeof(T);
+    if (tuning().bigtile && a.Kpad >= tuning().bigtile_min_k && a.Cout >= 256 && cdivl(M, 256) * cdiv(a.Cout, 256) >= 256) {
+        // round 5: the persistent 8-phase loop with the gather in its request stream, for K-tiles aligned with filter taps (an odd K-tile count
+        // gets a virtual K-tile of zeros). The one-tile 2-stage kernel spent 15 % of a K = 576 tile in its set-up, 24 % in its epilogue and
+        // 4.0k cycles per K-tile in its drain-per-tile loop (tools/microbench/p8_timing.hip).
+        if constexpr (sizeof(T) == 2) {
+            const int nkc = a.Kpad / 64;
+            if (tuning().persist && tuning().conv_persist && a.Cin % 64 == 0 && a.Cin <= 1024 && a.KH <= 7 && a.KW <= 7 && nkc < 4096 && nkc + (nkc & 1) >= 4 && a.Cout % 8 == 0 &&
+                (long)a.B * a.H * a.W * a.Cin * (long)sizeof(T) < (1L << 31) - (1L << 24))
+                return launch_gemm_persist<T, T, EPI, true>(g, s);
+        }
         return launch_gemm_cfg<T, T, 256, 256, 4, 2, EPI, false, 2, true>(g, s);
+    }
     if (a.Cout >= 128) return launch_gemm_cfg<T, T, 128, 128, 2, 2, EPI, false, 2, true>(g, s);
     if (a.Cout >= 64) return launch_gemm_cfg<T, T, 128, 64, 4, 1, EPI, false, 2, true>(g, s);
     return launch_gemm_cfg<T, T, 128, 32, 4, 1, EPI, false, 2, true>(g, s);

@@ -36,6 +36,25 @@ namespace sa {
 enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6, EPI_ROPE = 7,
                EPI_GEGLU = 8 /* gelu_tanh(gate) * up, rows interleaved like SWIGLU (ADETR decoder MLP, adetr/decoder.py:331-344) */ };
 
+// x / d for 32-bit unsigned x without a division instruction sequence (an integer division is ~40 VALU instructions on this ISA): d a
+// power of two -> shift; otherwise the 33-bit round-up magic m = floor(2^(33 + k) / d) + 1, k = floor(log2 d), whose top bit is implicit:
+// q = mulhi(x, m), x / d = (((x - q) >> 1) + q) >> k -- exact for every 32-bit x (checked against // for d up to 2^31 in Python).
+struct FastDiv { unsigned m = 0, s = 0; };
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    if (d == 0) d = 1;
+    unsigned k = 31 - (unsigned)__builtin_clz(d);
+    if ((d & (d - 1)) == 0) { f.m = 0; f.s = k; return f; }
+    f.m = (unsigned)((((unsigned __int128)1 << (33 + k)) / d + 1) & 0xffffffffu);
+    f.s = k;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned x, FastDiv f) {
+    if (f.m == 0) return x >> f.s;
+    const unsigned q = __umulhi(x, f.m);
+    return (((x - q) >> 1) + q) >> f.s;
+}
+
 template <typename TI, typename TO>
 struct GemmArgs {
     const TI* X; long ldx;       // [M, K]
@@ -66,6 +85,13 @@ struct GemmArgs {
     const TI* conv_zero = nullptr;
     int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKW = 0, cStride = 0, cPad = 0, cTaps = 0;
     int conv_lean = 1;           // 1: per-(row, tap) gather state precomputed once per workgroup when K-tiles align with taps (0 = round-4 gather, for A/B)
+    FastDiv fd_hw, fd_wo;        // CONV on the persistent loop: per-row divisors cHo * cWo and cWo (set by the launcher)
+    // ... and its wave-uniform tap math, per request and therefore on the K loop's critical path: K-tile kt covers channels of tap
+    // kt / (cCin / 64) = (kt * cv_m1) >> 16, filter row tap / cKW = (tap * cv_m2) >> 16 (cv_m = ceil(2^16 / d): exact for kt < 4096 and
+    // d <= 16, tools checked in Python); the K-tile's byte offset from the row's first tap is kt * 128 + ky * cv_rowskip (a filter row's
+    // cKW * cCin channels are contiguous in NHWC; cv_rowskip = (cW - cKW) * cCin * sizeof(TI) steps to the next image row)
+    unsigned cv_m1 = 0, cv_m2 = 0;
+    int cv_rowskip = 0;
 #ifndef SA_P8_TIMING
 #define SA_P8_TIMING 0                // tools/microbench/p8_timing.hip: s_memtime stamps of the persistent 8-phase loop's segments into `dbg`
 #endif
@@ -153,6 +179,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         tile_n = sc * p.swz_n + rem2 % w;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+#if SA_P8_TIMING
+#define SA_STAMP1(IDX) { if (p.dbg && tid == 0) p.dbg[(long)blockIdx.x * 4 + (IDX)] = (long long)__builtin_readcyclecounter(); }
+#else
+#define SA_STAMP1(IDX) {}
+#endif
+    SA_STAMP1(0);
     const int nk_all = p.K / KE;
     const int kt_begin = SPLIT ? (int)((long)ks * nk_all / p.splitk) : 0;
     const int kt_end = SPLIT ? (int)((long)(ks + 1) * nk_all / p.splitk) : nk_all;
@@ -501,6 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             // (The refill after the last tile is skipped: round 2 re-fetched the last K-tile there, clamped, "so the loads in flight
             // stay constant" -- a rule of the register-staged loop below that this loop, with its explicit vmcnt(0), never needed;
             // it cost every workgroup one more K-tile of L2 traffic and the wait for it, ~0.8 us of a 20-step decode gate|up launch.)
+            SA_STAMP1(1);
             SA_ISSUE(0, 0);
             SA_LANDED();
             for (int pi = 0; pi < pairs; ++pi) {
@@ -622,6 +655,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 #undef SA_STASH
     }
 
+    SA_STAMP1(2);
     // Epilogue through LDS. 32x32 result D[n][m]: a lane owns row m = .. + (lane & 31) and, per register group g, four
     // consecutive columns -- written straight to HBM that is 64 scattered 8-byte pieces per store instruction (the
     // N = 1280 residual GEMMs ran at 400 TF/s on it). Instead the tile is staged in the (now idle) staging LDS with bias /
@@ -896,6 +930,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
             }
         }
     }
+    SA_STAMP1(3);
+#undef SA_STAMP1
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -920,7 +956,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 // needed from a fresh v_mbcnt: kept live across the tile loop beside 128 accumulators it is spilled, and a scratch reload waits vmcnt(0).
 // K order, MFMA, accumulator assignment and every epilogue formula are the one-tile kernel's: bit-identical (tests/test_gpu_round4.py).
 // Requires an even K-tile count >= 4 and a 2-byte output type.
-template <typename TI, typename TO, int EPI>
+template <typename TI, typename TO, int EPI, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     constexpr int BM = 256, BN = 256, GRP = 32, KE = Ty<TI>::KE, HT = 16384;
     static_assert(sizeof(TI) == 2 && sizeof(TO) == 2 && EPI != EPI_ARGMAX, "persistent 8-phase loop: bf16 operands, 2-byte outputs");
@@ -931,7 +967,10 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, total = tiles_m * tiles_n;
     const int padded = ((total + 8 * GRP - 1) / (8 * GRP)) * (8 * GRP);
-    const int nk = p.K / KE, pairs = nk >> 1;
+    // CONV (implicit-GEMM convolution, K-tiles aligned with filter taps: Cin % 64 == 0): an odd K-tile count gets one VIRTUAL K-tile of
+    // zeros behind the last (its X requests fall past the last tap and take the zero page like any padded tap, its W requests take the
+    // zero page too): + 0 * 0 leaves every accumulator bit unchanged and the phase structure stays two K-tiles per round.
+    const int nk_real = p.K / KE, nk = CONV ? nk_real + (nk_real & 1) : nk_real, pairs = nk >> 1;
 
     // virtual block id -> output tile (the one-tile kernel's XCD-aware super-tile order)
     auto map_tile = [&](int vb, int& tile_m, int& tile_n) -> bool {
@@ -986,6 +1025,62 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
                 wq[hh][i] = (unsigned)(min(wr_, p.N - 1 - n0) * (int)(p.ldw * sizeof(TI)) + c * 16);
             }
     };
+    // CONV request state per (half, instruction): signed byte offset of the window's top-left pixel (+ the lane's channel chunk) from conv_in,
+    // and one validity bit per filter tap (the launcher guarantees the tensor spans < 2 GiB and <= 32 taps)
+    [[maybe_unused]] int cb[2][2];
+    [[maybe_unused]] unsigned cm[2][2];
+    [[maybe_unused]] auto set_conv = [&](int tile_m, int hh) {
+        // cm: bit ky = filter row ky lies inside the image for this output pixel, bit 16 + kx = filter column kx does (closed form, no tap
+        // loop; no division instruction sequences: this runs once per tile inside a phase's load segment, and the first version -- `/` and
+        // `%` per tap and per row -- cost thousands of cycles per tile, tools/microbench/p8_timing.hip)
+        const int lane = fresh_lane();
+        const int hw = p.cHo * p.cWo, KH = p.cTaps / p.cKW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (wv * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((lr >> 1) & 7);
+            const int xr = (lr >> 5) * 64 + hh * 32 + (lr & 31);
+            const unsigned m = (unsigned)min(tile_m * BM + xr, p.M - 1);
+            const unsigned bi = fast_div(m, p.fd_hw), r = m - bi * (unsigned)hw, oy = fast_div(r, p.fd_wo), ox = r - oy * (unsigned)p.cWo;
+            const int iy0 = (int)oy * p.cStride - p.cPad, ix0 = (int)ox * p.cStride - p.cPad;
+            cb[hh][i] = ((((int)bi * p.cH + iy0) * p.cW + ix0) * p.cCin) * (int)sizeof(TI) + c * 16;
+            const int rlo = max(0, -iy0), rhi = max(rlo, min(KH, p.cH - iy0)), clo = max(0, -ix0), chi = max(clo, min(p.cKW, p.cW - ix0));
+            cm[hh][i] = ((1u << rhi) - (1u << rlo)) | (((1u << chi) - (1u << clo)) << 16);
+        }
+    };
+    // X request of half HH for K-tile KT: plain rows, or the convolution gather (tap of the K-tile: scalar; ~8 VALU per request)
+#define SP_REQX(HH, SLOT, KT)                                                                                     \
+    {                                                                                                             \
+        if constexpr (CONV) {                                                                                     \
+            const unsigned tap_ = ((unsigned)(KT) * p.cv_m1) >> 16, ky_ = (tap_ * p.cv_m2) >> 16, kx_ = tap_ - ky_ * (unsigned)p.cKW;   /* scalar */ \
+            const int toff_ = (KT) * 128 + (int)ky_ * p.cv_rowskip;                                               \
+            const unsigned bit_ = (1u << ky_) | (0x10000u << kx_);    /* the virtual K-tile: ky = KH, no such row bit */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
+                int c_ = cb[HH][i_];                                                                              \
+                asm volatile("" : "+v"(c_));          /* the 64-bit address is formed HERE, not hoisted as a register pair per request */ \
+                const unsigned char* src_ = ((cm[HH][i_] & bit_) == bit_) ? reinterpret_cast<const unsigned char*>(p.conv_in) + (long)(c_ + toff_) \
+                                                                : reinterpret_cast<const unsigned char*>(p.conv_zero); \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            SP_REQ(xbase, xq[HH], SLOT, KT);                                                                      \
+        }                                                                                                         \
+    }
+    // W request: the virtual K-tile of an odd CONV K-tile count reads the zero page
+#define SP_REQW(HH, SLOT, KT)                                                                                     \
+    {                                                                                                             \
+        if constexpr (CONV) {                                                                                     \
+            const bool real_ = (KT) < nk_real;                                                                    \
+            const unsigned char* b_ = real_ ? wbase + (long)(KT) * 128 : reinterpret_cast<const unsigned char*>(p.conv_zero); \
+            asm volatile("" : "+s"(b_));                                                                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
+                unsigned o_ = real_ ? wq[HH][i_] : 0u;                                                            \
+                asm volatile("" : "+v"(o_));                                                                      \
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_ + o_), (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            SP_REQ(wbase, wq[HH], SLOT, KT);                                                                      \
+        }                                                                                                         \
+    }
 #define SP_REQ(BASE, OFFS, SLOT, KT)                                                                              \
     {                                                                                                             \
         const unsigned char* b_ = (BASE) + (long)(KT) * 128;                                                      \
@@ -1011,12 +1106,15 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     };
     u32x4 xa[4], xb[4], wf[2][4];
     f32x16 acc[4][2];
-#define SP_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : xl1[kk_]) + ((SLOT) & 3) * HT); }
+    // (CONV: its request state takes eight registers more than the plain rows' and the loop has none to spare -- the second buffer's address set
+    // is not kept but formed where it is used: one v_add per fragment read of an odd K-tile, opaque so that hipcc does not hoist it back)
+    auto far = [](int a_) -> int { int r_ = a_ + 4 * 16384; asm volatile("" : "+v"(r_)); return r_; };
+#define SP_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : (CONV ? far(xl0[kk_]) : xl1[kk_])) + ((SLOT) & 3) * HT); }
 #define SP_RW(SLOT)                                                                                               \
     {                                                                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
             _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                   \
-                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : wl1[kk_]) + ((SLOT) & 3) * HT + j_ * 4096); \
+                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : (CONV ? far(wl0[kk_]) : wl1[kk_])) + ((SLOT) & 3) * HT + j_ * 4096); \
     }
     // ZERO: the quadrant's first MFMAs of the tile take the constant-zero C operand (0 * anything + 0: same bits as a cleared register)
 #define SP_MMA(XR, JH, I, ZERO)                                                                                   \
@@ -1065,8 +1163,9 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     int tile_m = 0, tile_n = 0;
     if (!next_tile(tile_m, tile_n)) return;
     set_req(tile_m, tile_n);
-    SP_REQ(xbase, xq[0], 0, 0); SP_REQ(wbase, wq[0], 1, 0); SP_REQ(xbase, xq[1], 2, 0); SP_REQ(wbase, wq[1], 3, 0);
-    SP_REQ(xbase, xq[0], 4, 1); SP_REQ(wbase, wq[0], 5, 1);
+    if constexpr (CONV) { set_conv(tile_m, 0); set_conv(tile_m, 1); }
+    SP_REQX(0, 0, 0); SP_REQW(0, 1, 0); SP_REQX(1, 2, 0); SP_REQW(1, 3, 0);
+    SP_REQX(0, 4, 1); SP_REQW(0, 5, 1);
     SP_VM(0);                                                    // the first pair's early phases run without counted waits (below)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1077,6 +1176,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         const bool have_next = next_tile(nt_m, nt_n);
         set_req(tile_m, tile_n);                                 // (again, although the previous tile's tail already set them for its six look-ahead requests:
         set_read();                                              //  recomputed, the offsets are not live across the epilogue -- which needs the registers)
+        if constexpr (CONV) { set_conv(tile_m, 0); set_conv(tile_m, 1); }
         // The second wave of every SIMD runs one barrier behind the first -- INSIDE a tile's K loop only. The two groups are re-aligned
         // behind the last phase (below) and staggered again here: with the stagger carried through the epilogue, the trailing group waited
         // at its last barrier for the leading group's whole epilogue and the leading group then waited in phase 0 for the trailing group's
@@ -1086,28 +1186,28 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         SP_STAMP(0);
         {   // first two K-tiles of the tile: everything phases 0..3 read was requested before the previous tile's stores and retired
             // by the vmcnt(0) in front of them (or by the prologue's) -- no counted wait until phase 4
-            SP_PHASE({ SP_RX(xa, 0); SP_RW(1); }, SP_REQ(xbase, xq[1], 6, 1), -1, xa, 0, 0, true);       // X0(0) is read HERE, not in the previous tile's last phase: 16 registers less across the epilogue
-            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, 1), -1, xb, 0, 1, true);
-            SP_PHASE(SP_RW(3),     SP_REQ(xbase, xq[0], 0, 2), -1, xb, 1, 1, true);
-            SP_PHASE(SP_RX(xb, 4), SP_REQ(wbase, wq[0], 1, 2), -1, xa, 1, 0, true);
+            SP_PHASE({ SP_RX(xa, 0); SP_RW(1); }, SP_REQX(1, 6, 1), -1, xa, 0, 0, true);       // X0(0) is read HERE, not in the previous tile's last phase: 16 registers less across the epilogue
+            SP_PHASE(SP_RX(xb, 2), SP_REQW(1, 7, 1), -1, xb, 0, 1, true);
+            SP_PHASE(SP_RW(3),     SP_REQX(0, 0, 2), -1, xb, 1, 1, true);
+            SP_PHASE(SP_RX(xb, 4), SP_REQW(0, 1, 2), -1, xa, 1, 0, true);
             SP_STAMP(1);
-            SP_PHASE(SP_RW(5),     SP_REQ(xbase, xq[1], 2, 2),  8, xb, 0, 0, false);
+            SP_PHASE(SP_RW(5),     SP_REQX(1, 2, 2),  8, xb, 0, 0, false);
             SP_STAMP(2);
-            SP_PHASE(SP_RX(xa, 6), SP_REQ(wbase, wq[1], 3, 2),  8, xa, 0, 1, false);
-            SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, 3),  8, xa, 1, 1, false);
-            SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, 3),  8, xb, 1, 0, false);
+            SP_PHASE(SP_RX(xa, 6), SP_REQW(1, 3, 2),  8, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     SP_REQX(0, 4, 3),  8, xa, 1, 1, false);
+            SP_PHASE(SP_RX(xa, 0), SP_REQW(0, 5, 3),  8, xb, 1, 0, false);
         }
         SP_STAMP(3);
         for (int pi = 1; pi < pairs - 1; ++pi) {
             const int t = 2 * pi;
-            SP_PHASE(SP_RW(1),     SP_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0, false);
-            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1, false);
-            SP_PHASE(SP_RW(3),     SP_REQ(xbase, xq[0], 0, t + 2), 8, xb, 1, 1, false);
-            SP_PHASE(SP_RX(xb, 4), SP_REQ(wbase, wq[0], 1, t + 2), 8, xa, 1, 0, false);
-            SP_PHASE(SP_RW(5),     SP_REQ(xbase, xq[1], 2, t + 2), 8, xb, 0, 0, false);
-            SP_PHASE(SP_RX(xa, 6), SP_REQ(wbase, wq[1], 3, t + 2), 8, xa, 0, 1, false);
-            SP_PHASE(SP_RW(7),     SP_REQ(xbase, xq[0], 4, t + 3), 8, xa, 1, 1, false);
-            SP_PHASE(SP_RX(xa, 0), SP_REQ(wbase, wq[0], 5, t + 3), 8, xb, 1, 0, false);
+            SP_PHASE(SP_RW(1),     SP_REQX(1, 6, t + 1), 8, xa, 0, 0, false);
+            SP_PHASE(SP_RX(xb, 2), SP_REQW(1, 7, t + 1), 8, xb, 0, 1, false);
+            SP_PHASE(SP_RW(3),     SP_REQX(0, 0, t + 2), 8, xb, 1, 1, false);
+            SP_PHASE(SP_RX(xb, 4), SP_REQW(0, 1, t + 2), 8, xa, 1, 0, false);
+            SP_PHASE(SP_RW(5),     SP_REQX(1, 2, t + 2), 8, xb, 0, 0, false);
+            SP_PHASE(SP_RX(xa, 6), SP_REQW(1, 3, t + 2), 8, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     SP_REQX(0, 4, t + 3), 8, xa, 1, 1, false);
+            SP_PHASE(SP_RX(xa, 0), SP_REQW(0, 5, t + 3), 8, xb, 1, 0, false);
         }
         SP_STAMP(4);
         unsigned bpack_raw = 0, bias_mask = 0;
@@ -1116,14 +1216,18 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             // W1(nk - 1) and the counted waits shrink with what is still in flight. ONE code path (the branches are wave-uniform and
             // enclose requests and waits only): two copies of the phases, each redefining all accumulators, made hipcc spill them.
             const int t = nk - 2;
-            SP_PHASE(SP_RW(1),     SP_REQ(xbase, xq[1], 6, t + 1), 8, xa, 0, 0, false);
-            SP_PHASE(SP_RX(xb, 2), SP_REQ(wbase, wq[1], 7, t + 1), 8, xb, 0, 1, false);
+            SP_PHASE(SP_RW(1),     SP_REQX(1, 6, t + 1), 8, xa, 0, 0, false);
+            SP_PHASE(SP_RX(xb, 2), SP_REQW(1, 7, t + 1), 8, xb, 0, 1, false);
+            SP_STAMP(9);
             if (have_next) set_req(nt_m, nt_n);
-            SP_PHASE(SP_RW(3),     { if (have_next) { SP_REQ(xbase, xq[0], 0, 0); SP_VM(8); } else { SP_VM(6); } }, -1, xb, 1, 1, false);
-            SP_PHASE(SP_RX(xb, 4), { if (have_next) { SP_REQ(wbase, wq[0], 1, 0); SP_VM(8); } else { SP_VM(4); } }, -1, xa, 1, 0, false);
-            SP_PHASE(SP_RW(5),     { if (have_next) { SP_REQ(xbase, xq[1], 2, 0); SP_VM(8); } else { SP_VM(2); } }, -1, xb, 0, 0, false);
-            SP_PHASE(SP_RX(xa, 6), { if (have_next) { SP_REQ(wbase, wq[1], 3, 0); SP_VM(8); } else { SP_VM(0); } }, -1, xa, 0, 1, false);
-            SP_PHASE(SP_RW(7),     { if (have_next) { SP_REQ(xbase, xq[0], 4, 1); SP_VM(8); } },                    -1, xa, 1, 1, false);
+            if constexpr (CONV) { if (have_next) { set_conv(nt_m, 0); set_conv(nt_m, 1); } }
+            SP_STAMP(10);
+            SP_PHASE(SP_RW(3),     { if (have_next) { SP_REQX(0, 0, 0); SP_VM(8); } else { SP_VM(6); } }, -1, xb, 1, 1, false);
+            SP_STAMP(11);
+            SP_PHASE(SP_RX(xb, 4), { if (have_next) { SP_REQW(0, 1, 0); SP_VM(8); } else { SP_VM(4); } }, -1, xa, 1, 0, false);
+            SP_PHASE(SP_RW(5),     { if (have_next) { SP_REQX(1, 2, 0); SP_VM(8); } else { SP_VM(2); } }, -1, xb, 0, 0, false);
+            SP_PHASE(SP_RX(xa, 6), { if (have_next) { SP_REQW(1, 3, 0); SP_VM(8); } else { SP_VM(0); } }, -1, xa, 0, 1, false);
+            SP_PHASE(SP_RW(7),     { if (have_next) { SP_REQX(0, 4, 1); SP_VM(8); } },                    -1, xa, 1, 1, false);
             // this wave's bias slice: lane l holds columns wn * 128 + 2 l, + 1 (packed bf16 pair). Requested in the tile's LAST phase: one
             // register for one phase (at the top of the tile it lived through the whole K loop and the RoPE instantiation spilled it behind
             // a vmcnt(0) -- at the top of a tile that waits for the previous tile's stores); one more op in the request stream, older than
@@ -1134,7 +1238,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             const TI* bias_p = p.bias ? p.bias : p.W;
             bias_mask = p.bias ? 0xffffffffu : 0u;
             bpack_raw = *reinterpret_cast<const unsigned*>(bias_p + min(n0 + wn * 128 + 2 * fresh_lane(), p.N - 2));
-            SP_PHASE({},           { if (have_next) { SP_REQ(wbase, wq[0], 5, 1); SP_VM(8); } },                    -1, xb, 1, 0, false);
+            SP_PHASE({},           { if (have_next) { SP_REQW(0, 5, 1); SP_VM(8); } },                    -1, xb, 1, 0, false);
             if (wv < 4) __builtin_amdgcn_s_barrier();             // the leading half meets the trailing half's last barrier: both enter the epilogue together
         }
 
@@ -1302,6 +1406,8 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
 #undef SP_MMA
 #undef SP_RW
 #undef SP_RX
+#undef SP_REQX
+#undef SP_REQW
 #undef SP_REQ
 }
 #undef SA_COMPUTE
@@ -1376,7 +1482,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
 }
 
 // Launch of the persistent 8-phase tile loop: one workgroup per CU (160 KB of LDS each), XCD-aware super-tiles as in launch_gemm_cfg.
-template <typename TI, typename TO, int EPI>
+template <typename TI, typename TO, int EPI, bool CONV = false>
 static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr int BM = 256, BN = 256, GRP = 32;
     const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
@@ -1394,7 +1500,7 @@ static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) 
     }
     const int grid = std::min(padded, n_cu);
     constexpr size_t lds = (size_t)2 * (BM + BN) * 128 + 8 * 4096;      // the half-tile ring + 4 KiB of epilogue staging per wave
-    auto kern = gemm_nt_p8p_kernel<TI, TO, EPI>;
+    auto kern = gemm_nt_p8p_kernel<TI, TO, EPI, CONV>;
     static AttrOnce attr;
     attr.ensure(kern, lds);
     GemmProfiler& pf = gemm_profiler();
@@ -1403,8 +1509,8 @@ static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, aa);
     if (prof) {
         (void)hipEventRecord(pf.ev[2 * pf.n + 1], s);
-        pf.cfg_of[pf.n] = gemm_cfg_id(BM, BN);
-        pf.flops_of[pf.n] = 2.0 * a.M * a.N * a.K;
+        pf.cfg_of[pf.n] = CONV ? 3 : gemm_cfg_id(BM, BN);       // bucket 3 = implicit-GEMM convolutions
+        pf.flops_of[pf.n] = CONV ? 2.0 * a.M * a.N * a.cTaps * a.cCin : 2.0 * a.M * a.N * a.K;
         const double outn = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : a.N;
         pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
                             (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
