@@ -1029,14 +1029,13 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     // and one validity bit per filter tap (the launcher guarantees the tensor spans < 2 GiB and <= 32 taps)
     [[maybe_unused]] int cb[2][2];
     [[maybe_unused]] unsigned cm[2][2];
-    [[maybe_unused]] auto set_conv = [&](int tile_m, int hh) {
+    [[maybe_unused]] auto set_conv = [&](int tile_m, int hh, int i) {
         // cm: bit ky = filter row ky lies inside the image for this output pixel, bit 16 + kx = filter column kx does (closed form, no tap
         // loop; no division instruction sequences: this runs once per tile inside a phase's load segment, and the first version -- `/` and
         // `%` per tap and per row -- cost thousands of cycles per tile, tools/microbench/p8_timing.hip)
         const int lane = fresh_lane();
         const int hw = p.cHo * p.cWo, KH = p.cTaps / p.cKW;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        {
             const int lr = (wv * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((lr >> 1) & 7);
             const int xr = (lr >> 5) * 64 + hh * 32 + (lr & 31);
             const unsigned m = (unsigned)min(tile_m * BM + xr, p.M - 1);
@@ -1102,19 +1101,19 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             wl0[kk] = wn * 64 * 128 + fo;
             xl1[kk] = xl0[kk] + 4 * HT;
             wl1[kk] = wl0[kk] + 4 * HT;
+            // (CONV has eight registers of gather state more: keep hipcc from folding slot offsets past the 16-bit immediate into further
+            // address registers -- it spilled one, and its reload is a vmcnt(0) in the tile's tail)
+            if constexpr (CONV) asm volatile("" : "+v"(xl0[kk]), "+v"(wl0[kk]), "+v"(xl1[kk]), "+v"(wl1[kk]));
         }
     };
     u32x4 xa[4], xb[4], wf[2][4];
     f32x16 acc[4][2];
-    // (CONV: its request state takes eight registers more than the plain rows' and the loop has none to spare -- the second buffer's address set
-    // is not kept but formed where it is used: one v_add per fragment read of an odd K-tile, opaque so that hipcc does not hoist it back)
-    auto far = [](int a_) -> int { int r_ = a_ + 4 * 16384; asm volatile("" : "+v"(r_)); return r_; };
-#define SP_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : (CONV ? far(xl0[kk_]) : xl1[kk_])) + ((SLOT) & 3) * HT); }
+#define SP_RX(XR, SLOT) { _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) XR[kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? xl0[kk_] : xl1[kk_]) + ((SLOT) & 3) * HT); }
 #define SP_RW(SLOT)                                                                                               \
     {                                                                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
             _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                   \
-                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : (CONV ? far(wl0[kk_]) : wl1[kk_])) + ((SLOT) & 3) * HT + j_ * 4096); \
+                wf[j_][kk_] = *reinterpret_cast<const u32x4*>(smem + ((SLOT) < 4 ? wl0[kk_] : wl1[kk_]) + ((SLOT) & 3) * HT + j_ * 4096); \
     }
     // ZERO: the quadrant's first MFMAs of the tile take the constant-zero C operand (0 * anything + 0: same bits as a cleared register)
 #define SP_MMA(XR, JH, I, ZERO)                                                                                   \
@@ -1163,7 +1162,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     int tile_m = 0, tile_n = 0;
     if (!next_tile(tile_m, tile_n)) return;
     set_req(tile_m, tile_n);
-    if constexpr (CONV) { set_conv(tile_m, 0); set_conv(tile_m, 1); }
+    if constexpr (CONV) { set_conv(tile_m, 0, 0); set_conv(tile_m, 0, 1); set_conv(tile_m, 1, 0); set_conv(tile_m, 1, 1); }
     SP_REQX(0, 0, 0); SP_REQW(0, 1, 0); SP_REQX(1, 2, 0); SP_REQW(1, 3, 0);
     SP_REQX(0, 4, 1); SP_REQW(0, 5, 1);
     SP_VM(0);                                                    // the first pair's early phases run without counted waits (below)
@@ -1176,7 +1175,9 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
         const bool have_next = next_tile(nt_m, nt_n);
         set_req(tile_m, tile_n);                                 // (again, although the previous tile's tail already set them for its six look-ahead requests:
         set_read();                                              //  recomputed, the offsets are not live across the epilogue -- which needs the registers)
-        if constexpr (CONV) { set_conv(tile_m, 0); set_conv(tile_m, 1); }
+        // (CONV: the gather state of this tile was set by the previous tile's tail -- or the prologue -- and stays live across the epilogue;
+        // the residual epilogue has no eight registers for that -- 20 bytes of scratch -- and recomputes it)
+        if constexpr (CONV && EPI == EPI_RESIDUAL) { set_conv(tile_m, 0, 0); set_conv(tile_m, 0, 1); set_conv(tile_m, 1, 0); set_conv(tile_m, 1, 1); }
         // The second wave of every SIMD runs one barrier behind the first -- INSIDE a tile's K loop only. The two groups are re-aligned
         // behind the last phase (below) and staggered again here: with the stagger carried through the epilogue, the trailing group waited
         // at its last barrier for the leading group's whole epilogue and the leading group then waited in phase 0 for the trailing group's
@@ -1216,14 +1217,20 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             // W1(nk - 1) and the counted waits shrink with what is still in flight. ONE code path (the branches are wave-uniform and
             // enclose requests and waits only): two copies of the phases, each redefining all accumulators, made hipcc spill them.
             const int t = nk - 2;
+            // CONV: the next tile's gather state, a quarter per phase (one (half, load) pair is ~350 cycles of address arithmetic -- about one
+            // phase's MFMA time -- and the whole of it in one load segment stood exposed). X0's was free since the last middle phase, X1's is
+            // after this tile's last X request (phase 0); the next tile's X0 / X1 requests are in phases 2 / 4.
+            if constexpr (CONV) { if (have_next) set_conv(nt_m, 0, 0); }
             SP_PHASE(SP_RW(1),     SP_REQX(1, 6, t + 1), 8, xa, 0, 0, false);
+            if constexpr (CONV) { if (have_next) set_conv(nt_m, 0, 1); }
             SP_PHASE(SP_RX(xb, 2), SP_REQW(1, 7, t + 1), 8, xb, 0, 1, false);
             SP_STAMP(9);
             if (have_next) set_req(nt_m, nt_n);
-            if constexpr (CONV) { if (have_next) { set_conv(nt_m, 0); set_conv(nt_m, 1); } }
+            if constexpr (CONV) { if (have_next) set_conv(nt_m, 1, 0); }
             SP_STAMP(10);
             SP_PHASE(SP_RW(3),     { if (have_next) { SP_REQX(0, 0, 0); SP_VM(8); } else { SP_VM(6); } }, -1, xb, 1, 1, false);
             SP_STAMP(11);
+            if constexpr (CONV) { if (have_next) set_conv(nt_m, 1, 1); }
             SP_PHASE(SP_RX(xb, 4), { if (have_next) { SP_REQW(0, 1, 0); SP_VM(8); } else { SP_VM(4); } }, -1, xa, 1, 0, false);
             SP_PHASE(SP_RW(5),     { if (have_next) { SP_REQX(1, 2, 0); SP_VM(8); } else { SP_VM(2); } }, -1, xb, 0, 0, false);
             SP_PHASE(SP_RX(xa, 6), { if (have_next) { SP_REQW(1, 3, 0); SP_VM(8); } else { SP_VM(0); } }, -1, xa, 0, 1, false);
