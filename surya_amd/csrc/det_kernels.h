@@ -351,9 +351,10 @@ static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
 // pixels of a row x 16 bytes of channels. The plain kernel above reads every input vector K*K times through L1/L2 (the
 // L2->CU path, not HBM, was its limit: 142 us average per launch in the r01 profile); here a loaded input column serves
 // up to K outputs from registers. Accumulation order per output is unchanged (ky outer, kx inner).
-template <typename T, int K, int S, int TX>
+template <typename T, int K, int S, int TX, bool FD = false>
 __global__ __launch_bounds__(256) void dwconv_tx_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias,
-                                                        T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pad, int act) {
+                                                        T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pad, int act,
+                                                        FastDiv fcv, FastDiv fwx, FastDiv fho) {
     constexpr int V = Ty<T>::V16;
     constexpr int NIN = (TX - 1) * S + K;            // input columns feeding TX outputs
     const int cv = C / V, wx = (Wo + TX - 1) / TX;
@@ -363,11 +364,22 @@ __global__ __launch_bounds__(256) void dwconv_tx_kernel(const T* __restrict__ in
     // share input rows are then neighbours in ONE XCD's queue.
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3, rem = nb & 7;
     const unsigned lb = xcd * per + min(xcd, rem) + (blockIdx.x >> 3);
-    const long idx = (long)lb * blockDim.x + threadIdx.x;
-    if (idx >= (long)B * Ho * wx * cv) return;
-    const int c0 = (int)(idx % cv) * V;
-    const long t = idx / cv;
-    const int ox0 = (int)(t % wx) * TX, oy = (int)((t / wx) % Ho), b = (int)(t / ((long)wx * Ho));
+    int c0, ox0, oy, b;
+    if constexpr (FD) {
+        // round 5: 32-bit index (the launcher checks the thread count) split by host-made reciprocals of C / V, ceil(Wo / TX) and Ho -- the
+        // 64-bit `%` and `/` below are ~700 instructions of software division per thread, in front of 27 loads and 288 FMAs
+        const unsigned idx = lb * blockDim.x + threadIdx.x;
+        if (idx >= (unsigned)B * Ho * wx * cv) return;
+        const unsigned t = fast_div(idx, fcv), t2 = fast_div(t, fwx), bq = fast_div(t2, fho);
+        c0 = (int)(idx - t * (unsigned)cv) * V;
+        ox0 = (int)(t - t2 * (unsigned)wx) * TX; oy = (int)(t2 - bq * (unsigned)Ho); b = (int)bq;
+    } else {
+        const long idx = (long)lb * blockDim.x + threadIdx.x;
+        if (idx >= (long)B * Ho * wx * cv) return;
+        c0 = (int)(idx % cv) * V;
+        const long t = idx / cv;
+        ox0 = (int)(t % wx) * TX; oy = (int)((t / wx) % Ho); b = (int)(t / ((long)wx * Ho));
+    }
     float acc[TX][V];
     if (bias) {
         float bv[V];
@@ -405,6 +417,100 @@ __global__ __launch_bounds__(256) void dwconv_tx_kernel(const T* __restrict__ in
 #pragma unroll
                 for (int i = 0; i < V; ++i) acc[o][i] += xin[o * S + kx][i] * wv[i];
         }
+    }
+#pragma unroll
+    for (int o = 0; o < TX; ++o) {
+        if (ox0 + o >= Wo) break;
+        float r[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = act == ACT_HSWISH ? hardswish_f(acc[o][i]) : (act == ACT_RELU ? fmaxf(acc[o][i], 0.f) : acc[o][i]);
+        T* op = out + (((long)b * Ho + oy) * Wo + ox0 + o) * C + c0;
+#pragma unroll
+        for (int i = 0; i < V; i += 4) store4(op + i, r[i], r[i + 1], r[i + 2], r[i + 3]);
+    }
+}
+
+// Round 5, measured and NOT the default (sa::Tuning::dwconv_pipe = 1): the same thread mapping and accumulation order with the loads taken
+// out of the control flow. In dwconv_tx_kernel every input vector sits behind its own bounds branch and a filter row outside the image is
+// skipped by `continue`: hipcc emits a branch per load and an `s_waitcnt vmcnt(0)` after the first two -- six dependent round trips per
+// thread at 4 waves per SIMD, 2.5 TB/s of HBM traffic on a kernel that moves two tensors and nothing else
+// (profiles/r05_w_det_hbm_traffic_pmc.md). Here every load is unconditional (clamped address, masked to zero: a padded tap contributes
+// 0 * w exactly as the reference's zero padding does). What hipcc makes of it -- whether the rows are written double-buffered or one at a
+// time between compiler barriers, the loads are readonly / noalias and move over both -- is ALL K * (NIN + K) loads in front of the
+// first use: 27 in flight per thread but 187 VGPRs = 2 waves per SIMD (K = 5: 256 VGPRs, 1 wave), and the 16-page forward is 4.5 %
+// SLOWER (11.53 -> 12.05 ms, profiles/r05_ab_*): this kernel wants waves, not loads per wave. Bit-identical to dwconv_tx_kernel.
+template <typename T, int K, int S, int TX>
+__global__ __launch_bounds__(256) void dwconv_pipe_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ bias,
+                                                          T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int pad, int act,
+                                                          FastDiv fcv, FastDiv fwx, FastDiv fho) {
+    constexpr int V = Ty<T>::V16;
+    constexpr int NIN = (TX - 1) * S + K;
+    const int cv = C / V, wx = (Wo + TX - 1) / TX;
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3, rem = nb & 7;
+    const unsigned lb = xcd * per + min(xcd, rem) + (blockIdx.x >> 3);
+    // 32-bit index (the launcher checks the thread count) split by host-made reciprocals of C / V, ceil(Wo / TX) and Ho: the round-3
+    // kernel's 64-bit `%` and `/` were ~700 instructions of software division per thread in front of 27 loads and 288 FMAs
+    const unsigned idx = lb * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)B * Ho * wx * cv) return;
+    const unsigned t = fast_div(idx, fcv), t2 = fast_div(t, fwx), bq = fast_div(t2, fho);
+    const int c0 = (int)(idx - t * (unsigned)cv) * V;
+    const int ox0 = (int)(t - t2 * (unsigned)wx) * TX, oy = (int)(t2 - bq * (unsigned)Ho), b = (int)bq;
+    const int ix0 = ox0 * S - pad;
+    int coff[NIN];
+    unsigned cmask[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        const int ix = ix0 + j;
+        coff[j] = min(max(ix, 0), W - 1) * C;
+        cmask[j] = (unsigned)ix < (unsigned)W ? 0xffffffffu : 0u;
+    }
+    const T* img = in + (long)b * H * W * C + c0;
+    float acc[TX][V];
+    uint4 braw = *reinterpret_cast<const uint4*>((bias ? bias : w) + c0);     // unconditional as well: a null bias reads the filter and is masked to + 0
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        // one filter row: its NIN input vectors and K weight vectors
+        uint4 raw[NIN], wraw[K];
+        const int iy = oy * S + ky - pad;
+        const T* row_ = img + (long)min(max(iy, 0), H - 1) * W * C;
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) raw[j] = *reinterpret_cast<const uint4*>(row_ + coff[j]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) wraw[kx] = *reinterpret_cast<const uint4*>(w + (long)(ky * K + kx) * C + c0);
+        asm volatile("" ::: "memory");       // (no effect on the readonly loads, see above)
+        if (ky == 0) {
+            const unsigned bm = bias ? 0xffffffffu : 0u;
+            braw.x &= bm; braw.y &= bm; braw.z &= bm; braw.w &= bm;
+            float bv[V];
+            unpack16(braw, bv, (T*)nullptr);
+#pragma unroll
+            for (int o = 0; o < TX; ++o)
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[o][i] = bv[i];
+        }
+        const unsigned rmask = (unsigned)iy < (unsigned)H ? 0xffffffffu : 0u;
+        float wv[K][V];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) unpack16(wraw[kx], wv[kx], (T*)nullptr);
+        // input column j feeds output o through tap kx = j - o * S: walking j upwards visits every output's taps in ascending kx, the same
+        // order as the (kx outer, o inner) loops of dwconv_tx_kernel -- and only ONE unpacked column is live
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            uint4 r = raw[j];
+            const unsigned m = cmask[j] & rmask;
+            r.x &= m; r.y &= m; r.z &= m; r.w &= m;
+            float x[V];
+            unpack16(r, x, (T*)nullptr);
+#pragma unroll
+            for (int o = 0; o < TX; ++o) {
+                const int kx = j - o * S;
+                if (kx >= 0 && kx < K) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[o][i] += x[i] * wv[kx][i];
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int o = 0; o < TX; ++o) {

@@ -141,8 +141,20 @@ struct DetModel : DetBase {
                     constexpr int TX = 4;
                     const long nt = (long)B * op.hout * cdiv(op.wout, TX) * (op.cin / Ty<T>::V16);
 #define SA_DWTX(KK, SS)                                                                                                     \
-    hipLaunchKernelGGL((dwconv_tx_kernel<T, KK, SS, TX>), dim3((unsigned)cdivl(nt, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx), \
-                       WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.p0, op.act)
+    do {                                                                                                                    \
+        const FastDiv fcv_ = make_fastdiv((unsigned)(op.cin / Ty<T>::V16)), fwx_ = make_fastdiv((unsigned)cdiv(op.wout, TX)), \
+                      fho_ = make_fastdiv((unsigned)op.hout);                                                               \
+        const int v_ = nt < (1L << 31) ? tuning().dwconv_pipe : 0;                                                          \
+        if (v_ == 1)                                                                                                        \
+            hipLaunchKernelGGL((dwconv_pipe_kernel<T, KK, SS, TX>), dim3((unsigned)cdivl(nt, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx), \
+                               WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.p0, op.act, fcv_, fwx_, fho_); \
+        else if (v_ == 2)                                                                                                   \
+            hipLaunchKernelGGL((dwconv_tx_kernel<T, KK, SS, TX, true>), dim3((unsigned)cdivl(nt, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx), \
+                               WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.p0, op.act, fcv_, fwx_, fho_); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((dwconv_tx_kernel<T, KK, SS, TX, false>), dim3((unsigned)cdivl(nt, 256)), dim3(256), 0, s, bufs[op.in0], WT(op.w_idx), \
+                               WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.cin, op.hout, op.wout, op.p0, op.act, fcv_, fwx_, fho_); \
+    } while (0)
                     if (op.k == 3 && op.stride == 1) SA_DWTX(3, 1);
                     else if (op.k == 3 && op.stride == 2) SA_DWTX(3, 2);
                     else if (op.k == 5 && op.stride == 1) SA_DWTX(5, 1);
