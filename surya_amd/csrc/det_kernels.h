@@ -46,11 +46,24 @@ __global__ void u8_to_nhwc_kernel(const unsigned char* __restrict__ in, T* __res
 //   m = (b, oy, ox) output pixel, weights [Cout][KH*KW*Cin padded to a multiple of the K-tile] (zero padded).
 // Same tile machinery as gemm_nt_kernel (2-deep register prefetch, swizzled LDS, weight fragment first); only the
 // A-operand fetch differs: a 16-byte chunk = 8 (bf16) / 4 (fp32) consecutive input channels of one tap, zero outside.
+// x / d in conv_gemm_kernel: by the host-made reciprocal, or (A/B builds, -DSA_CONV_TRUE_DIV=1) by the division it replaced
+#ifndef SA_CONV_TRUE_DIV
+#define SA_CONV_TRUE_DIV 0
+#endif
+__device__ __forceinline__ int conv_div(int x, int d, FastDiv f) {
+#if SA_CONV_TRUE_DIV
+    (void)f; return x / d;
+#else
+    (void)d; return (int)fast_div((unsigned)x, f);
+#endif
+}
+
 template <typename T>
 struct ConvArgs {
     const T* in; const T* w; T* out; const T* bias; const T* res;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, act;
     const T* zero = nullptr;        // >= 16 zero bytes on the device: what the direct-to-LDS gather reads outside the image
+    FastDiv fcin, fkw, fhw, fwo;    // reciprocals of Cin, KW, Ho * Wo, Wo (launch_conv sets them): conv_gemm_kernel divides per staged chunk
 };
 
 // CIN64: Cin is a multiple of the K-tile (64 bf16 / 32 fp32 elements), so a K-tile never straddles two filter taps: the
@@ -81,8 +94,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
     for (int i = 0; i < XCH; ++i) {
         const int id = tid + i * NT, row = id >> 3, c = id & 7;
         const int m = min(m0 + row, M - 1);
-        const int b = m / (p.Ho * p.Wo), r = m % (p.Ho * p.Wo);
-        xb[i] = b; xiy[i] = (r / p.Wo) * p.stride - p.pad; xix[i] = (r % p.Wo) * p.stride - p.pad;
+        const int b = conv_div(m, p.Ho * p.Wo, p.fhw), r = m - b * (p.Ho * p.Wo), oy_ = conv_div(r, p.Wo, p.fwo);
+        xb[i] = b; xiy[i] = oy_ * p.stride - p.pad; xix[i] = (r - oy_ * p.Wo) * p.stride - p.pad;
         xc[i] = c * V;
         xdst[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     }
@@ -109,8 +122,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
         const int kbase_ = (KT) * KE;                                                                           \
         int tap_u = 0, ci_u = 0, ky_u = 0, kx_u = 0;                                                            \
         if constexpr (CIN64) {                                                                                  \
-            tap_u = kbase_ / p.Cin; ci_u = kbase_ - tap_u * p.Cin;                                              \
-            ky_u = tap_u / p.KW; kx_u = tap_u - ky_u * p.KW;                                                    \
+            tap_u = conv_div(kbase_, p.Cin, p.fcin); ci_u = kbase_ - tap_u * p.Cin;                             \
+            ky_u = conv_div(tap_u, p.KW, p.fkw); kx_u = tap_u - ky_u * p.KW;                                   \
         }                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                       \
             int tap, ci, ky, kx;                                                                                \
@@ -118,8 +131,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs<T> p) 
                 tap = tap_u; ci = ci_u + xc[i]; ky = ky_u; kx = kx_u;                                           \
             } else {                                                                                            \
                 const int k0 = kbase_ + xc[i];                                                                  \
-                tap = k0 / p.Cin; ci = k0 - tap * p.Cin;                                                        \
-                ky = tap / p.KW; kx = tap - ky * p.KW;                                                          \
+                tap = conv_div(k0, p.Cin, p.fcin); ci = k0 - tap * p.Cin;              /* (round 5: reciprocals -- two integer */ \
+                ky = conv_div(tap, p.KW, p.fkw); kx = tap - ky * p.KW;               /* divisions per chunk and K-tile were ~80 VALU) */ \
             }                                                                                                   \
             const int iy = xiy[i] + ky, ix = xix[i] + kx;                                                       \
             const bool ok = (tap < ntaps) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);                    \
@@ -323,8 +336,11 @@ static inline int launch_conv_on_gemm(const ConvArgs<T>& a, hipStream_t s) {
 }
 
 template <typename T>
-static inline int launch_conv(const ConvArgs<T>& a, hipStream_t s) {
+static inline int launch_conv(const ConvArgs<T>& a_in, hipStream_t s) {
+    ConvArgs<T> a = a_in;
     if (a.Cin % Ty<T>::V16 != 0 || a.Kpad % Ty<T>::KE != 0 || a.Cout % 4 != 0) return SA_ERR_SHAPE;
+    a.fcin = make_fastdiv((unsigned)a.Cin); a.fkw = make_fastdiv((unsigned)a.KW);
+    a.fhw = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.fwo = make_fastdiv((unsigned)a.Wo);
     const long M = (long)a.B * a.Ho * a.Wo;
     if constexpr (std::is_same<T, bf16_t>::value) {
         // (the 32-channel stem convolutions stay on the register-staged kernel: 128x32 tiles measured 5-15 % slower on the gather)
