@@ -187,7 +187,7 @@ struct Tuning {
     int bigtile = 3;         // 256x256 tiles for large bf16 GEMMs: 3 = the 8-phase schedule (round 5; even K-tile counts, else the 2-stage loop), 1 = 2-stage loop, 2 = 2-stage on 4 waves, 0 = 128x128 only
     int bigtile_any = 0;     // 1: every M > 256 bf16 GEMM takes the 256x256 tile whatever its round count (tests / race screens of the tile on small shapes)
     int gateup_ring = 2;     // decode gate|up (64x64 tiles, M in (128, 256]): LDS stages of its direct-to-LDS loop (2 = unrolled pair, 3 / 4 = ring with counted vmcnt)
-    int conv_persist = 1;    // 3 x 3 / 5 x 5 convolutions on 256x256 tiles, Cin % 64 == 0: the persistent 8-phase loop with the gather in its request stream (0 = one-tile 2-stage kernel)
+    int conv_persist = 3;    // 3 x 3 / 5 x 5 convolutions on 256x256 tiles on the persistent 8-phase loop with the gather in its request stream: bit 0 = Cin % 64 == 0 (a K-tile is one tap), bit 1 = Cin == 32 (two taps per K-tile); 0 = one-tile 2-stage kernel
     int dwconv_pipe = 2;     // depthwise convolutions: 2 = round-3 kernel with its index split by host-made reciprocals (64-bit % and / were ~700 instructions per thread; +1 % on the forward), 1 = all loads unconditional (hipcc hoists them all: 2 waves per SIMD, -4.5 %), 0 = round-3 kernel
     int conv_lean = 1;       // implicit-GEMM convolutions whose K-tiles align with filter taps: gather state precomputed per workgroup (0 = round-4 per-request arithmetic)
     int bigtile_ratio_pct = 0;  // tile choice: assumed throughput of a full round of 256x256 tiles over one of 128x128 tiles, in percent (0 = built-in: 140 for the 8-phase loop, 117 otherwise)

@@ -324,9 +324,13 @@ static inline int launch_conv_on_gemm(const ConvArgs<T>& a, hipStream_t s) {
         // 4.0k cycles per K-tile in its drain-per-tile loop (tools/microbench/p8_timing.hip).
         if constexpr (sizeof(T) == 2) {
             const int nkc = a.Kpad / 64;
-            if (tuning().persist && tuning().conv_persist && a.Cin % 64 == 0 && a.Cin <= 1024 && a.KH <= 7 && a.KW <= 7 && nkc < 4096 && nkc + (nkc & 1) >= 4 && a.Cout % 8 == 0 &&
-                (long)a.B * a.H * a.W * a.Cin * (long)sizeof(T) < (1L << 31) - (1L << 24))
-                return launch_gemm_persist<T, T, EPI, true>(g, s);
+            const bool fits = tuning().persist && a.KH <= 7 && a.KW <= 7 && nkc < 4096 && nkc + (nkc & 1) >= 4 && a.Cout % 8 == 0 &&
+                              (long)a.B * a.H * a.W * a.Cin * (long)sizeof(T) < (1L << 31) - (1L << 24);
+            if (fits && (tuning().conv_persist & 1) && a.Cin % 64 == 0 && a.Cin <= 1024) return launch_gemm_persist<T, T, EPI, 1>(g, s);
+            // Cin = 32 (the detector's largest single launch: 3 x 3 stride 2, 32 -> 512 channels at 256^2): two taps per K-tile, the tap chosen per
+            // lane by the half of the 128-byte row its chunk lies in (Hardswish epilogue only: the one such convolution in the network)
+            if constexpr (EPI == EPI_HARDSWISH)
+                if (fits && (tuning().conv_persist & 2) && a.Cin == 32) return launch_gemm_persist<T, T, EPI, 2>(g, s);
         }
         return launch_gemm_cfg<T, T, 256, 256, 4, 2, EPI, false, 2, true>(g, s);
     }

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
 // needed from a fresh v_mbcnt: kept live across the tile loop beside 128 accumulators it is spilled, and a scratch reload waits vmcnt(0).
 // K order, MFMA, accumulator assignment and every epilogue formula are the one-tile kernel's: bit-identical (tests/test_gpu_round4.py).
 // Requires an even K-tile count >= 4 and a 2-byte output type.
-template <typename TI, typename TO, int EPI, bool CONV = false>
+template <typename TI, typename TO, int EPI, int CONV = 0>
 __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
     constexpr int BM = 256, BN = 256, GRP = 32, KE = Ty<TI>::KE, HT = 16384;
     static_assert(sizeof(TI) == 2 && sizeof(TO) == 2 && EPI != EPI_ARGMAX, "persistent 8-phase loop: bf16 operands, 2-byte outputs");
@@ -1043,19 +1043,37 @@ __global__ __launch_bounds__(512) void gemm_nt_p8p_kernel(GemmArgs<TI, TO> p) {
             const int iy0 = (int)oy * p.cStride - p.cPad, ix0 = (int)ox * p.cStride - p.cPad;
             cb[hh][i] = ((((int)bi * p.cH + iy0) * p.cW + ix0) * p.cCin) * (int)sizeof(TI) + c * 16;
             const int rlo = max(0, -iy0), rhi = max(rlo, min(KH, p.cH - iy0)), clo = max(0, -ix0), chi = max(clo, min(p.cKW, p.cW - ix0));
-            cm[hh][i] = ((1u << rhi) - (1u << rlo)) | (((1u << chi) - (1u << clo)) << 16);
+            cm[hh][i] = ((1u << rhi) - (1u << rlo)) | (((1u << chi) - (1u << clo)) << 16) | (CONV == 2 ? (unsigned)(c >> 2) << 31 : 0u);
         }
     };
     // X request of half HH for K-tile KT: plain rows, or the convolution gather (tap of the K-tile: scalar; ~8 VALU per request)
 #define SP_REQX(HH, SLOT, KT)                                                                                     \
     {                                                                                                             \
-        if constexpr (CONV) {                                                                                     \
+        if constexpr (CONV == 1) {                                                                                \
             const unsigned tap_ = ((unsigned)(KT) * p.cv_m1) >> 16, ky_ = (tap_ * p.cv_m2) >> 16, kx_ = tap_ - ky_ * (unsigned)p.cKW;   /* scalar */ \
             const int toff_ = (KT) * 128 + (int)ky_ * p.cv_rowskip;                                               \
             const unsigned bit_ = (1u << ky_) | (0x10000u << kx_);    /* the virtual K-tile: ky = KH, no such row bit */ \
             _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
                 int c_ = cb[HH][i_];                                                                              \
                 asm volatile("" : "+v"(c_));          /* the 64-bit address is formed HERE, not hoisted as a register pair per request */ \
+                const unsigned char* src_ = ((cm[HH][i_] & bit_) == bit_) ? reinterpret_cast<const unsigned char*>(p.conv_in) + (long)(c_ + toff_) \
+                                                                : reinterpret_cast<const unsigned char*>(p.conv_zero); \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
+            }                                                                                                     \
+        } else if constexpr (CONV == 2) {                                                                         \
+            /* Cin = 32: a K-tile row is taps 2 kt (chunks 0..3) and 2 kt + 1 (chunks 4..7). Both taps' scalars, selected per lane by */ \
+            /* the chunk's half (bit 31 of cm); the byte offset tap * 64 = kt * 128 + half * 64 is already in cb (c * 16). Taps past */ \
+            /* the filter (the odd ninth tap's partner, the virtual K-tile) have ky >= KH: no such row bit, zero page.               */ \
+            const unsigned ta_ = 2u * (unsigned)(KT), kya_ = (ta_ * p.cv_m2) >> 16, kxa_ = ta_ - kya_ * (unsigned)p.cKW;          \
+            const unsigned tb_ = ta_ + 1u, kyb_ = (tb_ * p.cv_m2) >> 16, kxb_ = tb_ - kyb_ * (unsigned)p.cKW;                      \
+            const int toa_ = (KT) * 128 + (int)kya_ * p.cv_rowskip, tob_ = (KT) * 128 + (int)kyb_ * p.cv_rowskip;                  \
+            const unsigned bita_ = (1u << kya_) | (0x10000u << kxa_), bitb_ = (1u << kyb_) | (0x10000u << kxb_);                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
+                int c_ = cb[HH][i_];                                                                              \
+                asm volatile("" : "+v"(c_));                                                                      \
+                const bool hi_ = (int)cm[HH][i_] < 0;                                                             \
+                const unsigned bit_ = hi_ ? bitb_ : bita_;                                                        \
+                const int toff_ = hi_ ? tob_ : toa_;                                                              \
                 const unsigned char* src_ = ((cm[HH][i_] & bit_) == bit_) ? reinterpret_cast<const unsigned char*>(p.conv_in) + (long)(c_ + toff_) \
                                                                 : reinterpret_cast<const unsigned char*>(p.conv_zero); \
                 __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (SLOT) * HT + (wv * 2 + i_) * 1024), 16, 0, 0); \
@@ -1489,7 +1507,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
 }
 
 // Launch of the persistent 8-phase tile loop: one workgroup per CU (160 KB of LDS each), XCD-aware super-tiles as in launch_gemm_cfg.
-template <typename TI, typename TO, int EPI, bool CONV = false>
+template <typename TI, typename TO, int EPI, int CONV = 0>
 static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) {
     constexpr int BM = 256, BN = 256, GRP = 32;
     const int tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);

@@ -137,16 +137,16 @@ def test_det_forward_from_uint8_pages_is_bit_identical(hip_lib, dtype):
 @pytest.mark.parametrize("pages_n,size", [(2, 1024), (3, 672)])
 def test_persistent_conv_loop_is_bit_identical_to_the_one_tile_kernel(hip_lib, pages_n, size):
     """The 3 x 3 convolutions of the large stages run on the persistent 8-phase loop with the gather in its request stream (sa::Tuning
-    conv_persist = 1, the default) or on the one-tile 2-stage kernel (0): same K order, same MFMA, the virtual zero K-tile of an odd
-    K-tile count adds 0 * 0 -- DET-DEFAULT bf16 heat maps must agree bit for bit, run to run and across the two kernels. 672^2 x 3 pages
-    leaves the last 256-row tile of every such convolution ragged."""
+    conv_persist: bit 0 = the Cin % 64 == 0 convolutions, bit 1 = the Cin = 32 one with two taps per K-tile; default 3) or on the one-tile
+    2-stage kernel (0): same K order, same MFMA, the virtual zero K-tile of an odd K-tile count adds 0 * 0 -- DET-DEFAULT bf16 heat maps
+    must agree bit for bit, run to run and across the kernels. 672^2 x 3 pages leaves the last 256-row tile of every such convolution ragged."""
     import ctypes as C
     from surya_amd import _lib as L
     cfg, sd, m = build("DET-DEFAULT", size, torch.bfloat16, max_batch=pages_n)
     x = do.normalise_pages(list(make_pages(pages_n, size, seed=99))).cuda().contiguous()
     outs = {}
     try:
-        for v in (0, 1, 0, 1):
+        for v in (0, 1, 3, 0, 1, 3):
             L.check(hip_lib.surya_set_tuning(b"conv_persist", C.c_int(v)), "surya_set_tuning")
             h = m.forward(x).clone()
             torch.cuda.synchronize()
@@ -154,6 +154,7 @@ def test_persistent_conv_loop_is_bit_identical_to_the_one_tile_kernel(hip_lib, p
                 assert torch.equal(outs[v].view(torch.int32), h.view(torch.int32)), f"conv_persist={v}: not run-to-run identical"
             outs[v] = h
     finally:
-        L.check(hip_lib.surya_set_tuning(b"conv_persist", C.c_int(1)), "surya_set_tuning")
-    assert torch.isfinite(outs[1]).all()
+        L.check(hip_lib.surya_set_tuning(b"conv_persist", C.c_int(3)), "surya_set_tuning")
+    assert torch.isfinite(outs[3]).all()
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.equal(outs[0].view(torch.int32), outs[3].view(torch.int32))

@@ -43,4 +43,3 @@ for pages_n, size in ((16, 1024), (3, 640)):
         ms = sorted(times[v])[2]
         print(f"    {KNOB.decode()}={v}: {ms:.3f} ms per forward, {pages_n / ms * 1e3:.1f} pages/s", flush=True)
     del m
-L.check(lib.surya_set_tuning(KNOB, C.c_int(1)), "tuning")
