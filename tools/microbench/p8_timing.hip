@@ -93,7 +93,7 @@ static void run_conv(const char* name, int B, int H, int W, int Cin, int Cout, i
     GemmArgs<bf16_t, bf16_t> a{nullptr, 0, Wt, (long)K, C, (long)Cout, Bi, nullptr, (long)Cout, M, Cout, K};
     a.conv_in = X; a.conv_zero = Z; a.cH = H; a.cW = W; a.cCin = Cin; a.cHo = Ho; a.cWo = Wo; a.cKW = 3; a.cStride = stride; a.cPad = 1; a.cTaps = 9;
     a.fd_hw = make_fastdiv((unsigned)(Ho * Wo)); a.fd_wo = make_fastdiv((unsigned)Wo);
-    a.cv_m1 = (65536u + Cin / 64 - 1) / (Cin / 64); a.cv_m2 = (65536u + 2) / 3; a.cv_rowskip = (W - 3) * Cin * 2;
+    a.cv_m1 = Cin >= 64 ? (65536u + Cin / 64 - 1) / (Cin / 64) : 0u; a.cv_m2 = (65536u + 2) / 3; a.cv_rowskip = (W - 3) * Cin * 2;
     const int tm = cdiv(M, 256), tn = cdiv(Cout, 256);
     a.swz_n = cdiv(tn, cdiv(tn, 8)); a.swz_m = std::max(1, 32 / a.swz_n);
     const int tiles = cdiv(tm * tn, 256) * 256;
@@ -130,6 +130,7 @@ static void run_conv(const char* name, int B, int H, int W, int Cin, int Cout, i
 }
 
 // The same convolutions on the persistent 8-phase loop (gather in the request stream; odd K-tile counts get a virtual zero K-tile).
+template <int MODE = 1>      // 1: Cin % 64 == 0 (a K-tile is one tap), 2: Cin == 32 (two taps per K-tile)
 static void run_conv_p8p(const char* name, int B, int H, int W, int Cin, int Cout, int stride) {
     const int Ho = H / stride, Wo = W / stride, M = B * Ho * Wo, K = ((9 * Cin + 63) / 64) * 64;
     bf16_t *X, *Wt, *C, *Bi, *Z;
@@ -141,14 +142,14 @@ static void run_conv_p8p(const char* name, int B, int H, int W, int Cin, int Cou
     GemmArgs<bf16_t, bf16_t> a{nullptr, 0, Wt, (long)K, C, (long)Cout, Bi, nullptr, (long)Cout, M, Cout, K};
     a.conv_in = X; a.conv_zero = Z; a.cH = H; a.cW = W; a.cCin = Cin; a.cHo = Ho; a.cWo = Wo; a.cKW = 3; a.cStride = stride; a.cPad = 1; a.cTaps = 9;
     a.fd_hw = make_fastdiv((unsigned)(Ho * Wo)); a.fd_wo = make_fastdiv((unsigned)Wo);
-    a.cv_m1 = (65536u + Cin / 64 - 1) / (Cin / 64); a.cv_m2 = (65536u + 2) / 3; a.cv_rowskip = (W - 3) * Cin * 2;
+    a.cv_m1 = Cin >= 64 ? (65536u + Cin / 64 - 1) / (Cin / 64) : 0u; a.cv_m2 = (65536u + 2) / 3; a.cv_rowskip = (W - 3) * Cin * 2;
     const int tm = cdiv(M, 256), tn = cdiv(Cout, 256);
     a.swz_n = cdiv(tn, cdiv(tn, 8)); a.swz_m = std::max(1, 32 / a.swz_n);
     const int grid = 256, TILES = 24;
     long long* dbg;
     const size_t dbg_n = (size_t)grid * 2 * TILES * 12;
     hipMalloc(&dbg, dbg_n * 8);
-    auto kern = gemm_nt_p8p_kernel<bf16_t, bf16_t, EPI_HARDSWISH, true>;
+    auto kern = gemm_nt_p8p_kernel<bf16_t, bf16_t, EPI_HARDSWISH, MODE>;
     const size_t lds = (size_t)2 * 512 * 128 + 8 * 4096;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -195,6 +196,8 @@ static void run_conv_p8p(const char* name, int B, int H, int W, int Cin, int Cou
 }
 
 int main() {
+    run_conv_p8p<2>("det op 4: 3x3 s2, 32 -> 512 ch, 512^2 -> 256^2 x 16 pages", 16, 512, 512, 32, 512, 2);
+    run_conv("det op 4: 3x3 s2, 32 -> 512 ch, 512^2 -> 256^2 x 16 pages", 16, 512, 512, 32, 512, 2);
     run_conv_p8p("det op 6: 3x3 s1, 64 -> 256 ch, 256^2 x 16 pages", 16, 256, 256, 64, 256, 1);
     run_conv_p8p("det op 10: 3x3 s1, 128 -> 512 ch, 128^2 x 16 pages", 16, 128, 128, 128, 512, 1);
     run_conv("det op 6: 3x3 s1, 64 -> 256 ch, 256^2 x 16 pages", 16, 256, 256, 64, 256, 1);
