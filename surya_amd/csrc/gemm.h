@@ -30,30 +30,12 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fastdiv.h"
 
 namespace sa {
 
 enum GemmEpi { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_SWIGLU = 3, EPI_HARDSWISH = 4, EPI_RELU = 5, EPI_ARGMAX = 6, EPI_ROPE = 7,
                EPI_GEGLU = 8 /* gelu_tanh(gate) * up, rows interleaved like SWIGLU (ADETR decoder MLP, adetr/decoder.py:331-344) */ };
-
-// x / d for 32-bit unsigned x without a division instruction sequence (an integer division is ~40 VALU instructions on this ISA): d a
-// power of two -> shift; otherwise the 33-bit round-up magic m = floor(2^(33 + k) / d) + 1, k = floor(log2 d), whose top bit is implicit:
-// q = mulhi(x, m), x / d = (((x - q) >> 1) + q) >> k -- exact for every 32-bit x (checked against // for d up to 2^31 in Python).
-struct FastDiv { unsigned m = 0, s = 0; };
-static inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    if (d == 0) d = 1;
-    unsigned k = 31 - (unsigned)__builtin_clz(d);
-    if ((d & (d - 1)) == 0) { f.m = 0; f.s = k; return f; }
-    f.m = (unsigned)((((unsigned __int128)1 << (33 + k)) / d + 1) & 0xffffffffu);
-    f.s = k;
-    return f;
-}
-__device__ __forceinline__ unsigned fast_div(unsigned x, FastDiv f) {
-    if (f.m == 0) return x >> f.s;
-    const unsigned q = __umulhi(x, f.m);
-    return (((x - q) >> 1) + q) >> f.s;
-}
 
 template <typename TI, typename TO>
 struct GemmArgs {
