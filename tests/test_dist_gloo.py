@@ -318,7 +318,7 @@ def test_forced_one_rank_group_takes_the_collective_branch():
 
 
 # ------------------------------------------------------------------ whole pages per rank (RecognitionPredictor.shard_pages)
-def _page_worker(rank, world, port, q):
+def _page_worker(rank, world, port, q, n_pages=7):
     """_call_page_sharded on `world` ranks: the orchestration (fingerprint, page deal, the rank's own single-rank call, the gather) with
     the single-rank call replaced by a stand-in that derives a page's OCRResult from its pixels."""
     import torch.distributed as dist
@@ -353,7 +353,7 @@ def _page_worker(rank, world, port, q):
     real_call = RecognitionPredictor._call
     pred._call = lambda *a: real_call(pred, *a) if pred.shard_pages else fake_call(*a)     # the outer call is the product's, the rank's own call the stand-in
     pred.tasks = {"ocr_with_boxes": {}}
-    pages = [Image.fromarray(np.full((20 + i, 30, 3), 10 + i, np.uint8)) for i in range(7)]
+    pages = [Image.fromarray(np.full((20 + i, 30, 3), 10 + i, np.uint8)) for i in range(n_pages)]
     det = Det()
     full = pred(pages, det_predictor=det)
     assert det.shard_pages and pred.shard_pages
@@ -361,7 +361,7 @@ def _page_worker(rank, world, port, q):
     part = pred(pages, det_predictor=det)
     summary = list(pred.last_page_summary)
     try:
-        pred(pages[:3] if rank == 0 else pages[:4], det_predictor=det)
+        pred(pages[:-1] if rank == 0 else pages, det_predictor=det)          # rank 0 was handed one page fewer
         err = "no error"
     except Exception as e:
         err = "raised " + type(e).__name__
@@ -370,26 +370,26 @@ def _page_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_page_sharded_call(world):
+@pytest.mark.parametrize("world,n_pages", [(2, 7), (3, 7), (3, 2), (4, 1)])      # the last two: ranks that are dealt no page at all
+def test_page_sharded_call(world, n_pages):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_page_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_page_worker, args=(r, world, port, q, n_pages)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda g: g[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    expect_lines = [(10 + i) % 4 for i in range(7)]
+    expect_lines = [(10 + i) % 4 for i in range(n_pages)]
     for rank, full, part, summary, calls, err in got:
         assert [len(r["text_lines"]) for r in full] == expect_lines            # every rank holds every page, in page order
         assert full == got[0][1]
-        mine = list(range(rank, 7, world))
+        mine = list(range(rank, n_pages, world))
         assert [i for i, r in enumerate(part) if r is not None] == mine         # partitioned: own pages only ...
         assert all(part[i] == full[i] for i in mine)
         assert [s_[0] for s_ in summary] == expect_lines                        # ... and a record of every page on every rank
-        assert calls == [len(mine), len(mine)] and err.startswith("raised")
+        assert calls == ([len(mine), len(mine)] if mine else []) and err.startswith("raised")      # a rank without pages makes no call of its own
