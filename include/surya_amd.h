@@ -298,6 +298,12 @@ int surya_det_destroy(surya_det* h);
  * heatmaps: device fp32 [batch, labels, H, W] (may be NULL); lowres: device fp32 [batch, labels, H/4, W/4] (may be NULL)
  * = the model's own output before the predictor-side upsample. Enqueue only. */
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream);
+/* Measurement support (tools/det_op_times.py, bench.py's detection buckets): the same forward with a hipEvent in front of every op of the
+ * list; op_ms[i] (host, n_op_ms >= surya_det_op_count) = milliseconds of op i, 0 for an op folded into a fused form (sa::Tuning det_fuse).
+ * Synchronises the stream. Not for timed regions. */
+int surya_det_op_count(surya_det* h);
+int surya_det_forward_timed(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream, float* op_ms,
+                            int n_op_ms);
 /* Same forward from the resized pages themselves: device uint8 [batch, H, W, pixel_stride], pixel_stride 3 (RGB) or 4 (RGBX =
  * PIL's in-memory layout, uploaded without repacking; the fourth byte is ignored). The rescale
  * (x * 1/255 in fp32) and normalisation ((x - mean) / std) of SegformerImageProcessor._preprocess

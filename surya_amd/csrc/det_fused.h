@@ -1,0 +1,610 @@
+// Fused forms of the text detector's blocks (round 6). The op-by-op kernels of det_kernels.h moved every intermediate through HBM:
+// 29 GB per 16 pages of 1024^2 against ~3.5 GB of block-boundary tensors, and the LiteMLA chain spent 2 ms of a 10.5 ms
+// forward on 0.3 % of its FLOPs. Each kernel here keeps one intermediate on the chip:
+//   litemla_fused_kernel      kv = relu(K)^T [V | 1] and out = relu(Q) kv / (den + eps) per (image, head), both on the fp32 MFMA
+//                             (surya/detection/model/encoderdecoder.py:332-359; fp32 like the reference's _attn)
+//   dw5_g1x1_kernel           LiteMLA's multi-scale branch: depthwise 5x5 -> (LDS) -> grouped 1x1 on the bf16 MFMA (:313-318)
+//   head_z0_kernel            the full-resolution stage's folded 1x1 convolution z0 = A0 x0 + c computed per 128-channel slab on the MFMA inside the
+//                             decode head's sum + ReLU + classify + sigmoid pass (:699-722 in the folded form of detection/plan.py)
+//   dwproj_kernel             MBConv's depthwise 3x3 (+ bias + Hardswish) as the producer of the projection GEMM's A tile (:174-225)
+// All are bf16 product-path kernels (fp32 reference mode keeps the op list); litemla_fused_kernel is templated on the storage type.
+// Rounding points are the op list's own: every tensor the reference materialises in the model dtype is rounded to bf16 at the same place.
+#pragma once
+#include "det_kernels.h"
+
+namespace sa {
+
+// ---------------------------------------------------------------------------------------------------
+// LiteMLA, one workgroup per (head, image). v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain over the contraction index (here: tokens
+// for kv, the 32 head channels for out), so this is the reference's fp32 arithmetic in a fixed, batch-independent order.
+//   phase A  per 128-token chunk: relu(k), v staged as fp32 in LDS; wave w reduces tokens [32 w, 32 w + 32) of the chunk:
+//            D[i][j] += relu(k)[t][i] * v[t][j] (A = k column i, B = v column j, contraction over t, two tokens per MFMA); the ones-column
+//            of v (row sums of relu(k)) is a running add of the A operand. The four waves' partial 32 x 32 matrices meet in LDS.
+//   phase B  per chunk: relu(q) staged [token][33] (padded: the B operand walks tokens across lanes); D[j][t] = sum_i kv[i][j] * q[t][i]
+//            (A = kv row i as 16 hoisted registers); the divisor den[t] = sum_i q[t][i] * ksum[i] rides on the same operand loads.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict__ qa, const T* __restrict__ qb, T* __restrict__ out, int HW,
+                                                            int heads_a, int heads, float eps) {
+    static_assert(DIM == 32, "one 32 x 32 fp32 MFMA tile per head");
+    constexpr int CH = 128, V = Ty<T>::V16;
+    __shared__ __attribute__((aligned(16))) float sm[CH * 64 + 4 * 1024 + 1024 + 160];
+    float* ks = sm;                      // [CH][32] relu(k)        (phase A)
+    float* vs = sm + CH * 32;            // [CH][32] v              (phase A)
+    float* qs = sm;                      // [CH][33] relu(q)        (phase B, aliases ks / vs)
+    float* part = sm + CH * 64;          // [4][32][32] per-wave partial kv
+    float* kv = part + 4096;             // [32][32]
+    float* ksp = kv + 1024;              // [4][32] per-wave partial column sums of relu(k)
+    float* ksf = ksp + 128;              // [32]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int Ca = heads_a * 3 * DIM, Cb = (heads - heads_a) * 3 * DIM;
+    const T* src = h < heads_a ? qa + (long)b * HW * Ca + h * 3 * DIM : qb + (long)b * HW * Cb + (h - heads_a) * 3 * DIM;
+    const int C = h < heads_a ? Ca : Cb;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ksum = 0.f;
+    for (int n0 = 0; n0 < HW; n0 += CH) {
+        constexpr int CPT = 2 * DIM / V;                 // 16-byte chunks of k | v per token (contiguous behind q)
+        for (int idx = tid; idx < CH * CPT; idx += 256) {
+            const int n = idx / CPT, pc = idx % CPT, tok = n0 + n;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (tok < HW) raw = *reinterpret_cast<const uint4*>(src + (long)tok * C + DIM + pc * V);
+            float x[V];
+            unpack16(raw, x, (T*)nullptr);
+            const int e0 = pc * V;
+            if (e0 < DIM) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) ks[n * 32 + e0 + e] = fmaxf(x[e], 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) vs[n * 32 + e0 - DIM + e] = x[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int t = w * 32 + 2 * s + lh;
+            const float a = ks[t * 32 + lr], bv = vs[t * 32 + lr];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            ksum += a;
+        }
+        __syncthreads();
+    }
+    ksum += __shfl_xor(ksum, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[r];
+    if (lane < 32) ksp[w * 32 + lane] = ksum;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) kv[e] = ((part[e] + part[1024 + e]) + part[2048 + e]) + part[3072 + e];      // fixed order
+    if (tid < 32) ksf[tid] = ((ksp[tid] + ksp[32 + tid]) + ksp[64 + tid]) + ksp[96 + tid];
+    __syncthreads();
+
+    float ak[16], ksl[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { ak[s] = kv[(2 * s + lh) * 32 + lr]; ksl[s] = ksf[2 * s + lh]; }
+    const int Cout = heads * DIM;
+    for (int n0 = 0; n0 < HW; n0 += CH) {
+        constexpr int QPT = DIM / V;
+        for (int idx = tid; idx < CH * QPT; idx += 256) {
+            const int n = idx / QPT, pc = idx % QPT, tok = n0 + n;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (tok < HW) raw = *reinterpret_cast<const uint4*>(src + (long)tok * C + pc * V);
+            float x[V];
+            unpack16(raw, x, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) qs[n * 33 + pc * V + e] = fmaxf(x[e], 0.f);
+        }
+        __syncthreads();
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        float den = 0.f;
+        const int tl = w * 32 + lr;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bq = qs[tl * 33 + 2 * s + lh];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[s], bq, o, 0, 0, 0);
+            den += bq * ksl[s];
+        }
+        den += __shfl_xor(den, 32, 64);
+        const float inv = 1.0f / (den + eps);
+        const int tok = n0 + tl;
+        if (tok < HW) {
+            T* dst = out + ((long)b * HW + tok) * Cout + h * DIM;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) store4(dst + 8 * g + 4 * lh, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LiteMLA multi-scale branch (encoderdecoder.py:313-318): depthwise 5x5 (no bias) then a grouped 1x1 with 32-channel groups (no bias).
+// Workgroup = one 8 x 32 pixel tile of one image x one 32-channel group. The group's input patch (12 x 36 pixels, zero outside the image)
+// and its 25 x 32 filter taps sit in LDS; a thread produces 4 vertically adjacent pixels x 8 channels of the depthwise result (fp32, taps in
+// (ky, kx) order as dwconv_tx_kernel), rounds them to bf16 into the A tile [256 px][32 ch] and the group's 32 x 32 matrix runs on the bf16 MFMA.
+__global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
+                                                      bf16_t* __restrict__ out, int H, int W, int C, int tiles_x) {
+    constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char in_t[PH * PW * 64];
+    __shared__ __attribute__((aligned(16))) float wd[25 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char a_t[TH * TW * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int y0 = ((int)blockIdx.x / tiles_x) * TH, x0 = ((int)blockIdx.x % tiles_x) * TW;
+    const bf16_t* img = in + (long)b * H * W * C + g * 32;
+    for (int idx = tid; idx < PH * PW * 4; idx += 256) {
+        const int px = idx >> 2, c = idx & 3, ty = px / PW, tx = px - ty * PW;
+        const int gy = y0 - 2 + ty, gx = x0 - 2 + tx;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) raw = *reinterpret_cast<const uint4*>(img + ((long)gy * W + gx) * C + c * 8);
+        *reinterpret_cast<uint4*>(in_t + px * 64 + c * 16) = raw;
+    }
+    if (tid < 100) {
+        const int tap = tid >> 2, c = tid & 3;
+        float t[8];
+        unpack16(*reinterpret_cast<const uint4*>(wdw + (long)tap * C + g * 32 + c * 8), t, (bf16_t*)nullptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wd[tap * 32 + c * 8 + e] = t[e];
+    }
+    __syncthreads();
+    {
+        const int chunk = tid & 3, x = (tid >> 2) & 31, yg = tid >> 7;
+        float acc[4][8];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky) {                    // (rolled, and one output row at a time below: unrolled, hipcc hoists all 150 LDS reads and spills)
+            float wr[5][8];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wd + (ky * 5 + kx) * 32 + chunk * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wd + (ky * 5 + kx) * 32 + chunk * 8 + 4);
+                wr[kx][0] = w0.x; wr[kx][1] = w0.y; wr[kx][2] = w0.z; wr[kx][3] = w0.w;
+                wr[kx][4] = w1.x; wr[kx][5] = w1.y; wr[kx][6] = w1.z; wr[kx][7] = w1.w;
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int row = yg * 4 + o + ky;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    float xv[8];
+                    unpack16(*reinterpret_cast<const uint4*>(in_t + (row * PW + x + kx) * 64 + chunk * 16), xv, (bf16_t*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][e] += xv[e] * wr[kx][e];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int px = (yg * 4 + o) * TW + x;
+            *reinterpret_cast<uint4*>(a_t + px * 64 + ((chunk ^ ((px >> 2) & 3)) << 4)) =
+                make_uint4(pack2(acc[o][0], acc[o][1]), pack2(acc[o][2], acc[o][3]), pack2(acc[o][4], acc[o][5]), pack2(acc[o][6], acc[o][7]));
+        }
+    }
+    __syncthreads();
+    const int lr = lane & 31, lh = lane >> 5;
+    u32x4 wf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const u32x4*>(wg + (long)(g * 32 + lr) * 32 + ks * 16 + lh * 8);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mt = wv * 2 + m, px = mt * 32 + lr;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(a_t + px * 64 + (((ks * 2 + lh) ^ ((px >> 2) & 3)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+        }
+        const int gy = y0 + mt, gx = x0 + lr;
+        if (gy < H && gx < W) {
+            bf16_t* dst = out + (((long)b * H + gy) * W + gx) * C + g * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store4(dst + 8 * q + 4 * lh, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
+static inline int launch_dw5_g1x1(const bf16_t* in, const bf16_t* wdw, const bf16_t* wg, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
+    const int tx = cdiv(W, 32), ty = cdiv(H, 8);
+    hipLaunchKernelGGL(dw5_g1x1_kernel, dim3(tx * ty, C / 32, B), dim3(256), 0, s, in, wdw, wg, out, H, W, C, tx);
+    return (int)hipGetLastError();
+}
+template <typename T>
+static inline int launch_dw5_g1x1(const T*, const T*, const T*, T*, int, int, int, int, hipStream_t) { return SA_ERR_UNSUPPORTED; }
+
+// ---------------------------------------------------------------------------------------------------
+// Decode head with z0 inside (SA_DET_UPSUM_CLASSIFY + the stage-0 1x1 convolution that feeds it). head_upsum_classify_blk_kernel read
+// z0 = A0 x0 + c ([P, 512] bf16, 1.07 GB per 16 pages of 1024^2) that a GEMM launch had just written. Here a workgroup of 256 threads owns 16
+// blocks of 4 x 2 pixels (128 pixels); per 128-channel slab its 4 waves compute the slab of z0 for those pixels on the MFMA (x0 fragments straight
+// from global memory, loaded once: K = 64; A0 fragments from L2), add the bias in fp32, round to bf16 -- the GEMM epilogue's arithmetic, bit
+// for bit -- and hand the slab over in 32 KiB of LDS ([128 px][128 ch], 16-byte chunks XOR-swizzled by the pixel row); from there on the
+// pass is head_upsum_classify_blk_kernel's: 16 lanes per block, lane `sub` takes channels [slab + 8 sub, + 8), same tap tiles, same sums.
+template <int R1, int R2, int R3, int BH>
+__global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ A0, const bf16_t* __restrict__ zb,
+                                                      const bf16_t* __restrict__ z1, const bf16_t* __restrict__ z2, const bf16_t* __restrict__ z3,
+                                                      const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, float* __restrict__ out,
+                                                      int B, int H0, int W0, int C, int L) {
+    typedef bf16_t T;
+    constexpr int K = 64, NP = 4, V = 8;
+    static_assert(BH == 2, "4 x 2 pixel blocks: 8 GEMM rows per block");
+    __shared__ __attribute__((aligned(16))) unsigned char slab[128 * 256];     // [128 px][256 B]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int sub = tid & 15, bl = tid >> 4;
+    const int bw = W0 / 4, bh = H0 / BH;
+    const long nblk = (long)B * bh * bw;
+    // producer side: GEMM row m = wv * 32 + lr = block (m >> 3), pixel (py, px) = ((m >> 2) & 1, m & 3)
+    u32x4 xf[4];
+    {
+        const int m = wv * 32 + lr;
+        long gm = (long)blockIdx.x * 16 + (m >> 3);
+        gm = gm < nblk ? gm : nblk - 1;
+        const int bxm = (int)(gm % bw), bym = (int)((gm / bw) % bh);
+        const long im = gm / ((long)bw * bh);
+        const bf16_t* xp = x0 + ((im * H0 + BH * bym + ((m >> 2) & 1)) * W0 + 4 * bxm + (m & 3)) * K;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(xp + (ks * 2 + lh) * 8);
+    }
+    // consumer side
+    const long g = (long)blockIdx.x * 16 + bl;
+    const long gc = g < nblk ? g : nblk - 1;
+    const int bx = (int)(gc % bw), by = (int)((gc / bw) % bh);
+    const long img = gc / ((long)bw * bh);
+    float acc[BH][4][2];
+#pragma unroll
+    for (int py = 0; py < BH; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) acc[py][px][l] = 0.f;
+    const long w1off = (long)(L > 1 ? 1 : 0) * C;
+    for (int n0 = 0; n0 < C; n0 += 128) {
+        {   // z0 slab [128 px][128 ch]
+            f32x16 za[4];
+            u32x4 wf[4][4];
+            uint2 braw[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    wf[j][ks] = *reinterpret_cast<const u32x4*>(A0 + (long)(n0 + j * 32 + lr) * K + (ks * 2 + lh) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) braw[j][q] = *reinterpret_cast<const uint2*>(zb + n0 + j * 32 + q * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) za[j][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    za[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[j][ks]), __builtin_bit_cast(bf16x8, xf[ks]), za[j], 0, 0, 0);
+            }
+            const int row = wv * 32 + lr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float bq[4];
+                    load4(reinterpret_cast<const bf16_t*>(&braw[j][q]), bq);
+                    const int chunk = j * 4 + q;
+                    *reinterpret_cast<uint2*>(slab + row * 256 + ((chunk ^ (row & 15)) << 4) + lh * 8) =
+                        make_uint2(pack2(za[j][4 * q] + bq[0], za[j][4 * q + 1] + bq[1]), pack2(za[j][4 * q + 2] + bq[2], za[j][4 * q + 3] + bq[3]));
+                }
+        }
+        __syncthreads();
+        const int c = n0 + sub * V;
+        uint4 zr[BH][4];
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int m = bl * 8 + py * 4 + px;
+                zr[py][px] = *reinterpret_cast<const uint4*>(slab + m * 256 + ((sub ^ (m & 15)) << 4));
+            }
+        UpsumTile<R1, BH> t1; UpsumTile<R2, BH> t2; UpsumTile<R3, BH> t3;
+        upsum_load<T, R1, BH>(t1, z1 + c, img, H0 / R1, W0 / R1, C, by, bx);
+        upsum_load<T, R2, BH>(t2, z2 + c, img, H0 / R2, W0 / R2, C, by, bx);
+        upsum_load<T, R3, BH>(t3, z3 + c, img, H0 / R3, W0 / R3, C, by, bx);
+        const uint4 w0r = *reinterpret_cast<const uint4*>(w + c), w1r = *reinterpret_cast<const uint4*>(w + w1off + c);
+        __syncthreads();                                   // every lane holds its rows of the slab: the next slab may overwrite it
+        f32x2 v[BH][4][NP];
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) UpsumPk<T>::unpack(zr[py][px], v[py][px]);
+        upsum_apply<T, R1, BH, NP>(v, t1, by, bx);
+        upsum_apply<T, R2, BH, NP>(v, t2, by, bx);
+        upsum_apply<T, R3, BH, NP>(v, t3, by, bx);
+        const uint32_t w0u[4] = {w0r.x, w0r.y, w0r.z, w0r.w}, w1u[4] = {w1r.x, w1r.y, w1r.z, w1r.w};
+#pragma unroll
+        for (int py = 0; py < BH; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const f32x2 yv = f32x2{fmaxf(v[py][px][i].x, 0.f), fmaxf(v[py][px][i].y, 0.f)};
+                    const bf16x2_t yb = __builtin_convertvector(yv, bf16x2_t);
+                    acc[py][px][0] = __builtin_amdgcn_fdot2_f32_bf16(yb, __builtin_bit_cast(bf16x2_t, w0u[i]), acc[py][px][0], false);
+                    acc[py][px][1] = __builtin_amdgcn_fdot2_f32_bf16(yb, __builtin_bit_cast(bf16x2_t, w1u[i]), acc[py][px][1], false);
+                }
+    }
+    const long HW = (long)H0 * W0;
+    const float blv[2] = {Ty<T>::ld(bias), Ty<T>::ld(bias + (L > 1 ? 1 : 0))};
+#pragma unroll
+    for (int py = 0; py < BH; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const float a = row16_sum(acc[py][px][l]);
+                if (sub == 0 && g < nblk && l < L) {
+                    const float z = Ty<T>::rnd(a + blv[l]);
+                    out[(img * L + l) * HW + (long)(BH * by + py) * W0 + 4 * bx + px] = Ty<T>::rnd(1.0f / (1.0f + expf(-z)));
+                }
+            }
+}
+
+static inline int launch_head_z0(const bf16_t* x0, const bf16_t* A0, const bf16_t* zb, const bf16_t* z1, const bf16_t* z2, const bf16_t* z3,
+                                 const bf16_t* w, const bf16_t* bias, float* planes, int B, int H0, int W0, int K, int C, int L, hipStream_t s) {
+    if (K != 64 || C % 128 || L > 2 || H0 % 8 || W0 % 8 || !zb) return SA_ERR_SHAPE;
+    const long nblk = (long)B * (H0 / 2) * (W0 / 4);
+    hipLaunchKernelGGL((head_z0_kernel<2, 4, 8, 2>), dim3((unsigned)cdivl(nblk, 16)), dim3(256), 0, s, x0, A0, zb, z1, z2, z3, w, bias, planes, B, H0, W0, C, L);
+    return (int)hipGetLastError();
+}
+template <typename T>
+static inline int launch_head_z0(const T*, const T*, const T*, const T*, const T*, const T*, const T*, const T*, float*, int, int, int, int, int,
+                                 int, hipStream_t) { return SA_ERR_UNSUPPORTED; }
+
+// ---------------------------------------------------------------------------------------------------
+// MBConv tail (encoderdecoder.py:174-225): depthwise 3x3 (+ bias + Hardswish) -> projection 1x1 (+ folded BN bias, + residual).
+// Workgroup = 8 x 16 output pixels x 256 output channels (blockIdx.y picks the 256-column half when Cout = 512: both halves then do the
+// depthwise arithmetic of their pixels), 8 waves in two roles -- one of each on every SIMD, so the vector ALU (depthwise) and the matrix
+// pipe (projection) of a SIMD work at the same time:
+//   producers (waves 4..7): per 64-channel chunk of the expanded tensor the depthwise result of the tile, each thread 4 horizontally
+//     adjacent pixels x 8 channels: inputs straight from global memory (16-byte loads, 8 lanes per 128-byte pixel row), fp32 in
+//     dwconv_tx_kernel's (ky, kx) order with the bias first, Hardswish, round to bf16, into the A tile [128 px][64 ch] in LDS (gemm.h's XOR
+//     swizzle), double buffered. ONE register set of inputs: an input vector is re-requested for the next chunk right after its last
+//     use, so every load has about one chunk of arithmetic (~1500 cycles) to arrive. The chunk's 9 filter taps + bias come through a
+//     two-slot LDS ring (80 threads fetch the next chunk's, one chunk ahead).
+//   consumers (waves 0..3): wave w owns output channels [64 w, 64 w + 64) for all 128 pixels (4 x 2 MFMA tiles, 128 accumulator registers);
+//     its W fragments are its own 64 rows of the projection weight -- no other wave reads them, so they skip LDS -- re-requested for the
+//     next chunk right after use as well.
+//   One s_barrier per chunk: behind it chunk c is complete in buffer c & 1 and every consumer has finished reading chunk c - 1.
+// K order and MFMA are the projection GEMM's (one accumulator per output, K-tiles ascending, kk 0..3): with identical A bits the sums are the
+// GEMM's, and the epilogue repeats its rounding (bias in fp32, round; + residual, round): bit-identical to the two launches it replaces.
+#ifndef SA_DWP_ABL
+#define SA_DWP_ABL 0     // ablation builds (tools/microbench/dwproj_ablate.sh): 1 = producers never re-request inputs, 2 = consumers skip the MFMAs, 4 = producers skip the depthwise arithmetic, 8 = consumers never re-request W
+#endif
+template <int S>
+__global__ __launch_bounds__(512) void dwproj_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wd, const bf16_t* __restrict__ bd,
+                                                     const bf16_t* __restrict__ w2, const bf16_t* __restrict__ b2,
+                                                     const bf16_t* __restrict__ res, bf16_t* __restrict__ out, int H, int W, int Cm, int Ho, int Wo,
+                                                     int Cout, int tiles_x, int tiles_y) {
+    constexpr int CW = 256, TX = 4, NIN = (TX - 1) * S + 3;
+    constexpr int WRING = 65536, WSLOT = 1280;              // LDS: [0, 32 KiB) A tiles; [0, 64 KiB) the output tile (epilogue); then the tap ring
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int n0 = (int)blockIdx.y * CW;
+    // XCD x takes the x-th contiguous eighth of the tile raster (rows that share input rows meet in one L2, see dwconv_tx_kernel)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3, rem = nb & 7;
+    const int bid = (int)(xcd * per + min(xcd, rem) + (blockIdx.x >> 3));
+    const int b = bid / (tiles_x * tiles_y), tr = bid - b * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * 8, ox0 = (tr % tiles_x) * 16;
+    const int nch = Cm / 64;                                 // even (launcher)
+    constexpr int ROWB = CW * 2, CPR = ROWB / 16;            // epilogue tile [128 px][256] bf16, 16-byte chunks XOR-swizzled by the pixel row
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const int dch = pt & 7, dxg = (pt >> 3) & 3, dy = pt >> 5;
+        const int iy0 = (oy0 + dy) * S - 1, ix0 = (ox0 + dxg * TX) * S - 1;
+        const bf16_t* img = in + (long)b * H * W * Cm + dch * 8;
+        int roff[3], coff[NIN];                              // (sums and masks are formed per load: 3 x NIN of each kept live spill)
+        unsigned rmask[3], cmask[NIN];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int iy = iy0 + r; roff[r] = min(max(iy, 0), H - 1) * W * Cm; rmask[r] = (unsigned)iy < (unsigned)H ? 0xffffffffu : 0u; }
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) { const int ix = ix0 + j; coff[j] = min(max(ix, 0), W - 1) * Cm; cmask[j] = (unsigned)ix < (unsigned)W ? 0xffffffffu : 0u; }
+        // tap ring: thread pt < 80 carries 16 bytes of (tap pt >> 3 | bias = row 9), channels (pt & 7) * 8 of the chunk
+        const bool wl = pt < 80;
+        const bf16_t* wsrc = (pt >> 3) < 9 ? wd + (long)(pt >> 3) * Cm + (pt & 7) * 8 : bd + (pt & 7) * 8;
+        u32x4 wld;
+        if (wl) {
+            *reinterpret_cast<u32x4*>(smem + WRING + pt * 16) = *reinterpret_cast<const u32x4*>(wsrc);
+            wld = *reinterpret_cast<const u32x4*>(wsrc + (nch > 1 ? 64 : 0));
+        }
+        u32x4 raw[3][NIN];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) raw[r][j] = *reinterpret_cast<const u32x4*>(img + (roff[r] + coff[j]));
+        __syncthreads();                                     // (P0) tap slot 0 visible
+        for (int c = 0; c < nch; ++c) {
+            const unsigned char* ws = smem + WRING + (c & 1) * WSLOT + dch * 16;
+            // (every re-request below is UNCONDITIONAL, the chunk index clamped at the tail: behind `if (more)` hipcc branches around each load
+            // and drains vmcnt(0) per element -- the first ISA of this loop had 27 branches per chunk)
+            if (wl) {
+                *reinterpret_cast<u32x4*>(smem + WRING + ((c + 1) & 1) * WSLOT + pt * 16) = wld;      // chunk c + 1's taps (visible behind this chunk's barrier)
+                wld = *reinterpret_cast<const u32x4*>(wsrc + min(c + 2, nch - 1) * 64);
+            }
+            f32x2 a2[TX][4];
+            {
+                f32x2 bv[4];
+                UpsumPk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(ws + 9 * 128), bv);
+#pragma unroll
+                for (int o = 0; o < TX; ++o)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a2[o][e] = bv[e];
+            }
+            const int cn = min(c + 1, nch - 1) * 64;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                f32x2 w3[3][4];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) UpsumPk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(ws + (ky * 3 + kx) * 128), w3[kx]);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const unsigned m = rmask[ky] & cmask[j];
+                    f32x2 x[4];
+                    UpsumPk<bf16_t>::unpack(make_uint4(raw[ky][j][0] & m, raw[ky][j][1] & m, raw[ky][j][2] & m, raw[ky][j][3] & m), x);
+                    if constexpr (!(SA_DWP_ABL & 1)) raw[ky][j] = *reinterpret_cast<const u32x4*>(img + (roff[ky] + coff[j] + cn));       // its last use was the line above
+#pragma unroll
+                    for (int o = 0; o < TX; ++o) {
+                        const int kx = j - o * S;
+                        if (kx >= 0 && kx < 3) {
+                            if constexpr (SA_DWP_ABL & 4) { if (kx == 0 && ky == 0) a2[o][0] += x[0]; }
+                            else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a2[o][e] += x[e] * w3[kx][e];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < TX; ++o) {
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = a2[o][e].x, v1 = a2[o][e].y;
+                    r[2 * e] = hardswish_f(v0);
+                    r[2 * e + 1] = hardswish_f(v1);
+                }
+                const int row = dy * 16 + dxg * TX + o;
+                *reinterpret_cast<uint4*>(smem + (c & 1) * 16384 + row * 128 + ((dch ^ ((row >> 1) & 7)) << 4)) =
+                    make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
+            }
+            __syncthreads();                                 // (B_c) chunk c is in buffer c & 1
+        }
+        __syncthreads();                                     // (E1)
+    } else {
+        // ------------------------------------------------------------------ consumers
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+        const bf16_t* w2p = w2 + (long)(n0 + wv * 64 + lr) * Cm + lh * 8;
+        // W fragments: two named sets; all eight 16-byte loads of the NEXT chunk are issued in one burst at the top of a chunk (the four
+        // loads of a 128-byte weight row then meet in L1; spread over the chunk, one per kk, every one of them went to L2 again)
+        u32x4 wa[2][4], wb[2][4];
+#define DP_LW(WF, C0)                                                                                                   \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                         \
+                WF[j_][kk_] = *reinterpret_cast<const u32x4*>(w2p + (long)j_ * 32 * Cm + (C0) + kk_ * 16);              \
+    }
+#define DP_MM(WF, BUF)                                                                                                  \
+    {                                                                                                                   \
+        const unsigned char* at_ = smem + (BUF) * 16384;                                                                \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                           \
+            u32x4 xf_[4];                                                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+                const int row_ = i_ * 32 + lr;                                                                          \
+                xf_[i_] = *reinterpret_cast<const u32x4*>(at_ + row_ * 128 + (((kk_ * 2 + lh) ^ ((row_ >> 1) & 7)) << 4)); \
+            }                                                                                                           \
+            if constexpr (SA_DWP_ABL & 2) { asm volatile("" :: "v"(xf_[0]), "v"(xf_[1]), "v"(xf_[2]), "v"(xf_[3]), "v"(WF[0][kk_]), "v"(WF[1][kk_])); } else \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                            \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                        \
+                    acc[j_][i_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_][kk_]), __builtin_bit_cast(bf16x8, xf_[i_]), acc[j_][i_], 0, 0, 0); \
+        }                                                                                                               \
+    }
+        DP_LW(wa, 0);
+        if constexpr (SA_DWP_ABL & 8) DP_LW(wb, 0);
+        __syncthreads();                                     // (P0)
+        for (int c = 0; c < nch; c += 2) {                   // nch is even
+            if constexpr (!(SA_DWP_ABL & 8)) DP_LW(wb, (c + 1) * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // (B_c)
+            DP_MM(wa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(SA_DWP_ABL & 8)) DP_LW(wa, min(c + 2, nch - 1) * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // (B_c+1)
+            DP_MM(wb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DP_LW
+#undef DP_MM
+        // ---- epilogue through LDS; then whole rows out, residual added on the way
+        __syncthreads();                                     // (E1) every consumer is done with the A tiles
+        float bq[2][4][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load4(b2 + n0 + wv * 64 + j * 32 + q * 8 + lh * 4, bq[j][q]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 32 + lr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int chunk = (wv * 64 + j * 32 + q * 8) >> 3;
+                    *reinterpret_cast<uint2*>(smem + row * ROWB + ((chunk ^ (row & 31)) << 4) + lh * 8) =
+                        make_uint2(pack2(acc[j][i][4 * q] + bq[j][q][0], acc[j][i][4 * q + 1] + bq[j][q][1]),
+                                   pack2(acc[j][i][4 * q + 2] + bq[j][q][2], acc[j][i][4 * q + 3] + bq[j][q][3]));
+                }
+        }
+    }
+    __syncthreads();                                         // (E2)
+    for (int id = tid; id < 128 * CPR; id += 512) {
+        const int row = id / CPR, cc = id % CPR;
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        if (oy >= Ho || ox >= Wo) continue;
+        const uint4 rawo = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((cc ^ (row & 31)) << 4));
+        const long off = (((long)b * Ho + oy) * Wo + ox) * Cout + n0 + cc * 8;
+        if (res) {
+            float a[8], r8[8];
+            unpack16(rawo, a, (bf16_t*)nullptr);
+            unpack16(*reinterpret_cast<const uint4*>(res + off), r8, (bf16_t*)nullptr);
+            store4(out + off, a[0] + r8[0], a[1] + r8[1], a[2] + r8[2], a[3] + r8[3]);
+            store4(out + off + 4, a[4] + r8[4], a[5] + r8[5], a[6] + r8[6], a[7] + r8[7]);
+        } else {
+            *reinterpret_cast<uint4*>(out + off) = rawo;
+        }
+    }
+}
+
+static inline int launch_dwproj(const bf16_t* in, const bf16_t* wd, const bf16_t* bd, int act, const bf16_t* w2, const bf16_t* b2, const bf16_t* res,
+                                bf16_t* out, int B, int H, int W, int Cm, int Ho, int Wo, int Cout, int stride, hipStream_t s) {
+    if (Cm % 128 || (Cout != 256 && Cout != 512) || (stride != 1 && stride != 2) || (long)B * H * W * Cm >= (1L << 31) || act != ACT_HSWISH) return SA_ERR_SHAPE;
+    const int tx = cdiv(Wo, 16), ty = cdiv(Ho, 8);
+    const unsigned grid = (unsigned)(B * tx * ty);
+#define SA_DWPROJ(SS)                                                                                                           \
+    {                                                                                                                           \
+        constexpr size_t lds = 65536 + 2 * 1280;                                                                                \
+        auto kern = dwproj_kernel<SS>;                                                                                          \
+        static AttrOnce attr;                                                                                                   \
+        attr.ensure(kern, lds);                                                                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid, Cout / 256), dim3(512), lds, s, in, wd, bd, w2, b2, res, out, H, W, Cm, Ho, Wo, Cout, tx, ty); \
+    }
+    if (stride == 1) SA_DWPROJ(1) else SA_DWPROJ(2)
+#undef SA_DWPROJ
+    return (int)hipGetLastError();
+}
+template <typename T>
+static inline int launch_dwproj(const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int, int, int, int, int, int, int, int,
+                                hipStream_t) { return SA_ERR_UNSUPPORTED; }
+
+// ---------------------------------------------------------------------------------------------------
+// FusedMBConv (3x3 expand + Hardswish + 1x1 projection): see below (fmb_*). Shapes the kernel takes:
+static inline bool fmb_shape_ok(int cin, int mid, int cout, int stride, int ho, int wo) {
+    (void)cin; (void)mid; (void)cout; (void)stride; (void)ho; (void)wo;
+    return false;
+}
+template <typename T>
+static inline int launch_fmb(const T*, const T*, const T*, const T*, const T*, const T*, T*, const T*, int, int, int, int, int, int, int, int, int, int,
+                             int, hipStream_t) { return SA_ERR_UNSUPPORTED; }
+
+}  // namespace sa

@@ -9,6 +9,7 @@
 
 #include "../../include/surya_amd.h"
 #include "det_kernels.h"
+#include "det_fused.h"
 #include "det_post.h"
 #include "resample.h"
 
@@ -17,7 +18,8 @@ namespace sa {
 struct DetBase {
     virtual ~DetBase() {}
     virtual int forward(const float* pixels, const unsigned char* pixels_u8, const float* mean_std, int B, float* heat, float* lowres,
-                        hipStream_t s, int pix = 3) = 0;
+                        hipStream_t s, int pix = 3, float* op_ms = nullptr) = 0;
+    virtual int n_ops() const = 0;
 };
 
 template <typename T>
@@ -31,6 +33,7 @@ struct DetModel : DetBase {
     T* zero_page = nullptr;              // 256 zero bytes: source of the convolution gather outside the image
     char* arena = nullptr;
     int max_batch = 0, H = 0, W = 0, labels = 0, in_cp = 8;
+    std::vector<hipEvent_t> evs;         // per-op timing (surya_det_forward_timed): one event in front of every op + one behind the last
 
     int init(const surya_det_config& c, const surya_det_op* o, const void* const* weights, int n_weights, const size_t* be,
              int n_bufs) {
@@ -59,18 +62,88 @@ struct DetModel : DetBase {
         for (int i = 0; i < n_bufs; ++i) bufs[i] = reinterpret_cast<T*>(arena + offs[i]);
         planes = reinterpret_cast<float*>(arena + planes_off);
         kvp = reinterpret_cast<float*>(arena + kvp_off);
+        find_fusions();
         return SA_OK;
     }
-    ~DetModel() override { if (arena) (void)hipFree(arena); }
+    ~DetModel() override {
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        if (arena) (void)hipFree(arena);
+    }
 
     const T* WT(int idx) const { return idx < 0 ? nullptr : reinterpret_cast<const T*>(w[idx]); }
 
+    int n_ops() const override { return (int)ops.size(); }
+
+    // ---- fused forms (round 6), found once by a peephole pass over the op list. The list itself is unchanged (every op still owns its
+    // output buffer), so sa::Tuning::det_fuse can switch each form on and off at run time: the op-by-op path stays the checker of
+    // tests/test_gpu_det_fused.py and the A/B arm of tools/det_op_times.py.
+    //   bit 0  depthwise 5x5 + grouped 1x1 of LiteMLA's multi-scale branch in one kernel (the depthwise result lives in LDS only)
+    //   bit 1  LiteMLA's kv reduction and output in one launch per (image, head) on the fp32 MFMA
+    //   bit 2  the full-resolution stage's 1x1 convolution z0 inside the sum + classify pass (the [P, 512] tensor is never written)
+    //   bit 3  MBConv's depthwise 3x3 + projection 1x1 in one kernel (the depthwise result is the projection's A operand, in LDS only)
+    //   bit 4  FusedMBConv's 3x3 expand + Hardswish + 1x1 projection in one kernel (the expanded tensor exists per 64-channel chunk, in registers / LDS only)
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16 };
+    std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
+    std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
+
+    void find_fusions() {
+        const int n = (int)ops.size();
+        fuse_kind.assign(n, 0); fuse_with.assign(n, -1);
+        constexpr bool BF = std::is_same<T, bf16_t>::value;
+        for (int i = 0; i < n; ++i) {
+            const surya_det_op& a = ops[i];
+            if (a.type == SA_DET_LITEMLA && a.p0 == 32) fuse_kind[i] = FUSE_MLA_ATTN;
+            if (!BF || i + 1 >= n) continue;
+            const surya_det_op& b = ops[i + 1];
+            if (a.type == SA_DET_DWCONV && a.k == 5 && a.stride == 1 && a.b_idx < 0 && a.act == SA_ACT_NONE && b.type == SA_DET_GROUPED1X1 &&
+                b.in0 == a.out && b.p0 == 32 && a.cin % 32 == 0) { fuse_kind[i] = FUSE_MLA_AGG; fuse_with[i] = i + 1; }
+            if (a.type == SA_DET_DWCONV && a.k == 3 && (a.stride == 1 || a.stride == 2) && b.type == SA_DET_CONV && b.k == 1 && b.stride == 1 &&
+                b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && a.cin % 128 == 0 && (b.cout == 256 || b.cout == 512) && b.b_idx >= 0 &&
+                a.b_idx >= 0 && a.act == SA_ACT_HSWISH) { fuse_kind[i] = FUSE_DWPROJ; fuse_with[i] = i + 1; }
+            if (a.type == SA_DET_CONV && a.k == 3 && a.act == SA_ACT_HSWISH && a.res < 0 && b.type == SA_DET_CONV && b.k == 1 && b.stride == 1 &&
+                b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && fmb_supported(a, b)) { fuse_kind[i] = FUSE_FMB; fuse_with[i] = i + 1; }
+        }
+        // the folded head: UPSUM_CLASSIFY whose full-resolution operand comes from a plain 1x1 convolution
+        for (int j = 0; j < n && BF; ++j) {
+            if (ops[j].type != SA_DET_UPSUM_CLASSIFY) continue;
+            int srcs = 0, r_ok = 1, prod = -1;
+            for (int i = j - 1; i >= 0 && ops[i].type == SA_DET_UPSUM_SRC; --i) ++srcs;
+            for (int k = 0; k < srcs; ++k) {                // the addends are declared finest first: addend k is 2 << k times coarser
+                const surya_det_op& u = ops[j - srcs + k];
+                r_ok &= u.hin * (2 << k) == ops[j].hin && u.win * (2 << k) == ops[j].win;
+            }
+            for (int i = 0; i < j; ++i) if (ops[i].type == SA_DET_CONV && ops[i].out == ops[j].in0) prod = i;
+            if (prod < 0 || srcs != 3 || !r_ok) continue;
+            const surya_det_op& c = ops[prod];
+            bool only_reader = true;
+            for (int i = 0; i < n; ++i) if (i != j && (ops[i].in0 == c.out || ops[i].in1 == c.out || ops[i].res == c.out)) only_reader = false;
+            if (c.k == 1 && c.stride == 1 && c.act == SA_ACT_NONE && c.res < 0 && c.p1 == c.cin && c.cin == 64 && c.cout % 128 == 0 && c.cout <= 1024 &&
+                ops[j].cout <= 2 && ops[j].hin % 8 == 0 && ops[j].win % 8 == 0 && only_reader) { fuse_kind[j] = FUSE_HEAD_Z0; fuse_with[j] = prod; }
+        }
+    }
+    static bool fmb_supported(const surya_det_op& a, const surya_det_op& b) { return fmb_shape_ok(a.cin, a.cout, b.cout, a.stride, a.hout, a.wout); }
+
     int forward(const float* pixels, const unsigned char* pixels_u8, const float* ms, int B, float* heat, float* lowres,
-                hipStream_t s, int pix = 3) override {
+                hipStream_t s, int pix = 3, float* op_ms = nullptr) override {
         if (B <= 0 || B > max_batch) return SA_ERR_ARG;
         int rc;
+        const int fuse = tuning().det_fuse;
+        const int n = (int)ops.size();
+        if (op_ms && (int)evs.size() < n + 1) {
+            const size_t have = evs.size();
+            evs.resize(n + 1);
+            for (size_t i = have; i < evs.size(); ++i) SA_HIP(hipEventCreate(&evs[i]));
+        }
         UpsumSrc upsum{};                                   // low-resolution addends declared for the next SA_DET_UPSUM_CLASSIFY
-        for (const surya_det_op& op : ops) {
+        for (int oi = 0; oi < n; ++oi) {
+            const surya_det_op& op = ops[oi];
+            if (op_ms) SA_HIP(hipEventRecord(evs[oi], s));
+            // an op folded into a fused form that is switched on does not run
+            bool skip = false;
+            if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) skip = true;
+            for (int j = oi + 1; j < n && !skip; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) skip = true;
+            if (skip) continue;
+            const int fk = fuse_kind[oi] & fuse;
             switch (op.type) {
                 case SA_DET_UPSUM_SRC: {
                     if (upsum.n >= 3) return SA_ERR_UNSUPPORTED;
@@ -81,6 +154,18 @@ struct DetModel : DetBase {
                 case SA_DET_UPSUM_CLASSIFY: {
                     const long HWl = (long)op.hin * op.win, P = (long)B * HWl;
                     if (op.cin % Ty<T>::V16 || op.cout > 4) return SA_ERR_SHAPE;
+                    if constexpr (std::is_same<T, bf16_t>::value) {
+                        if (fk == FUSE_HEAD_Z0 && upsum.n == 3) {
+                            const surya_det_op& zc = ops[fuse_with[oi]];
+                            if ((rc = launch_head_z0(bufs[zc.in0], WT(zc.w_idx), WT(zc.b_idx), reinterpret_cast<const T*>(upsum.p[0]),
+                                                     reinterpret_cast<const T*>(upsum.p[1]), reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx),
+                                                     WT(op.b_idx), planes, B, op.hin, op.win, zc.cin, op.cin, op.cout, s))) return rc;
+                            upsum.n = 0;
+                            if (lowres)
+                                SA_HIP(hipMemcpyAsync(lowres, planes, (size_t)P * op.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                            break;
+                        }
+                    }
                     // the register-blocked kernel takes addends exactly 2 / 4 / 8 times coarser (every shipped configuration: the stage
                     // strides are 2) and <= 2 labels; anything else runs the per-pixel kernel
                     bool blk = tuning().det_head_blk && upsum.n == 3 && op.cout <= 2 && op.hin % 8 == 0 && op.win % 8 == 0;
@@ -120,6 +205,15 @@ struct DetModel : DetBase {
                     break;
                 }
                 case SA_DET_CONV: {
+                    if constexpr (std::is_same<T, bf16_t>::value) {
+                        if (fk == FUSE_FMB) {
+                            const surya_det_op& pj = ops[fuse_with[oi]];
+                            if ((rc = launch_fmb(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(pj.w_idx), WT(pj.b_idx), pj.res >= 0 ? bufs[pj.res] : nullptr,
+                                                 bufs[pj.out], zero_page, B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, pj.cout, op.stride, op.p0,
+                                                 op.p1, s))) return rc;
+                            break;
+                        }
+                    }
                     if (op.k == 1 && op.stride == 1 && op.cin % Ty<T>::KE == 0 && op.p1 == op.cin) {
                         // 1x1 convolution on NHWC == plain NT GEMM over the B*H*W pixel rows: no gather arithmetic, XCD-aware
                         // tile order (55 % of the network's FLOPs go this way)
@@ -138,6 +232,20 @@ struct DetModel : DetBase {
                     break;
                 }
                 case SA_DET_DWCONV: {
+                    if constexpr (std::is_same<T, bf16_t>::value) {
+                        if (fk == FUSE_MLA_AGG) {
+                            const surya_det_op& gp = ops[fuse_with[oi]];
+                            if ((rc = launch_dw5_g1x1(bufs[op.in0], WT(op.w_idx), WT(gp.w_idx), bufs[gp.out], B, op.hin, op.win, op.cin, s))) return rc;
+                            break;
+                        }
+                        if (fk == FUSE_DWPROJ) {
+                            const surya_det_op& pj = ops[fuse_with[oi]];
+                            if ((rc = launch_dwproj(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), op.act, WT(pj.w_idx), WT(pj.b_idx),
+                                                    pj.res >= 0 ? bufs[pj.res] : nullptr, bufs[pj.out], B, op.hin, op.win, op.cin, op.hout, op.wout,
+                                                    pj.cout, op.stride, s))) return rc;
+                            break;
+                        }
+                    }
                     constexpr int TX = 4;
                     const long nt = (long)B * op.hout * cdiv(op.wout, TX) * (op.cin / Ty<T>::V16);
 #define SA_DWTX(KK, SS)                                                                                                     \
@@ -172,7 +280,10 @@ struct DetModel : DetBase {
                 case SA_DET_LITEMLA: {
                     const int HW = op.hin * op.win, heads = op.cout / op.p0, heads_a = heads / 2;
                     dim3 grid(B, heads, cdiv(HW, LITEMLA_CHUNK));
-                    if (op.p0 == 32) {
+                    if (fk == FUSE_MLA_ATTN) {
+                        hipLaunchKernelGGL((litemla_fused_kernel<T, 32>), dim3(heads, B), dim3(256), 0, s, bufs[op.in0], bufs[op.in1], bufs[op.out],
+                                           HW, heads_a, heads, 1e-5f);
+                    } else if (op.p0 == 32) {
                         hipLaunchKernelGGL((litemla_kv_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, HW, heads_a, heads);
                         hipLaunchKernelGGL((litemla_out_kernel<T, 32>), grid, dim3(256), 0, s, bufs[op.in0], bufs[op.in1], kvp, bufs[op.out],
                                            HW, heads_a, heads, 1e-5f);
@@ -209,6 +320,24 @@ struct DetModel : DetBase {
                 default: return SA_ERR_UNSUPPORTED;
             }
             if ((rc = (int)hipGetLastError())) return rc;
+        }
+        if (op_ms) {
+            // per-op event times: op i = [event i, the next recorded event); ops that did not run (folded into a fused form) report 0
+            SA_HIP(hipEventRecord(evs[n], s));
+            SA_HIP(hipEventSynchronize(evs[n]));
+            std::vector<int> ran;
+            for (int oi = 0; oi < n; ++oi) {
+                bool skip = false;
+                if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) skip = true;
+                for (int j = oi + 1; j < n && !skip; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) skip = true;
+                op_ms[oi] = 0.f;
+                if (!skip) ran.push_back(oi);
+            }
+            for (size_t k = 0; k < ran.size(); ++k) {
+                float ms_ = 0.f;
+                SA_HIP(hipEventElapsedTime(&ms_, evs[ran[k]], evs[k + 1 < ran.size() ? ran[k + 1] : n]));
+                op_ms[ran[k]] = ms_;
+            }
         }
         return SA_OK;
     }
@@ -269,6 +398,14 @@ int surya_det_boxes(const float* heat, long page_stride, int batch, int height, 
 int surya_det_forward(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream) {
     if (!h || !pixel_values || (!heatmaps && !lowres)) return SA_ERR_ARG;
     return h->impl->forward(pixel_values, nullptr, nullptr, batch, heatmaps, lowres, (hipStream_t)stream);
+}
+
+int surya_det_op_count(surya_det* h) { return h ? h->impl->n_ops() : SA_ERR_ARG; }
+
+int surya_det_forward_timed(surya_det* h, const float* pixel_values, int batch, float* heatmaps, float* lowres, void* stream, float* op_ms,
+                            int n_op_ms) {
+    if (!h || !pixel_values || (!heatmaps && !lowres) || !op_ms || n_op_ms < h->impl->n_ops()) return SA_ERR_ARG;
+    return h->impl->forward(pixel_values, nullptr, nullptr, batch, heatmaps, lowres, (hipStream_t)stream, 3, op_ms);
 }
 
 int surya_det_forward_u8(surya_det* h, const uint8_t* pixels_nhwc, int pixel_stride, const float* mean, const float* std, int batch,

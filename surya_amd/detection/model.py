@@ -34,6 +34,7 @@ class HipDetModel:
         self.executed_flops_per_image = plan.flops_per_image
         from .plan import OP_LITEMLA, OP_UPSUM_SRC
         self.launches_per_forward = sum(2 if o["type"] == OP_LITEMLA else (0 if o["type"] == OP_UPSUM_SRC else 1) for o in plan.ops)
+        self.plan_ops = [dict(o) for o in plan.ops]
         self.weights = [w.to(device=self.device, dtype=dtype).contiguous() for w in plan.weights]
         if broadcast_weights:             # every rank planned the op list (shapes); the folded weights used are rank 0's
             from .. import dist as sdist
@@ -43,7 +44,7 @@ class HipDetModel:
                 sdist.broadcast_tensors(tmp, src=0, group=process_group)
                 for w, t in zip(self.weights, tmp):
                     w.copy_(t)
-        ops = (DetOpC * len(plan.ops))(*[DetOpC(**o) for o in plan.ops])
+        ops = (DetOpC * len(plan.ops))(*[DetOpC(**{k: v for k, v in o.items() if k != "tag"}) for o in plan.ops])
         table = (C.c_void_p * len(self.weights))(*[w.data_ptr() for w in self.weights])
         bufs = (C.c_size_t * len(plan.buf_elems))(*plan.buf_elems)
         c = L.DetConfigC(n_ops=len(plan.ops), max_batch=max_batch, height=height, width=width, num_labels=cfg.num_labels,
@@ -86,6 +87,20 @@ class HipDetModel:
         L.check(self.lib.surya_det_forward(self.handle, L.ptr(pixel_values), C.c_int(B), L.ptr(heat), L.ptr(low), stream),
                 "surya_det_forward")
         return (heat, low) if want_lowres else heat
+
+    def forward_timed(self, pixel_values: torch.Tensor):
+        """Measurement support (surya_det_forward_timed): the same forward with a hipEvent in front of every op of the plan.
+        Returns (heat maps, [(op dict, ms)]); ops folded into a fused form (sa::Tuning det_fuse) report 0 ms."""
+        assert pixel_values.is_cuda and pixel_values.dtype == torch.float32 and pixel_values.is_contiguous()
+        B = pixel_values.shape[0]
+        torch.cuda.set_device(self.device)
+        heat = torch.empty((B, self.cfg.num_labels, self.height, self.width), dtype=torch.float32, device=self.device)
+        n = int(self.lib.surya_det_op_count(self.handle))
+        ms = (C.c_float * n)()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.surya_det_forward_timed(self.handle, L.ptr(pixel_values), C.c_int(B), L.ptr(heat), L.ptr(None), stream, ms, C.c_int(n)),
+                "surya_det_forward_timed")
+        return heat, list(zip(self.plan_ops, [float(v) for v in ms]))
 
     def forward_u8(self, pages_u8: torch.Tensor, mean, std, want_lowres: bool = False):
         """pages cuda uint8 [B, H, W, 3 | 4] (RGB or RGBX, already at the processor size) -> heat maps; rescale + normalise run

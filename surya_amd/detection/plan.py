@@ -64,7 +64,7 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
     eps = cfg.layer_norm_eps
     CP = 8                                                   # input channels padded 3 -> 8 (16-byte NHWC pixels)
 
-    def conv(x, hw, cin, prefix, k, stride, act, res=-1, wb=None, cin_pad=None):
+    def conv(x, hw, cin, prefix, k, stride, act, res=-1, wb=None, cin_pad=None, tag="conv"):
         """Dense conv op on buffer x ([h, w, cin] per image). Returns (out buf, (ho, wo), cout)."""
         w, b = wb if wb is not None else _fold(sd, prefix, eps)
         cout = w.shape[0]
@@ -79,38 +79,38 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
         out = pl.new_buf(ho * wo * cout)
         pl.ops.append(dict(type=OP_CONV, in0=x, in1=-1, out=out, res=res, cin=cin_pad, cout=cout, k=k, stride=stride, act=act,
                            hin=hw[0], win=hw[1], hout=ho, wout=wo, w_idx=pl.add_weight(wflat),
-                           b_idx=pl.add_weight(b) if b is not None else -1, p0=pad, p1=wflat.shape[1]))
+                           b_idx=pl.add_weight(b) if b is not None else -1, p0=pad, p1=wflat.shape[1], tag=tag))
         pl.flops_per_image += 2.0 * ho * wo * cout * k * k * w.shape[1]
         return out, (ho, wo), cout
 
-    def dwconv(x, hw, c, w, b, k, stride, act):
+    def dwconv(x, hw, c, w, b, k, stride, act, tag="mb_dw"):
         pad = ((stride - 1) + (k - 1)) // 2 if k == 3 else k // 2
         ho, wo = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
         out = pl.new_buf(ho * wo * c)
         pl.ops.append(dict(type=OP_DWCONV, in0=x, in1=-1, out=out, res=-1, cin=c, cout=c, k=k, stride=stride, act=act, hin=hw[0],
                            win=hw[1], hout=ho, wout=wo, w_idx=pl.add_weight(w.reshape(c, k * k).t()),
-                           b_idx=pl.add_weight(b) if b is not None else -1, p0=pad, p1=0))
+                           b_idx=pl.add_weight(b) if b is not None else -1, p0=pad, p1=0, tag=tag))
         pl.flops_per_image += 2.0 * ho * wo * c * k * k
         return out, (ho, wo)
 
     def fused_mbconv(x, hw, cin, p, stride, res):
-        y, hw2, mid = conv(x, hw, cin, p + ".spatial_conv", 3, stride, ACT_HSWISH)
-        return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res)
+        y, hw2, mid = conv(x, hw, cin, p + ".spatial_conv", 3, stride, ACT_HSWISH, tag="fmb_3x3")
+        return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res, tag="fmb_proj")
 
     def mbconv(x, hw, cin, p, stride, res):
         wd, bd = _fold(sd, p + ".depth_conv", eps)
-        y, hw1, mid = conv(x, hw, cin, p + ".inverted_conv", 1, 1, ACT_HSWISH)
-        y, hw2 = dwconv(y, hw1, mid, wd, bd, 3, stride, ACT_HSWISH)
-        return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res)
+        y, hw1, mid = conv(x, hw, cin, p + ".inverted_conv", 1, 1, ACT_HSWISH, tag="mb_expand")
+        y, hw2 = dwconv(y, hw1, mid, wd, bd, 3, stride, ACT_HSWISH, tag="mb_dw")
+        return conv(y, hw2, mid, p + ".point_conv", 1, 1, ACT_NONE, res=res, tag="mb_proj")
 
     x = pl.new_buf(height * width * CP)
     pl.ops.append(dict(type=OP_INPUT, in0=-1, in1=-1, out=x, res=-1, cin=cfg.num_channels, cout=CP, k=0, stride=0, act=0,
-                       hin=height, win=width, hout=height, wout=width, w_idx=-1, b_idx=-1, p0=0, p1=0))
-    x, hw, c = conv(x, (height, width), cfg.num_channels, "vit.stem.in_conv", 3, cfg.strides[0], ACT_HSWISH, cin_pad=CP)
+                       hin=height, win=width, hout=height, wout=width, w_idx=-1, b_idx=-1, p0=0, p1=0, tag="input"))
+    x, hw, c = conv(x, (height, width), cfg.num_channels, "vit.stem.in_conv", 3, cfg.strides[0], ACT_HSWISH, cin_pad=CP, tag="stem")
     for r in range(cfg.depths[0]):
         p = f"vit.stem.res{r}.main"
-        y, _, _ = conv(x, hw, c, p + ".conv1", 3, 1, ACT_HSWISH)
-        x, hw, c = conv(y, hw, c, p + ".conv2", 3, 1, ACT_NONE, res=x)
+        y, _, _ = conv(x, hw, c, p + ".conv1", 3, 1, ACT_HSWISH, tag="stem")
+        x, hw, c = conv(y, hw, c, p + ".conv2", 3, 1, ACT_NONE, res=x, tag="stem")
     feats: List[Tuple[int, Tuple[int, int], int]] = []
     for si, depth in enumerate(cfg.depths[1:]):
         vit_stage, fewer = si >= 3, si >= 2
@@ -120,19 +120,20 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
             if vit_stage:
                 cp = f"vit.stages.{si}.blocks.{bi}.context_module.main"
                 dim = cfg.head_dim
-                q, _, td3 = conv(x, hw, c, cp + ".qkv", 1, 1, ACT_NONE)
-                a0, _ = dwconv(q, hw, td3, sd[cp + ".aggreg.0.0.weight"].float(), None, 5, 1, ACT_NONE)
+                q, _, td3 = conv(x, hw, c, cp + ".qkv", 1, 1, ACT_NONE, tag="mla_qkv")
+                a0, _ = dwconv(q, hw, td3, sd[cp + ".aggreg.0.0.weight"].float(), None, 5, 1, ACT_NONE, tag="mla_dw5")
                 a1 = pl.new_buf(hw[0] * hw[1] * td3)
                 pl.ops.append(dict(type=OP_GROUPED1X1, in0=a0, in1=-1, out=a1, res=-1, cin=td3, cout=td3, k=1, stride=1, act=0,
                                    hin=hw[0], win=hw[1], hout=hw[0], wout=hw[1],
-                                   w_idx=pl.add_weight(sd[cp + ".aggreg.0.1.weight"].float().reshape(td3, dim)), b_idx=-1, p0=dim, p1=0))
+                                   w_idx=pl.add_weight(sd[cp + ".aggreg.0.1.weight"].float().reshape(td3, dim)), b_idx=-1, p0=dim, p1=0,
+                                   tag="mla_g1x1"))
                 pl.flops_per_image += 2.0 * hw[0] * hw[1] * td3 * dim
                 td2 = 2 * td3 // 3
                 att = pl.new_buf(hw[0] * hw[1] * td2)
                 pl.ops.append(dict(type=OP_LITEMLA, in0=q, in1=a1, out=att, res=-1, cin=td3, cout=td2, k=0, stride=0, act=0, hin=hw[0],
-                                   win=hw[1], hout=hw[0], wout=hw[1], w_idx=-1, b_idx=-1, p0=dim, p1=0))
+                                   win=hw[1], hout=hw[0], wout=hw[1], w_idx=-1, b_idx=-1, p0=dim, p1=0, tag="mla_attn"))
                 pl.flops_per_image += 2.0 * 2 * hw[0] * hw[1] * (td2 // dim) * dim * (dim + 1)
-                x, _, _ = conv(att, hw, td2, cp + ".proj", 1, 1, ACT_NONE, res=x)
+                x, _, _ = conv(att, hw, td2, cp + ".proj", 1, 1, ACT_NONE, res=x, tag="mla_proj")
                 x, hw, c = mbconv(x, hw, c, f"vit.stages.{si}.blocks.{bi}.local_module.main", 1, x)
             else:
                 p = f"vit.stages.{si}.blocks.{bi}.main"
@@ -167,27 +168,27 @@ def build_det_plan(cfg: DetConfig, sd: Dict[str, torch.Tensor], height: int, wid
             zs.append((a_s, fb, fhw, fc))
         z_bufs = []
         for i, (a_s, fb, fhw, fc) in enumerate(zs):
-            z, _, ch = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(a_s.reshape(a_s.shape[0], fc, 1, 1), c_all if i == 0 else None))
+            z, _, ch = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(a_s.reshape(a_s.shape[0], fc, 1, 1), c_all if i == 0 else None), tag="head_z")
             z_bufs.append((z, fhw))
         for z, fhw in z_bufs[1:]:
             pl.ops.append(dict(type=OP_UPSUM_SRC, in0=z, in1=-1, out=-1, res=-1, cin=ch, cout=ch, k=0, stride=0, act=0, hin=fhw[0],
-                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=0, p1=0))
+                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=0, p1=0, tag="head"))
         y = z_bufs[0][0]
         pl.flops_per_image += sum(8.0 * h0 * w0 * ch for _ in z_bufs[1:])                # 4 taps, multiply-add, per addend
     else:
         cat = pl.new_buf(h0 * w0 * dl * nst)
         for i, (fb, fhw, fc) in enumerate(feats):
             wl = sd[f"decode_head.linear_c.{i}.proj.weight"].float().reshape(dl, fc, 1, 1)
-            y, _, _ = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(wl, sd[f"decode_head.linear_c.{i}.proj.bias"].float()))
+            y, _, _ = conv(fb, fhw, fc, None, 1, 1, ACT_NONE, wb=(wl, sd[f"decode_head.linear_c.{i}.proj.bias"].float()), tag="head_z")
             pl.ops.append(dict(type=OP_UPCAT, in0=y, in1=-1, out=cat, res=-1, cin=dl, cout=dl * nst, k=0, stride=0, act=0, hin=fhw[0],
-                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=(nst - 1 - i) * dl, p1=0))   # cat(...[::-1]) :715
-        y, _, ch = conv(cat, (h0, w0), dl * nst, None, 1, 1, ACT_RELU, wb=(wf * scale.view(-1, 1, 1, 1), bf))
+                               win=fhw[1], hout=h0, wout=w0, w_idx=-1, b_idx=-1, p0=(nst - 1 - i) * dl, p1=0, tag="head"))   # cat(...[::-1]) :715
+        y, _, ch = conv(cat, (h0, w0), dl * nst, None, 1, 1, ACT_RELU, wb=(wf * scale.view(-1, 1, 1, 1), bf), tag="head_z")
     L = cfg.num_labels
     pl.ops.append(dict(type=OP_UPSUM_CLASSIFY if folded else OP_CLASSIFY, in0=y, in1=-1, out=-1, res=-1, cin=ch, cout=L, k=1, stride=1, act=0, hin=h0, win=w0,
                        hout=h0, wout=w0, w_idx=pl.add_weight(sd["decode_head.classifier.weight"].float().reshape(L, ch)),
-                       b_idx=pl.add_weight(sd["decode_head.classifier.bias"].float()), p0=0, p1=0))
+                       b_idx=pl.add_weight(sd["decode_head.classifier.bias"].float()), p0=0, p1=0, tag="head"))
     pl.flops_per_image += 2.0 * h0 * w0 * ch * L
     pl.reference_flops_per_image = flops_before_head + head_ref_flops + 2.0 * h0 * w0 * ch * L
     pl.ops.append(dict(type=OP_UPSAMPLE_OUT, in0=-1, in1=-1, out=-1, res=-1, cin=0, cout=L, k=0, stride=0, act=0, hin=h0, win=w0,
-                       hout=height, wout=width, w_idx=-1, b_idx=-1, p0=0, p1=0))
+                       hout=height, wout=width, w_idx=-1, b_idx=-1, p0=0, p1=0, tag="head"))
     return pl

@@ -1,0 +1,120 @@
+"""GPU: the detector's fused forms (csrc/det_fused.h, sa::Tuning det_fuse) against the op list they replace, on the SAME engine and
+weights, and against the fp32 oracle.
+
+det_fuse = 0 runs detection/plan.py's op list as written (round 5's path: every intermediate through HBM); each bit folds one pair:
+  1  LiteMLA depthwise 5x5 + grouped 1x1      2  LiteMLA kv + out (fp32 MFMA)      4  z0 inside the head's sum + classify pass
+  8  MBConv depthwise 3x3 + projection        16 FusedMBConv 3x3 + Hardswish + projection
+Expectations written into the asserts:
+  * bits 4 and 8 repeat the op list's arithmetic exactly (same MFMA, same K order, same rounding points): heat maps bit-identical;
+  * bit 1 runs the grouped 1x1 on the bf16 MFMA instead of an fp32 fma chain and bit 2 sums tokens on the fp32 MFMA in another order:
+    fp32-accumulation re-association only -- <= 4e-3 abs on the [0, 1] maps in bf16 (one bf16 rounding step of an intermediate may flip),
+    and no further from the fp32 oracle than the op list is;
+  * bit 16 re-associates nothing in the 3x3 sum but feeds the projection from registers: same bound as bit 1.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import det_oracle as do
+from surya_amd.config import det_config
+from surya_amd.synth import make_det_weights, make_pages
+
+pytestmark = pytest.mark.gpu
+
+ALL = 31
+
+
+def _set(lib, v):
+    from surya_amd import _lib as L
+    L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(v)), "surya_set_tuning")
+
+
+def _default(lib):
+    _set(lib, DEFAULT)
+
+
+DEFAULT = 31
+
+
+def build(name, size, dtype, max_batch):
+    from surya_amd.detection.model import HipDetModel
+    cfg = det_config(name)
+    sd = make_det_weights(cfg, 0)
+    return cfg, sd, HipDetModel(cfg, sd, height=size, width=size, dtype=dtype, max_batch=max_batch)
+
+
+@pytest.mark.parametrize("pages_n,size", [(2, 1024), (3, 672), (1, 256)])
+def test_fused_forms_vs_op_list_bf16(hip_lib, pages_n, size):
+    """DET-DEFAULT bf16 at the BASELINE page size, at a ragged size (672 = 21 x 32: every stage has partial tiles) and at the size the
+    oracle tests use. Each bit alone and all together against det_fuse = 0."""
+    cfg, sd, m = build("DET-DEFAULT", size, torch.bfloat16, pages_n)
+    x = do.normalise_pages(list(make_pages(pages_n, size, seed=99))).cuda().contiguous()
+    try:
+        _set(hip_lib, 0)
+        base = m.forward(x).clone()
+        again = m.forward(x).clone()
+        assert torch.equal(base, again)
+        assert torch.isfinite(base).all() and base.std().item() > 0.02
+        for bit in (1, 2, 4, 8, 16, ALL):
+            _set(hip_lib, bit)
+            h = m.forward(x).clone()
+            h2 = m.forward(x).clone()
+            assert torch.equal(h, h2), f"det_fuse={bit}: not run-to-run identical"
+            d = (h - base).abs().max().item()
+            print(f"{size}^2 x {pages_n}: det_fuse={bit:2d} vs op list: max abs diff {d:.3e}, identical {torch.equal(h, base)}")
+            assert torch.isfinite(h).all()
+            if bit in (4, 8):
+                assert torch.equal(h.view(torch.int32), base.view(torch.int32)), f"det_fuse={bit} must repeat the op list's bits"
+            else:
+                assert d <= 4e-3, (bit, d)
+    finally:
+        _default(hip_lib)
+
+
+def test_fused_forms_vs_oracle(hip_lib):
+    """All fused forms on (the default) vs the fp32 oracle: inside the bf16 tolerance of tests/test_gpu_det.py and no further away than
+    the op list."""
+    cfg, sd, m = build("DET-DEFAULT", 256, torch.bfloat16, 2)
+    pages = make_pages(2, 256, seed=5)
+    x = do.normalise_pages(pages)
+    ref = do.heatmaps(sd, cfg, x)
+    try:
+        _set(hip_lib, 0)
+        e0 = (m.forward(x.cuda()).cpu() - ref).abs()
+        _set(hip_lib, ALL)
+        e1 = (m.forward(x.cuda()).cpu() - ref).abs()
+    finally:
+        _default(hip_lib)
+    print(f"vs oracle: op list max {e0.max():.4f} mean {e0.mean():.5f} | fused max {e1.max():.4f} mean {e1.mean():.5f}")
+    assert e1.max().item() <= max(3e-2, 1.5 * e0.max().item())
+    assert e1.mean().item() <= max(4e-3, 1.5 * e0.mean().item())
+
+
+@pytest.mark.parametrize("size", [256, 352])
+def test_litemla_one_launch_fp32_vs_two_launch(hip_lib, size):
+    """Reference mode: LiteMLA's kv + out in one launch on the fp32 MFMA (the only fused form fp32 takes) against the two-launch
+    kernels: fp32 sums in another order, <= 2e-5 on the maps; both <= 1e-4 from the oracle. 352 = 11 x 32: 121 tokens, a ragged chunk."""
+    cfg, sd, m = build("DET-DEFAULT", size, torch.float32, 1)
+    x = do.normalise_pages(make_pages(1, size, seed=3))
+    ref = do.heatmaps(sd, cfg, x)
+    try:
+        _set(hip_lib, 0)
+        a = m.forward(x.cuda()).cpu()
+        _set(hip_lib, 2)
+        b = m.forward(x.cuda()).cpu()
+    finally:
+        _default(hip_lib)
+    d = (a - b).abs().max().item()
+    print(f"fp32 {size}: one launch vs two: {d:.2e}; vs oracle {(a - ref).abs().max():.2e} / {(b - ref).abs().max():.2e}")
+    assert d <= 2e-5
+    assert (b - ref).abs().max().item() <= 1e-4
+
+
+def test_forward_timed_reports_every_op(hip_lib):
+    cfg, sd, m = build("DET-TINY", 128, torch.bfloat16, 2)
+    x = do.normalise_pages(make_pages(2, 128, seed=1)).cuda().contiguous()
+    ref = m.forward(x).clone()
+    heat, rows = m.forward_timed(x)
+    assert torch.equal(heat, ref)
+    assert len(rows) == len(m.plan_ops) and all(ms >= 0 for _, ms in rows) and sum(ms for _, ms in rows) > 0
