@@ -45,24 +45,38 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float ksum = 0.f;
+    // k | v of a token are 2 * DIM contiguous elements behind q: CPT 16-byte pieces per token, NLD of them per thread and chunk. The pieces of
+    // chunk n + 1 are requested before the MFMAs of chunk n (first version: load -> barrier -> multiply, one exposed memory round trip per chunk,
+    // 52 us per launch of 16 chunk steps)
+    constexpr int CPT = 2 * DIM / V, NLD = CH * CPT / 256, QPT = DIM / V, NLQ = CH * QPT / 256;
+    static_assert(CH * CPT % 256 == 0 && CH * QPT % 256 == 0, "staging split");
+    uint4 pre[NLD];
+#define ML_LOADKV(N0)                                                                                                   \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_) {                                                            \
+            const int idx_ = tid + i_ * 256, n_ = idx_ / CPT, pc_ = idx_ % CPT, tok_ = min((N0) + n_, HW - 1);          \
+            pre[i_] = *reinterpret_cast<const uint4*>(src + (long)tok_ * C + DIM + pc_ * V);                            \
+        }                                                                                                               \
+    }
+    ML_LOADKV(0);
     for (int n0 = 0; n0 < HW; n0 += CH) {
-        constexpr int CPT = 2 * DIM / V;                 // 16-byte chunks of k | v per token (contiguous behind q)
-        for (int idx = tid; idx < CH * CPT; idx += 256) {
-            const int n = idx / CPT, pc = idx % CPT, tok = n0 + n;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (tok < HW) raw = *reinterpret_cast<const uint4*>(src + (long)tok * C + DIM + pc * V);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256, n = idx / CPT, pc = idx % CPT;
             float x[V];
-            unpack16(raw, x, (T*)nullptr);
+            unpack16(pre[i], x, (T*)nullptr);
+            const bool live = n0 + n < HW;                   // a token past the end contributes relu(k) = 0 (its clamped load is discarded)
             const int e0 = pc * V;
             if (e0 < DIM) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) ks[n * 32 + e0 + e] = fmaxf(x[e], 0.f);
+                for (int e = 0; e < V; ++e) ks[n * 32 + e0 + e] = live ? fmaxf(x[e], 0.f) : 0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < V; ++e) vs[n * 32 + e0 - DIM + e] = x[e];
+                for (int e = 0; e < V; ++e) vs[n * 32 + e0 - DIM + e] = live ? x[e] : 0.f;
             }
         }
         __syncthreads();
+        ML_LOADKV(min(n0 + CH, HW - 1));                     // unconditional (clamped): a branch around the loads drains them at the merge
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int t = w * 32 + 2 * s + lh;
@@ -72,6 +86,7 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
         }
         __syncthreads();
     }
+#undef ML_LOADKV
     ksum += __shfl_xor(ksum, 32, 64);
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[w * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[r];
@@ -85,18 +100,26 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 #pragma unroll
     for (int s = 0; s < 16; ++s) { ak[s] = kv[(2 * s + lh) * 32 + lr]; ksl[s] = ksf[2 * s + lh]; }
     const int Cout = heads * DIM;
+    uint4 preq[NLQ];
+#define ML_LOADQ(N0)                                                                                                    \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLQ; ++i_) {                                                            \
+            const int idx_ = tid + i_ * 256, n_ = idx_ / QPT, pc_ = idx_ % QPT, tok_ = min((N0) + n_, HW - 1);          \
+            preq[i_] = *reinterpret_cast<const uint4*>(src + (long)tok_ * C + pc_ * V);                                 \
+        }                                                                                                               \
+    }
+    ML_LOADQ(0);
     for (int n0 = 0; n0 < HW; n0 += CH) {
-        constexpr int QPT = DIM / V;
-        for (int idx = tid; idx < CH * QPT; idx += 256) {
-            const int n = idx / QPT, pc = idx % QPT, tok = n0 + n;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (tok < HW) raw = *reinterpret_cast<const uint4*>(src + (long)tok * C + pc * V);
+#pragma unroll
+        for (int i = 0; i < NLQ; ++i) {
+            const int idx = tid + i * 256, n = idx / QPT, pc = idx % QPT;
             float x[V];
-            unpack16(raw, x, (T*)nullptr);
+            unpack16(preq[i], x, (T*)nullptr);
 #pragma unroll
             for (int e = 0; e < V; ++e) qs[n * 33 + pc * V + e] = fmaxf(x[e], 0.f);
         }
         __syncthreads();
+        ML_LOADQ(min(n0 + CH, HW - 1));
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -118,6 +141,7 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
         }
         __syncthreads();
     }
+#undef ML_LOADQ
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -265,20 +289,34 @@ __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int l = 0; l < 2; ++l) acc[py][px][l] = 0.f;
     const long w1off = (long)(L > 1 ? 1 : 0) * C;
+    // Software pipeline over the 128-channel slabs (first version: load A0 -> MFMA -> barrier -> load taps -> sum, every load's round trip
+    // exposed at one wave per SIMD: 804 us, no better than the two launches it replaced):
+    //   [A] request the tap tiles + classifier weights of slab s   (global, independent of LDS)
+    //   [B] z0 slab s on the MFMA from the A0 fragments requested during slab s - 1's sums, bias, round, into LDS       (covers [A])
+    //   [C] barrier, read this lane's rows of the slab, barrier
+    //   [D] request A0 fragments + bias of slab s + 1 (clamped at the tail: unconditional)
+    //   [E] the sums, ReLU, classifier dot products of slab s                                                           (covers [D])
+    u32x4 wf[4][4];
+    uint2 braw[4][4];
+#define HZ_LOADW(N0)                                                                                                    \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                         \
+                wf[j_][ks_] = *reinterpret_cast<const u32x4*>(A0 + (long)((N0) + j_ * 32 + lr) * K + (ks_ * 2 + lh) * 8); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) braw[j_][q_] = *reinterpret_cast<const uint2*>(zb + (N0) + j_ * 32 + q_ * 8 + lh * 4); \
+    }
+    HZ_LOADW(0);
     for (int n0 = 0; n0 < C; n0 += 128) {
+        const int c = n0 + sub * V;
+        UpsumTile<R1, BH> t1; UpsumTile<R2, BH> t2; UpsumTile<R3, BH> t3;
+        upsum_load<T, R1, BH>(t1, z1 + c, img, H0 / R1, W0 / R1, C, by, bx);
+        upsum_load<T, R2, BH>(t2, z2 + c, img, H0 / R2, W0 / R2, C, by, bx);
+        upsum_load<T, R3, BH>(t3, z3 + c, img, H0 / R3, W0 / R3, C, by, bx);
+        const uint4 w0r = *reinterpret_cast<const uint4*>(w + c), w1r = *reinterpret_cast<const uint4*>(w + w1off + c);
+        __builtin_amdgcn_sched_barrier(0);
         {   // z0 slab [128 px][128 ch]
             f32x16 za[4];
-            u32x4 wf[4][4];
-            uint2 braw[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    wf[j][ks] = *reinterpret_cast<const u32x4*>(A0 + (long)(n0 + j * 32 + lr) * K + (ks * 2 + lh) * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) braw[j][q] = *reinterpret_cast<const uint2*>(zb + n0 + j * 32 + q * 8 + lh * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -300,7 +338,6 @@ __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__
                 }
         }
         __syncthreads();
-        const int c = n0 + sub * V;
         uint4 zr[BH][4];
 #pragma unroll
         for (int py = 0; py < BH; ++py)
@@ -309,12 +346,10 @@ __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__
                 const int m = bl * 8 + py * 4 + px;
                 zr[py][px] = *reinterpret_cast<const uint4*>(slab + m * 256 + ((sub ^ (m & 15)) << 4));
             }
-        UpsumTile<R1, BH> t1; UpsumTile<R2, BH> t2; UpsumTile<R3, BH> t3;
-        upsum_load<T, R1, BH>(t1, z1 + c, img, H0 / R1, W0 / R1, C, by, bx);
-        upsum_load<T, R2, BH>(t2, z2 + c, img, H0 / R2, W0 / R2, C, by, bx);
-        upsum_load<T, R3, BH>(t3, z3 + c, img, H0 / R3, W0 / R3, C, by, bx);
-        const uint4 w0r = *reinterpret_cast<const uint4*>(w + c), w1r = *reinterpret_cast<const uint4*>(w + w1off + c);
         __syncthreads();                                   // every lane holds its rows of the slab: the next slab may overwrite it
+        __builtin_amdgcn_sched_barrier(0);
+        HZ_LOADW(min(n0 + 128, C - 128));
+        __builtin_amdgcn_sched_barrier(0);
         f32x2 v[BH][4][NP];
 #pragma unroll
         for (int py = 0; py < BH; ++py)
@@ -336,6 +371,7 @@ __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__
                     acc[py][px][1] = __builtin_amdgcn_fdot2_f32_bf16(yb, __builtin_bit_cast(bf16x2_t, w1u[i]), acc[py][px][1], false);
                 }
     }
+#undef HZ_LOADW
     const long HW = (long)H0 * W0;
     const float blv[2] = {Ty<T>::ld(bias), Ty<T>::ld(bias + (L > 1 ? 1 : 0))};
 #pragma unroll
@@ -596,6 +632,163 @@ static inline int launch_dwproj(const bf16_t* in, const bf16_t* wd, const bf16_t
 template <typename T>
 static inline int launch_dwproj(const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int, int, int, int, int, int, int, int,
                                 hipStream_t) { return SA_ERR_UNSUPPORTED; }
+
+// ---------------------------------------------------------------------------------------------------
+// Stem convolutions: 3x3, 32 output channels, Cin = 8 (the padded RGB input, stride 2) or 32 (the residual ConvBlock), at 512^2 x 16 pages the
+// three largest pixel counts of the network. As implicit GEMMs they are M = 4.2M x N = 32: the 128 x 32 tile of conv_gemm_kernel re-gathered
+// every input vector nine times through L1 / L2 and ran at 80 - 250 TF/s (240 - 340 us each against ~100 us of HBM time for one read and one
+// write of the tensor). Here a workgroup owns an 8 x 32 pixel tile: the input patch ((8 - 1) S + 3 rows x (32 - 1) S + 3 columns, zero outside
+// the image) is loaded ONCE into LDS and every MFMA's pixel fragment is a 16-byte LDS read at (pixel + tap) -- im2col without the copy; the
+// whole 32 x K weight matrix sits in registers as MFMA fragments (72 registers at Cin = 32), so the K loop is 18 x (2 LDS reads + 2 MFMAs) per
+// wave with nothing else in it. 4 waves, wave w = rows 2 w, 2 w + 1 of the tile. K order = the GEMM's ((ky, kx, ci) ascending in 16-element steps,
+// one accumulator per output) and the epilogue is conv_gemm_kernel's (bias, Hardswish, + residual in fp32, ONE rounding): bit-identical to it.
+//   Cin = 32: K step s = tap s >> 1, channels (s & 1) * 16 + (lane >> 5) * 8; LDS pixel = 64 bytes, 16-byte chunk XOR-swizzled by (column >> 2) & 3
+//   Cin = 8 : K step s = taps 2 s + (lane >> 5) (tap 9 = zero weights, reads tap 8's pixel), LDS pixel = 16 bytes
+// The 32 x 32 result D[cout][px] leaves a lane with 4 consecutive channels per group; v_permlane32_swap between lane l and l + 32 (same pixel)
+// makes that 8 consecutive channels, so the stores are 16 bytes.
+template <int CIN, int S, int EPI>      // EPI: 0 = bias + Hardswish, 1 = bias + residual
+__global__ __launch_bounds__(256, CIN == 32 ? 2 : 4) void stem_conv_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                       const bf16_t* __restrict__ res, bf16_t* __restrict__ out, int H, int W, int Ho, int Wo, int Kpad,
+                                                       int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PB = CIN * 2, CPP = PB / 16;
+    constexpr int NSTEP = CIN == 32 ? 18 : 5;
+    static_assert((CIN == 32 || CIN == 8), "stem shapes");
+    __shared__ __attribute__((aligned(16))) unsigned char patch[PH * PW * PB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    // weights: all K steps of this lane's output channel (lane & 31), ONCE per workgroup: the grid is persistent (a few workgroups per CU walk the
+    // tile raster). One tile per workgroup re-read the 18 KiB of fragments per wave and tile -- 1.2 GB of L2 traffic per launch for 0.27 GB of
+    // activations -- and exposed four memory round trips per tile (fragments, patch, residual, stores): 251 us.
+    u32x4 wf[NSTEP];
+#pragma unroll
+    for (int s_ = 0; s_ < NSTEP; ++s_) wf[s_] = *reinterpret_cast<const u32x4*>(w + (long)lr * Kpad + s_ * 16 + lh * 8);
+    constexpr int NPRE = (PH * PW * CPP + 255) / 256;
+    // XCD x (= blockIdx.x % 8) owns the x-th contiguous eighth of the tile raster; its workgroups take adjacent tiles of it
+    const int xcd = blockIdx.x & 7, gx = (int)gridDim.x >> 3, wx = (int)blockIdx.x >> 3;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int t_begin = xcd * per + min(xcd, rem), t_cnt = per + (xcd < rem ? 1 : 0);
+    uint4 pre[NPRE];
+#define ST_LOAD(TL)                                                                                                     \
+    {                                                                                                                   \
+        const int bid_ = t_begin + min((TL), t_cnt - 1);                                                                \
+        const int b_ = bid_ / (tiles_x * tiles_y), tr_ = bid_ - b_ * tiles_x * tiles_y;                                 \
+        const int iy0_ = (tr_ / tiles_x) * TH * S - 1, ix0_ = (tr_ % tiles_x) * TW * S - 1;                             \
+        const bf16_t* img_ = in + (long)b_ * H * W * CIN;                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                                           \
+            const int idx_ = min(tid + i_ * 256, PH * PW * CPP - 1), px_ = idx_ / CPP, c_ = idx_ % CPP, pr_ = px_ / PW, pc_ = px_ - pr_ * PW; \
+            const int iy_ = iy0_ + pr_, ix_ = ix0_ + pc_;                                                               \
+            const bool ok_ = (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                                \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(img_ + ((long)min(max(iy_, 0), H - 1) * W + min(max(ix_, 0), W - 1)) * CIN + c_ * 8); \
+            const unsigned m_ = ok_ ? 0xffffffffu : 0u;      /* unconditional load, masked: no branch between a load and its use */ \
+            pre[i_] = make_uint4(v_.x & m_, v_.y & m_, v_.z & m_, v_.w & m_);                                           \
+        }                                                                                                               \
+    }
+    if (wx >= t_cnt) return;
+    ST_LOAD(wx);
+    for (int tl = wx; tl < t_cnt; tl += gx) {
+        const int bid = t_begin + tl;
+        const int b = bid / (tiles_x * tiles_y), tr = bid - b * tiles_x * tiles_y;
+        const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < PH * PW * CPP) {
+                const int px = idx / CPP, c = idx % CPP, pc = px % PW;
+                const int pc_sw = CPP == 4 ? (c ^ ((pc >> 2) & 3)) : c;
+                *reinterpret_cast<uint4*>(patch + px * PB + pc_sw * 16) = pre[i];
+            }
+        }
+        __syncthreads();
+        ST_LOAD(tl + gx);                                    // the next tile's patch travels while this one is multiplied (clamped at the tail)
+        // residual rows of this tile, requested before the MFMAs as well
+        [[maybe_unused]] uint4 rraw[2][2];
+        long obase[2];
+        bool live[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + wv * 2 + i, ox = ox0 + lr;
+            live[i] = oy < Ho && ox < Wo;
+            obase[i] = (((long)b * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * 32;
+            if (EPI == 1) {
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) rraw[i][p_] = *reinterpret_cast<const uint4*>(res + obase[i] + 8 * (2 * p_ + lh));
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NSTEP; ++s_) {
+            int tap, chunk;
+            if (CIN == 32) { tap = s_ >> 1; chunk = (s_ & 1) * 2 + lh; }
+            else { tap = min(2 * s_ + lh, 8); chunk = 0; }
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int prow = (wv * 2 + i) * S + ky, pcol = lr * S + kx;
+                const int csw = CPP == 4 ? (chunk ^ ((pcol >> 2) & 3)) : chunk;
+                const u32x4 xf = *reinterpret_cast<const u32x4*>(patch + (prow * PW + pcol) * PB + csw * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s_]), __builtin_bit_cast(bf16x8, xf), acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // every wave is done with the patch: the next tile may overwrite it
+        // epilogue: lane (px = lr, half lh) ends with channels [8 (2 p + lh), + 8) for p = 0, 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int p_ = 0; p_ < 2; ++p_) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // quad g = 2 p (register 8 p + r) and quad g = 2 p + 1 (register 8 p + 4 + r): the upper half's copy of the first <-> the lower half's copy of the second
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][8 * p_ + r]), __float_as_uint(acc[i][8 * p_ + 4 + r]), false, false);
+                    v[r] = __uint_as_float(sw[0]);
+                    v[4 + r] = __uint_as_float(sw[1]);
+                }
+                const int c0 = 8 * (2 * p_ + lh);
+                float bv[8];
+                unpack16(*reinterpret_cast<const uint4*>(bias + c0), bv, (bf16_t*)nullptr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                if (EPI == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = hardswish_f(v[e]);
+                } else {
+                    float r8[8];
+                    unpack16(rraw[i][p_], r8, (bf16_t*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                }
+                if (live[i])
+                    *reinterpret_cast<uint4*>(out + obase[i] + c0) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            }
+        }
+    }
+#undef ST_LOAD
+}
+
+// Returns SA_ERR_UNSUPPORTED for shapes the kernel does not take (the caller then runs the implicit-GEMM path).
+static inline int launch_stem_conv(const bf16_t* in, const bf16_t* w, const bf16_t* bias, const bf16_t* res, bf16_t* out, int B, int H, int W, int Cin,
+                                   int Ho, int Wo, int Cout, int k, int stride, int pad, int Kpad, int act, hipStream_t s) {
+    if (Cout != 32 || k != 3 || pad != 1 || !bias) return SA_ERR_UNSUPPORTED;
+    const int tx = cdiv(Wo, 32), ty = cdiv(Ho, 8), ntiles = B * tx * ty;
+    const int wg_per_cu = Cin == 32 ? 2 : 4;                 // by registers (the Cin = 32 kernel holds 72 registers of weight fragments)
+    const unsigned grid = (unsigned)std::min(ntiles, 256 * wg_per_cu) / 8 * 8 ? (unsigned)std::min(ntiles, 256 * wg_per_cu) / 8 * 8 : 8u;      // persistent, whole XCD rounds
+    if (Cin == 32 && stride == 1 && act == ACT_HSWISH && !res)
+        hipLaunchKernelGGL((stem_conv_kernel<32, 1, 0>), dim3(grid), dim3(256), 0, s, in, w, bias, res, out, H, W, Ho, Wo, Kpad, tx, ty, ntiles);
+    else if (Cin == 32 && stride == 1 && act == ACT_NONE && res)
+        hipLaunchKernelGGL((stem_conv_kernel<32, 1, 1>), dim3(grid), dim3(256), 0, s, in, w, bias, res, out, H, W, Ho, Wo, Kpad, tx, ty, ntiles);
+    else if (Cin == 8 && stride == 2 && act == ACT_HSWISH && !res)
+        hipLaunchKernelGGL((stem_conv_kernel<8, 2, 0>), dim3(grid), dim3(256), 0, s, in, w, bias, res, out, H, W, Ho, Wo, Kpad, tx, ty, ntiles);
+    else
+        return SA_ERR_UNSUPPORTED;
+    return (int)hipGetLastError();
+}
+template <typename T>
+static inline int launch_stem_conv(const T*, const T*, const T*, const T*, T*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t) {
+    return SA_ERR_UNSUPPORTED;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // FusedMBConv (3x3 expand + Hardswish + 1x1 projection): see below (fmb_*). Shapes the kernel takes:

@@ -1050,4 +1050,26 @@ __global__ void upsample_planes_kernel(const float* __restrict__ src, float* __r
                ly * ((1.f - lx) * s[(long)y1 * Ws + x0] + lx * s[(long)y1 * Ws + x1]);
 }
 
+// The same map, four horizontally adjacent outputs per thread and one 16-byte store (round 6: the one-output kernel wrote 134 MB per 16 pages
+// in 4-byte stores, 119 us against ~25 us of HBM time). Per output the expression is the kernel's above, term for term: bit-identical.
+__global__ __launch_bounds__(256) void upsample_planes4_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd) {
+    const int wq = Wd >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * Hd * wq) return;
+    const int xq = (int)(idx % wq), y = (int)((idx / wq) % Hd);
+    const long n = idx / ((long)wq * Hd);
+    int y0, y1; float ly;
+    bilin_coeff(y, Hs, (float)Hs / (float)Hd, y0, y1, ly);
+    const float* s0 = src + n * Hs * Ws + (long)y0 * Ws;
+    const float* s1 = src + n * Hs * Ws + (long)y1 * Ws;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x0, x1; float lx;
+        bilin_coeff(xq * 4 + i, Ws, (float)Ws / (float)Wd, x0, x1, lx);
+        o[i] = (1.f - ly) * ((1.f - lx) * s0[x0] + lx * s0[x1]) + ly * ((1.f - lx) * s1[x0] + lx * s1[x1]);
+    }
+    *reinterpret_cast<float4*>(dst + (n * Hd + y) * (long)Wd + xq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace sa

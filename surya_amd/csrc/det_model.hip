@@ -82,7 +82,8 @@ struct DetModel : DetBase {
     //   bit 2  the full-resolution stage's 1x1 convolution z0 inside the sum + classify pass (the [P, 512] tensor is never written)
     //   bit 3  MBConv's depthwise 3x3 + projection 1x1 in one kernel (the depthwise result is the projection's A operand, in LDS only)
     //   bit 4  FusedMBConv's 3x3 expand + Hardswish + 1x1 projection in one kernel (the expanded tensor exists per 64-channel chunk, in registers / LDS only)
-    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16 };
+    //   bit 5  (not a fusion: a kernel choice) the three 32-channel stem convolutions on the patch-in-LDS kernel instead of the implicit GEMM
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32 };
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
 
@@ -214,6 +215,15 @@ struct DetModel : DetBase {
                             break;
                         }
                     }
+                    if constexpr (std::is_same<T, bf16_t>::value) {
+                        // the 32-channel stem convolutions: patch-in-LDS kernel (det_fuse bit 5; the implicit-GEMM path below is the checker)
+                        if ((fuse & FUSE_STEM) && op.cout == 32 && op.k == 3) {
+                            rc = launch_stem_conv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), op.res >= 0 ? bufs[op.res] : nullptr, bufs[op.out], B, op.hin,
+                                                  op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.p0, op.p1, op.act, s);
+                            if (rc == SA_OK) break;
+                            if (rc != SA_ERR_UNSUPPORTED) return rc;
+                        }
+                    }
                     if (op.k == 1 && op.stride == 1 && op.cin % Ty<T>::KE == 0 && op.p1 == op.cin) {
                         // 1x1 convolution on NHWC == plain NT GEMM over the B*H*W pixel rows: no gather arithmetic, XCD-aware
                         // tile order (55 % of the network's FLOPs go this way)
@@ -313,6 +323,10 @@ struct DetModel : DetBase {
                 case SA_DET_UPSAMPLE_OUT: {
                     if (!heat) break;
                     const long n = (long)B * op.cout * op.hout * op.wout;
+                    if (op.wout % 4 == 0)
+                        hipLaunchKernelGGL(upsample_planes4_kernel, dim3((unsigned)cdivl(n / 4, 256)), dim3(256), 0, s, planes, heat,
+                                           B * op.cout, op.hin, op.win, op.hout, op.wout);
+                    else
                     hipLaunchKernelGGL(upsample_planes_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, s, planes, heat,
                                        B * op.cout, op.hin, op.win, op.hout, op.wout);
                     break;
