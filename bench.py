@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--aux-timeout", type=float, default=None,
                     help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
                          "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
+    ap.add_argument("--det-fuse", type=int, default=63, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
+    ap.add_argument("--no-predictor-call", action="store_true", help="skip the predictor_call object (RecognitionPredictor.__call__ wall clock + CPU oracle through the same call shape)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo)")
     return ap.parse_args()
@@ -152,6 +154,83 @@ def cpu_baseline(cfg, sd, prep, n_lines, max_tokens, hip_tokens, threads8_lines=
                       "the oracle's only at a near-tie (the top-2 margin at every first divergence is reported relative to max|logit|)"}
     parity.update(fp32_mode_parity(cfg, sd, prep, n_lines, max_tokens, toks))
     return out, parity
+
+
+def bench_predictor_call(args, pred, cfg, sd, crops_u8):
+    """SURVEY 8(d) / benchmark/recognition.py:139-141: wall clock AROUND the predictor call, PIL images + one bbox per image in, OCRResults
+    out -- slicing, pre-processing (device: crop / area clamp / x28 resize / normalise / patchify), the continuous-batching loop, output
+    assembly (detokenise, polygons) -- on the same 256 crops as the headline leg; and the CPU oracle through the SAME call shape on 32 of
+    them: host slicing + the host pre-processing chain (numpy), the fp32 oracle's greedy loop, the same output assembly. The headline `value`
+    stays the device loop on resident tiles (its contract); this object is the call a user makes."""
+    from PIL import Image
+    from oracle import rec_oracle as ro
+    from surya_amd.recognition.predictor import RecognitionPrompt, slice_bboxes_from_image
+    from surya_amd.recognition.schema import TaskNames
+    imgs = [Image.fromarray(c) for c in crops_u8]
+    boxes = [[[0, 0, im.size[0], im.size[1]]] for im in imgs]
+    res = pred(imgs, bboxes=boxes)                       # warm-up
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = pred(imgs, bboxes=boxes)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"lines_per_s": round(len(imgs) / dt, 1), "ms_per_call": round(dt * 1e3, 2), "lines": len(imgs), "calls_timed": reps,
+           "phases_ms_last_call": {k: round(v, 2) for k, v in (pred.last_timing or {}).items()},
+           "chars_out": sum(len(l.text) for r in res for l in r.text_lines)}
+    # ---- CPU: the same call shape on n lines
+    n = min(32, len(imgs))
+    all_threads = torch.get_num_threads()
+    use = max(1, min(all_threads, n))
+    torch.set_num_threads(use)
+    ro.ATTN_IMPL = "sdpa"
+    om = ro.OracleRecModel(cfg, sd, cfg.image_token_id)
+    try:
+        t0 = time.perf_counter()
+        flat = {"slices": [], "polygons": [], "task_names": [], "input_text": [], "slice_map": []}
+        for im, bb in zip(imgs[:n], boxes[:n]):
+            arr = pred.processor.image_processor(im)
+            sl = slice_bboxes_from_image(arr, bb)
+            flat["slices"].extend(sl); flat["slice_map"].append(len(sl))
+            flat["polygons"].extend([[[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]] for b in bb])
+            flat["task_names"].extend([TaskNames.ocr_with_boxes] * len(sl)); flat["input_text"].extend([None] * len(sl))
+        flat["res_scales"] = [(1, 1)] * len(flat["slices"])
+        order = sorted(range(len(flat["slices"])), key=lambda i: -flat["slices"][i].shape[1])
+        outs = []
+        for i in order:
+            b = pred.prepare_input([flat["task_names"][i]], [flat["slices"][i]], [None], [True])
+            outs.append(pred.processor(b))
+        tiles = torch.from_numpy(np.concatenate([o["image_tiles"] for o in outs], 0)).float()
+        grids = [(1, int(o["grid_hw"][0][0]), int(o["grid_hw"][0][1])) for o in outs]
+        ids_list = [list(o["input_ids"][0]) for o in outs]
+        S = max(len(q) for q in ids_list)
+        pad = cfg.pad_token_id
+        ids = torch.tensor([[pad] * (S - len(q)) + q for q in ids_list], dtype=torch.long)
+        am = ids.ne(pad).long()
+        pos = am.cumsum(-1) - 1
+        pos[pos < 0] = 0
+        pos = am * pos
+        t1 = time.perf_counter()
+        toks, bxs, scs, _ = ro.generate(om, ids, tiles, grids, am, pos, args.max_tokens, cfg.eos_token_id, cfg.pad_token_id, cfg.nop_token_id)
+        t2 = time.perf_counter()
+        sorted_flat = dict(flat)
+        for key in ("slices", "input_text", "task_names"):
+            sorted_flat[key] = [flat[key][i] for i in order]
+        items = [(k, order[k], toks[k], scs[k], np.asarray(bxs[k], np.float32).reshape(-1, 6)) for k in range(len(order))]
+        lines = pred._assemble_batch(sorted_flat, items, False, False, cfg.bbox_size)
+        t3 = time.perf_counter()
+    finally:
+        torch.set_num_threads(all_threads)
+    cdt = t3 - t0
+    out["cpu_same_call_shape"] = {"value": round(n / cdt, 4), "unit": "lines/s", "cores": use, "kind": "port",
+                                  "sample": f"{n} of the same images (one bbox each) through host slicing + host pre-processing ({(t1 - t0) * 1e3:.0f} ms), "
+                                            f"the fp32 oracle's greedy loop as one batch ({t2 - t1:.1f} s), output assembly ({(t3 - t2) * 1e3:.0f} ms); "
+                                            f"{sum(len(l.text) for l in lines)} characters out; {use} of {all_threads} host threads"}
+    out["ratio_vs_cpu_same_call_shape"] = round(out["lines_per_s"] / out["cpu_same_call_shape"]["value"], 1)
+    out["note"] = ("wall clock around RecognitionPredictor.__call__(images, bboxes=...) -- what benchmark/recognition.py:139-141 times -- on the "
+                   "headline leg's crops as PIL images; the headline value itself is the device loop on tiles resident in HBM")
+    return out
 
 
 def fp32_mode_parity(cfg, sd, prep, n_lines, max_tokens, oracle_toks):
@@ -353,6 +432,7 @@ def bench_det(args, local_rank, world, rank, barrier):
     m = HipDetModel(cfg, sd, height=args.det_size, width=args.det_size, dtype=torch.bfloat16, device=f"cuda:{local_rank}",
                     max_batch=args.det_pages)
     pages = make_pages(args.det_pages, args.det_size, seed=1234 + rank)
+    L.check(L.lib().surya_set_tuning(b"det_fuse", C.c_int(args.det_fuse)), "surya_set_tuning")
     x = do.normalise_pages(pages).cuda().contiguous()       # input normalisation only (host logic), not the measured path
     for _ in range(2):
         m.forward(x)
@@ -375,6 +455,47 @@ def bench_det(args, local_rank, world, rank, barrier):
         cats = read_profile(lib, L)
         lib.surya_prof_enable(0)
         dom = max(cats, key=lambda c: c["ms"])
+        # where the forward goes: per-op hipEvent times (surya_det_forward_timed, min of 3 passes) summed into buckets, as scalar keys
+        # (VERDICT r05 item 2); and the op list as written (sa::Tuning det_fuse = 0: round 5's path, every intermediate through HBM)
+        # timed in the SAME process as the A/B arm of the fused forms
+        from surya_amd.detection.buckets import BUCKETS, bucket_of, op_bytes, op_flops
+        best = None
+        for _ in range(3):
+            _, rows = m.forward_timed(x)
+            ms = [r[1] for r in rows]
+            best = ms if best is None else [min(a, b) for a, b in zip(best, ms)]
+        bk = {b: [0.0, 0.0, 0] for b in BUCKETS}
+        for (o, _), t in zip(rows, best):
+            if t > 0:
+                e = bk[bucket_of(o)]
+                e[0] += t; e[1] += op_flops(o) * args.det_pages; e[2] += 1
+        buckets = {}
+        for b in BUCKETS:
+            buckets[f"{b}_ms"] = round(bk[b][0], 3)
+            if b in ("conv3x3", "conv1x1"):
+                buckets[f"{b}_tflops"] = round(bk[b][1] / bk[b][0] / 1e9, 1) if bk[b][0] else 0.0
+            buckets[f"{b}_launches"] = bk[b][2]
+        L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(0)), "surya_set_tuning")
+        try:
+            for _ in range(2):
+                m.forward(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.det_steps):
+                heat0 = m.forward(x)
+            torch.cuda.synchronize()
+            dt0 = (time.perf_counter() - t0) / args.det_steps
+        finally:
+            L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(args.det_fuse)), "surya_set_tuning")
+        dfu = (heat0 - heat).abs()
+        buckets.update({"op_list_ms_per_step": round(dt0 * 1e3, 2), "op_list_pages_per_s": round(args.det_pages / dt0, 1),
+                        "fused_vs_op_list_max_abs_diff": round(float(dfu.max()), 5), "fused_vs_op_list_mean_abs_diff": round(float(dfu.mean()), 6),
+                        "det_fuse": args.det_fuse,
+                        "bucket_note": "event-timed per op (min of 3 passes, ~4.5 us of event overhead inside each op's figure); depthwise_ms = MBConv "
+                                       "depthwise 3x3 launches INCLUDING the projection 1x1 folded into them (dwproj_kernel), conv1x1 = the remaining 1x1 "
+                                       "GEMMs (expand, FusedMBConv projection, LiteMLA qkv / proj), litemla = depthwise 5x5 + grouped 1x1 and kv + out, "
+                                       "head = the three coarse z convolutions, z0 + sum + classify, output upsample; op_list_* = the same forward with "
+                                       "every fused form off (det_fuse = 0), same process"})
         # `achieved` is priced on the FLOPs the device EXECUTES (the folded decode head runs fewer than the reference's op order: ADVICE r04);
         # the algorithmic figure of the reference's own op order is reported beside it
         whole = m.executed_flops_per_image * args.det_pages * args.det_steps / dt / 1e12
@@ -392,7 +513,7 @@ def bench_det(args, local_rank, world, rank, barrier):
                                                          "depthwise / LiteMLA / folded decode head)",
                             "achieved": round(whole, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(whole / PEAK_BF16_TFLOPS, 4), "achieved_on_reference_op_order_flops": round(whole_alg, 2),
-                            "traffic": traffic_for("detection forward (all kernels)"),
+                            "traffic": traffic_for("detection forward (all kernels)"), **buckets,
                             "largest_gemm_bucket": {"kernel": dom["kernel"].replace("(encoder + prefill GEMMs, lm_head)", "(1x1 convolutions as GEMMs)"),
                                                     "tflops": round(dom["tflops"], 2), "launches_per_step": dom["launches"],
                                                     "avg_launch_ms": round(dom["ms"] / dom["launches"], 4)}},
@@ -1146,6 +1267,7 @@ def main():
     crops.sort(key=lambda c: -c.shape[1])
     mine = sdist.shard_indices(n_global, world, rank)
     crops = [crops[i] for i in mine]
+    crops_u8 = [np.ascontiguousarray(c).astype(np.uint8) for c in crops]
     flat = {"slices": [c.astype(np.float32) for c in crops], "input_text": [None] * len(crops),
             "task_names": [TaskNames.ocr_with_boxes] * len(crops)}
     prep = pred.prepare_lines(flat, math_mode=True)             # host pre-processing + H2D: outside the timed region
@@ -1273,8 +1395,8 @@ def main():
                    "gather_collective_ms_per_step": (round(gather_stats.get("collective_s", 0.0) / args.steps * 1e3, 3) if dist_on else None),
                    "collectives": (f"forced one-rank {args.dist_backend} group: weights through broadcast, every step's records through "
                                    "all_gather_into_tensor on device buffers (--force-dist)" if (dist_on and world == 1) else None)},
-        "roofline": roof, "cpu_baseline": None, "parity": None, "detection": None, "e2e": None, "texify": None, "layout": None, "table_rec": None,
-        "force_dist_check": None,
+        "roofline": roof, "cpu_baseline": None, "predictor_call": None, "parity": None, "detection": None, "e2e": None, "texify": None, "layout": None,
+        "table_rec": None, "force_dist_check": None,
     }
     emit_lock = threading.Lock()
     emitted = [False]
@@ -1320,6 +1442,8 @@ def main():
                 out["parity"][key] = cp
             else:
                 out["parity"] = {key: cp}
+    if rank == 0 and world == 1 and not args.no_predictor_call:
+        out["predictor_call"] = leg("predictor_call", lambda: bench_predictor_call(args, pred, cfg, sd, crops_u8))
     if args.force_dist:
         def sharded_call_check():
             """The product's sharded __call__ (fingerprint all_gather, shard deal, one all_gather_into_tensor of the records) on the forced

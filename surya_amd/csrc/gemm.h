@@ -1498,10 +1498,11 @@ static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) 
     aa.swz_n = cdiv(tn, cdiv(tn, 8));
     aa.swz_m = std::max(1, GRP / aa.swz_n);
     const int padded = cdiv(tm * tn, 8 * GRP) * 8 * GRP;
-    static int n_cu = 0;
+    static int n_cu_of[64] = {};                             // per device (one cached count served every device of the process)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n_cu = n_cu_of[dev & 63];
     if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
         n_cu = (n_cu / 8) * 8;                              // whole XCD rounds: virtual block b stays on XCD b % 8 in every round
     }
@@ -1519,7 +1520,9 @@ static inline int launch_gemm_persist(const GemmArgs<TI, TO>& a, hipStream_t s) 
         pf.cfg_of[pf.n] = CONV ? 3 : gemm_cfg_id(BM, BN);       // bucket 3 = implicit-GEMM convolutions
         pf.flops_of[pf.n] = CONV ? 2.0 * a.M * a.N * a.cTaps * a.cCin : 2.0 * a.M * a.N * a.K;
         const double outn = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) ? a.N / 2 : a.N;
-        pf.bytes_of[pf.n] = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
+        // CONV: the input TENSOR once, not the im2col matrix M x K (~KH * KW times larger), as launch_gemm_cfg prices the same bucket
+        const double xelems = CONV ? (double)a.M / std::max(1, a.cHo * a.cWo) * a.cH * a.cW * a.cCin : (double)a.M * a.K;
+        pf.bytes_of[pf.n] = (xelems + (double)a.N * a.K) * sizeof(TI) + (double)a.M * outn * sizeof(TO) +
                             (EPI == EPI_RESIDUAL ? (double)a.M * a.N * sizeof(TO) : 0.0);
         pf.slab_of[pf.n] = 0.0;
         ++pf.n;

@@ -679,10 +679,12 @@ class RecognitionPredictor(BasePredictor):
             local["pages"] = flat["pages"]
         max_tokens = max(settings.RECOGNITION_MAX_TOKENS or self.tasks[t]["max_tokens"] for t in flat["task_names"])
         if mine:
-            toks, boxes, scores = self.prediction_loop(local, recognition_batch_size, math_mode)
+            self.last_packed = None                          # only what generate() sets DURING this call counts (a stand-in prediction_loop
+            toks, boxes, scores = self.prediction_loop(local, recognition_batch_size, math_mode)      # must not gather an earlier call's arrays)
             packed = getattr(self, "last_packed", None)
             if packed is not None and len(packed[0]) == len(toks):      # generate()'s dense arrays: no per-token Python in the pack
                 toks, scores = packed
+            self.last_packed = None                          # (and the [n, cap] matrices are not pinned on the predictor between calls)
             boxes = boxes.numpy()
             if boxes.shape[1] < max_tokens:
                 boxes = np.pad(boxes, ((0, 0), (0, max_tokens - boxes.shape[1]), (0, 0)))
@@ -894,6 +896,8 @@ class RecognitionPredictor(BasePredictor):
 
     def _call(self, images, task_names, det_predictor, detection_batch_size, recognition_batch_size, highres_images, bboxes,
               polygons, input_text, sort_lines, math_mode, return_words, drop_repeated_text) -> List[OCRResult]:
+        if getattr(self, "_poisoned", None):
+            raise RuntimeError(self._poisoned)
         allowed = self.tasks.keys()
         t_call = time.perf_counter()
         stamps = self.last_timing = {}                    # wall-clock phases of this call in ms (bench.py's e2e leg reports them)
@@ -1014,7 +1018,9 @@ class RecognitionPredictor(BasePredictor):
         n = len(images)
         dev = sdist.collective_device(self.model.device, group)
         sizes = np.asarray([im.size for im in images], np.int64).reshape(-1, 2)
-        probe = b"".join(images[i].tobytes()[:4096] for i in range(0, n, max(1, n // 16))) if n else b""
+        # (a 64 x 16 pixel corner of up to 16 pages: `tobytes()` of whole pages copied several MB per page on every rank, inside the call)
+        probe = b"".join(images[i].crop((0, 0, min(images[i].size[0], 64), min(images[i].size[1], 16))).tobytes()
+                         for i in range(0, n, max(1, n // 16))) if n else b""
         sdist.assert_same_inputs([n, zlib.crc32(sizes.tobytes()), zlib.crc32(probe)], group, dev)
         mine = sdist.shard_indices(n, world, rank)
         saved = (self.shard_pages, self.shard_lines, getattr(det_predictor, "shard_pages", False))
@@ -1030,12 +1036,22 @@ class RecognitionPredictor(BasePredictor):
             self.shard_pages, self.shard_lines = saved[0], saved[1]
             if hasattr(det_predictor, "shard_pages"):
                 det_predictor.shard_pages = saved[2]
+        if len(local) != len(mine):
+            # the single-rank call returns [] when its pages hold no line at all (reference contract, :928-929); this rank's pages then
+            # exist all the same: one empty OCRResult per page, so the gather below has an entry for every page of the whole call
+            # (a rank dealt only blank pages made those pages None on every rank / tripped the processed-once assert)
+            assert len(local) == 0, (len(local), len(mine))
+            local = [OCRResult(text_lines=[], image_bbox=[0, 0, images[i].size[0], images[i].size[1]]) for i in mine]
         if self.gather_page_results:
-            return sdist.gather_objects(local, mine, n, group)
+            out = sdist.gather_objects(local, mine, n, group)
+            # ... and the call as a whole keeps the single-rank contract: no line anywhere -> []
+            return out if any(r is not None and len(r.text_lines) for r in out) else []
         rec = [(len(r.text_lines), sum(len(l.text) for l in r.text_lines), zlib.crc32("\n".join(l.text for l in r.text_lines).encode()))
                for r in local]
         self.last_page_summary = sdist.gather_objects(rec, mine, n, group)
         assert all(x is not None for x in self.last_page_summary), "a page was processed by no rank"
+        if not any(x[0] for x in self.last_page_summary):
+            return []                                         # no line on any page of the call: the single-rank contract
         out = [None] * n
         for i, r in zip(mine, local):
             out[i] = r
@@ -1167,7 +1183,9 @@ class RecognitionPredictor(BasePredictor):
                 except BaseException:
                     stop.set()                         # the producer ends after the batch it is working on ...
                     producer.join(timeout=30.0)        # ... and is waited for: it launches detector and pre-processing work on this predictor's
-                    raise                              # objects and stream, and a retry of the call must not run beside it
+                    if producer.is_alive():            # objects and stream, and a retry of the call must not run beside it
+                        self._poisoned = "a streamed call failed and its detector thread did not stop within 30 s: create a new predictor"
+                    raise
                 producer.join()                        # it has put FEED_END: nothing left to run
                 on_flush()
                 t2 = time.perf_counter()

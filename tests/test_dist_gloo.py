@@ -318,7 +318,7 @@ def test_forced_one_rank_group_takes_the_collective_branch():
 
 
 # ------------------------------------------------------------------ whole pages per rank (RecognitionPredictor.shard_pages)
-def _page_worker(rank, world, port, q, n_pages=7):
+def _page_worker(rank, world, port, q, n_pages=7, vals=None):
     """_call_page_sharded on `world` ranks: the orchestration (fingerprint, page deal, the rank's own single-rank call, the gather) with
     the single-rank call replaced by a stand-in that derives a page's OCRResult from its pixels."""
     import torch.distributed as dist
@@ -348,18 +348,21 @@ def _page_worker(rank, world, port, q, n_pages=7):
             lines = [TextLine(text=f"page {v} line {k}", polygon=[[0, 0], [9, 0], [9, 9], [0, 9]], chars=[], confidence=0.5, words=[])
                      for k in range(v % 4)]
             out.append(OCRResult(text_lines=lines, image_bbox=[0, 0, im.size[0], im.size[1]]))
-        return out
+        return out if any(len(r.text_lines) for r in out) else []      # the real _call's contract: no line on any page -> [] (reference :928-929)
 
     real_call = RecognitionPredictor._call
     pred._call = lambda *a: real_call(pred, *a) if pred.shard_pages else fake_call(*a)     # the outer call is the product's, the rank's own call the stand-in
     pred.tasks = {"ocr_with_boxes": {}}
-    pages = [Image.fromarray(np.full((20 + i, 30, 3), 10 + i, np.uint8)) for i in range(n_pages)]
+    vals = vals or [10 + i for i in range(n_pages)]
+    pages = [Image.fromarray(np.full((20 + i, 30, 3), vals[i], np.uint8)) for i in range(n_pages)]
     det = Det()
     full = pred(pages, det_predictor=det)
     assert det.shard_pages and pred.shard_pages
     pred.gather_page_results = False
     part = pred(pages, det_predictor=det)
     summary = list(pred.last_page_summary)
+    if part == []:
+        part = [None] * n_pages
     try:
         pred(pages[:-1] if rank == 0 else pages, det_predictor=det)          # rank 0 was handed one page fewer
         err = "no error"
@@ -368,6 +371,36 @@ def _page_worker(rank, world, port, q, n_pages=7):
     q.put((rank, [r.model_dump() for r in full], [None if r is None else r.model_dump() for r in part], summary, calls, err))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_pages(world, n_pages, vals=None):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_page_worker, args=(r, world, port, q, n_pages, vals)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_page_sharded_call_with_a_rank_of_blank_pages():
+    """a rank whose pages hold no line gets [] from its own single-rank call (the reference's contract); those pages must come
+    back as EMPTY OCRResults on every rank, not as None -- and a call whose pages are all blank returns [] like the single-rank call."""
+    vals = [12, 11, 16, 13]                                  # lines per page = v % 4: rank 0 (pages 0, 2) sees 0, 0; rank 1 sees 3, 1
+    for rank, full, part, summary, calls, err in _run_pages(2, 4, vals):
+        assert [len(r["text_lines"]) for r in full] == [0, 3, 0, 1]
+        assert [r["image_bbox"] for r in full] == [[0, 0, 30, 20 + i] for i in range(4)]
+        assert [s_[0] for s_ in summary] == [0, 3, 0, 1]
+        mine = list(range(rank, 4, 2))
+        assert [i for i, r in enumerate(part) if r is not None] == mine and all(part[i] == full[i] for i in mine)
+    for rank, full, part, summary, calls, err in _run_pages(2, 3, [8, 12, 16]):      # every page blank
+        assert full == [] and all(p is None for p in part) and [s_[0] for s_ in summary] == [0, 0, 0]
 
 
 @pytest.mark.parametrize("world,n_pages", [(2, 7), (3, 7), (3, 2), (4, 1)])      # the last two: ranks that are dealt no page at all
