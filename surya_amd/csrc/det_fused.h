@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 // Workgroup = one 8 x 32 pixel tile of one image x one 32-channel group. The group's input patch (12 x 36 pixels, zero outside the image)
 // and its 25 x 32 filter taps sit in LDS; a thread produces 4 vertically adjacent pixels x 8 channels of the depthwise result (fp32, taps in
 // (ky, kx) order as dwconv_tx_kernel), rounds them to bf16 into the A tile [256 px][32 ch] and the group's 32 x 32 matrix runs on the bf16 MFMA.
+// (Tried and not kept, gpurun r06n: a wave per 8-channel chunk with the tap weights as SCALAR operands -- s_load + SALU unpack, v_fmac with an
+// SGPR source, each input vector unpacked once, 86 VGPRs -- runs 79 us against this version's 62: the scalar loads of a rolled row loop sit
+// on the critical path of every filter row.)
 __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
                                                       bf16_t* __restrict__ out, int H, int W, int C, int tiles_x) {
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4;

@@ -18,6 +18,17 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
     const long hw = (long)H * W;
     const long b = p / hw, r = p % hw;
     T* o = out + p * CP;
+    if constexpr (sizeof(T) == 2) {
+        if (CP == 8 && C <= 8) {
+            // the shipped configuration (3 -> 8 channels of bf16): ONE 16-byte store per pixel instead of eight 2-byte stores (192 us per
+            // 16 pages of 1024^2, 2.4 TB/s on a pure layout change); same conversions, same bits
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = c < C ? in[(b * C + c) * hw + r] : 0.f;
+            *reinterpret_cast<uint4*>(o) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            return;
+        }
+    }
     for (int c = 0; c < CP; ++c) Ty<T>::st(o + c, c < C ? in[(b * C + c) * hw + r] : 0.f);
 }
 
@@ -35,9 +46,16 @@ __global__ void u8_to_nhwc_kernel(const unsigned char* __restrict__ in, T* __res
     // normalisation -- px * float32(1 / 255) is one ulp off for some pixel values
     const double k = 1.0 / 255.0;
     T* o = out + p * CP;
-    Ty<T>::st(o + 0, ((float)((double)px[0] * k) - m0) / s0);
-    Ty<T>::st(o + 1, ((float)((double)px[1] * k) - m1) / s1);
-    Ty<T>::st(o + 2, ((float)((double)px[2] * k) - m2) / s2);
+    const float v0 = ((float)((double)px[0] * k) - m0) / s0, v1 = ((float)((double)px[1] * k) - m1) / s1, v2 = ((float)((double)px[2] * k) - m2) / s2;
+    if constexpr (sizeof(T) == 2) {
+        if (CP == 8) {                                       // one 16-byte store per pixel (see nchw_to_nhwc_kernel)
+            *reinterpret_cast<uint4*>(o) = make_uint4(pack2(v0, v1), pack2(v2, 0.f), 0u, 0u);
+            return;
+        }
+    }
+    Ty<T>::st(o + 0, v0);
+    Ty<T>::st(o + 1, v1);
+    Ty<T>::st(o + 2, v2);
     for (int c = 3; c < CP; ++c) Ty<T>::st(o + c, 0.f);
 }
 
