@@ -84,6 +84,8 @@ def parse():
                     help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
                          "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
     ap.add_argument("--det-fuse", type=int, default=63, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
+    ap.add_argument("--no-slot-sweep", action="store_true", help="skip the e2e leg's 256 / 512 / 1024-slot sweep")
+    ap.add_argument("--e2e-slots", type=lambda v: [int(x) for x in v.split(",")], default=[256, 512, 1024], help="slot counts of the e2e sweep")
     ap.add_argument("--no-predictor-call", action="store_true", help="skip the predictor_call object (RecognitionPredictor.__call__ wall clock + CPU oracle through the same call shape)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo)")
@@ -725,6 +727,49 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
                                                                                          for a, b in zip(o_ser, o)))}
         finally:
             pred.stream_detection = True
+    # ---- the same call at 256 / 512 / 1024 KV slots (reference: recognition_batch_size, recognition/__init__.py:504-513,
+    # README batch 864). BASELINE pins the HEADLINE at batch 256; this leg is not pinned: a decode step streams the same 0.97 GB of weights
+    # for 256 or 1024 tokens. A second predictor with max_slots = 1024 (KV cache, rings and prefill workspace sized for it).
+    by_slots = None
+    if world == 1 and not args.no_slot_sweep:
+        from surya_amd.recognition.predictor import RecognitionPredictor as RP, RecognitionModelLoader as RML
+        big = max(args.e2e_slots)
+
+        class BigLoader(RML):
+            def model(self, device=None, dtype=None, **caps):
+                return super().model(f"cuda:{local_rank}", dtype, max_slots=big, max_kv_len=64 + args.max_tokens + 32, max_patches=262144,
+                                     max_prefill_tokens=big * 72)
+
+        class BigPred(RP):
+            model_loader_cls = BigLoader
+            batch_size = big
+
+        pb = BigPred(checkpoint=args._rec_checkpoint)
+        by_slots = {"slots": [], "pages_per_s": [], "lines_per_s": [], "wall_ms": [], "results_identical_to_256_slot_call": []}
+        ref_dump = [r.model_dump() for r in o]
+        for slots in args.e2e_slots:
+            pb(imgs, det_predictor=det, recognition_batch_size=slots)          # warm-up
+            ts = []
+            ob = None
+            for _ in range(3):
+                ob = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ob = pb(imgs, det_predictor=det, recognition_batch_size=slots)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            nl = sum(len(r.text_lines) for r in ob)
+            by_slots["slots"].append(slots); by_slots["wall_ms"].append(round(ts[1] * 1e3, 1))
+            by_slots["pages_per_s"].append(round(len(imgs) / ts[1], 2)); by_slots["lines_per_s"].append(round(nl / ts[1], 1))
+            by_slots["results_identical_to_256_slot_call"].append(bool([r.model_dump() for r in ob] == ref_dump))
+        i_best = max(range(len(args.e2e_slots)), key=lambda i: by_slots["pages_per_s"][i])
+        by_slots.update({"best_slots": by_slots["slots"][i_best], "pages_per_s_best": by_slots["pages_per_s"][i_best],
+                         "lines_per_s_best": by_slots["lines_per_s"][i_best],
+                         "note": "ONE RecognitionPredictor.__call__(images, det_predictor, recognition_batch_size=slots) per figure, median of 3; a "
+                                 "second predictor whose engine holds 1024 KV slots; the 256-slot figure above is the headline predictor's"})
+        del pb
+        torch.cuda.empty_cache()
     # detection alone, for the split of the wall time (not part of the timed passes above)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -774,6 +819,7 @@ def bench_e2e(args, pred, local_rank, world, rank, barrier):
                           "whatever the rank count above ~4; expect the strong-scaling curve to flatten there")}),
             "detected_boxes": int(sum(len(r.bboxes) for r in d)),
             "serial_schedule": serial,
+            "lines_per_s_by_slots": by_slots,
             "note": "wall clock of ONE RecognitionPredictor.__call__(images, det_predictor=DetectionPredictor): PIL pages in, OCRResult out; "
                     "the recogniser is fed by the detector's own boxes (heat-map plane 0 replaced by the drawn text rows after each forward, "
                     "see docstring); host pre/post-processing, H2D / D2H and continuous-batching refills included; streamed: the detector "
@@ -1254,7 +1300,8 @@ def main():
         print_json(bench_texify(args, cfg, sd, local_rank))
         return
     RecognitionPredictor.model_loader_cls = Loader
-    pred = RecognitionPredictor(checkpoint={"config": cfg, "state_dict": sd})
+    args._rec_checkpoint = {"config": cfg, "state_dict": sd}
+    pred = RecognitionPredictor(checkpoint=args._rec_checkpoint)
     if args.e2e_only:
         print_json(bench_e2e(args, pred, local_rank, world, rank, lambda: None))
         return

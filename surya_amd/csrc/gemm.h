@@ -48,6 +48,7 @@ struct GemmArgs {
     int splitk = 1;              // > 1: K is cut into `splitk` slices, raw fp32 partial sums go to `part`
     float* part = nullptr;       // [splitk][M][N] fp32 (no bias / epilogue applied; the consumer kernel combines them)
     int swz_m = 0, swz_n = 0;    // > 0: XCD-aware rasterisation in super-tiles of swz_m x swz_n output tiles (set by the launcher)
+    int mgroup = 0;              // 1: the M-tiles of one W tile take consecutive places in ONE XCD's queue (lm_head above 256 rows: round 6)
     // EPI_ARGMAX (TO = float): C is not written; instead one float4 {max, bits of the first argmax column, sum exp(v - max), 0}
     // per (row, tile column) goes to amax[m * cdiv(N, bn_used) + tile_n]; the launcher reports the tile width it chose.
     float4* amax = nullptr;
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs<TI, TO> 
         tile_m = j % tiles_m;
         tile_n = pair / p.splitk;
         ks = pair % p.splitk;
+    }
+    if (!SPLIT && p.mgroup) {
+        // decode regime above 256 rows (round 6): every 256-row block of the batch multiplies the same W tile, so the blocks of a tile are dealt
+        // to one XCD back to back (the split-K mapping with one slice): the tile crosses the fabric once per step, not once per row block
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int pair = (j / tiles_m) * 8 + x;
+        if (pair >= tiles_n) return;
+        tile_m = j % tiles_m;
+        tile_n = pair;
     }
     if (!SPLIT && p.swz_n > 0) {
         // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only). Each XCD has a private 4 MiB L2,
@@ -1459,6 +1470,7 @@ static inline int launch_gemm_cfg(const GemmArgs<TI, TO>& a, hipStream_t s) {
             tiles = cdiv(tm * tn, 8 * GRP) * 8 * GRP;
         }
     }
+    if (!SPLIT && aa.mgroup) tiles = cdiv(cdiv(a.N, BN), 8) * 8 * cdiv(a.M, BM);
     constexpr size_t out_w = ((EPI == EPI_SWIGLU || EPI == EPI_GEGLU) && !SPLIT) ? BN / 2 : BN;
     constexpr size_t out_bytes = (size_t)BM * out_w * (SPLIT ? sizeof(float) : sizeof(TO));
     constexpr size_t stage_bytes = (size_t)(BM + BN) * 128 * (GLDS > 2 && GLDS != 8 ? GLDS : 2);
@@ -1577,6 +1589,22 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
         }
         if (a.N >= 64 * 128) return launch_gemm_cfg<TI, TO, 64, 64, 2, 2, EPI>(a, s);
         return launch_gemm_cfg<TI, TO, 64, 32, 2, 1, EPI>(a, s);
+    }
+    if constexpr (EPI == EPI_ARGMAX) {
+        // 257 ... 1024 (and more) rows (round 6; the reference's recognition_batch_size is open-ended, its README runs 864): the SAME 256 x 320
+        // tile per 256-row block, so the per-column-block (max, sum-exp) partials -- and with them every line's score bits -- are the ones the
+        // <= 256-row launch produces, whatever the slot count; the row blocks of a W tile share it through one XCD's L2 (mgroup)
+        if (a.N >= 64 * 512 && tuning().lmhead && (a.K / Ty<TI>::KE) % 2 == 0 && a.N % 4 == 0) {
+            GemmArgs<TI, TO> g = a;
+            g.mgroup = 1;
+            int rc;
+            if constexpr (sizeof(TI) == 2) {
+                if (tuning().lmhead == 2) { rc = launch_gemm_cfg<TI, TO, 256, 320, 4, 2, EPI, false, 2, false, 2>(g, s); a.bn_used = g.bn_used; return rc; }
+            }
+            rc = launch_gemm_cfg<TI, TO, 256, 320, 4, 2, EPI, false, 2>(g, s);
+            a.bn_used = g.bn_used;
+            return rc;
+        }
     }
     if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);

@@ -208,3 +208,38 @@ def test_streamed_detect_recognise_equals_the_serial_call(hip_lib, slots, det_ba
     s3 = rec(only_blank, det_predictor=det3)
     rec.stream_detection = True
     assert rec(only_blank, det_predictor=det3) == s3
+
+
+@pytest.mark.parametrize("cfg_name,dtype,n_lines,max_slots", [("REC-TINY", torch.bfloat16, 400, 512), ("REC-FULL", torch.bfloat16, 330, 384)])
+def test_ocr_results_identical_across_slot_counts(hip_lib, cfg_name, dtype, n_lines, max_slots):
+    """the decode regime above 256 slots. One predictor with max_slots > 256, the same images + boxes through
+    RecognitionPredictor.__call__ at recognition_batch_size = 64, 256 and max_slots: the OCRResults must be identical field for field -- a
+    line's stream does not depend on how many lines decode beside it (split-K counts are a function of (N, K) only, every tile shape walks K
+    in the same order), including the M > 256 tile choices of the gate|up and lm_head GEMMs."""
+    from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
+    cfg = rec_config(cfg_name)
+    sd = make_rec_weights(cfg, 0, recipe="conditioned") if cfg_name == "REC-FULL" else make_rec_weights(cfg, 0)
+
+    class Loader(RecognitionModelLoader):
+        def model(self, device=None, dtype_=None, **caps):
+            return super().model("cuda:0", dtype, max_slots=max_slots, max_kv_len=192, max_patches=max_slots * 260, max_prefill_tokens=max_slots * 72)
+
+    class Pred(RecognitionPredictor):
+        model_loader_cls = Loader
+        batch_size = max_slots
+
+    settings.RECOGNITION_MAX_TOKENS = 24
+    try:
+        pred = Pred(checkpoint={"config": cfg, "state_dict": sd})
+        crops = make_line_crops(n_lines, seed=11)
+        imgs = [Image.fromarray(c) for c in crops]
+        boxes = [[[0, 0, im.size[0], im.size[1]]] for im in imgs]
+        outs = {}
+        for slots in (64, 256, max_slots):
+            outs[slots] = [r.model_dump() for r in pred(imgs, bboxes=boxes, recognition_batch_size=slots)]
+        assert len(outs[64]) == n_lines and sum(len(r["text_lines"]) for r in outs[64]) == n_lines
+        assert outs[256] == outs[64]
+        assert outs[max_slots] == outs[64]
+        assert len({r["text_lines"][0]["text"] for r in outs[64]}) > n_lines // 4      # the streams are not degenerate
+    finally:
+        settings.RECOGNITION_MAX_TOKENS = None

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--tuning", action="append", default=[], help="sa::Tuning key=value applied before the runs (repeatable), e.g. bigtile_min_k=192")
     ap.add_argument("--rows", action="store_true", help="print the per-op rows (default: buckets only for arms after the first)")
     args = ap.parse_args()
     from surya_amd import _lib as L
@@ -45,6 +46,9 @@ def main():
     m = HipDetModel(cfg, sd, height=args.size, width=args.size, dtype=torch.bfloat16, max_batch=args.pages)
     x = do.normalise_pages(make_pages(args.pages, args.size, seed=1234)).cuda().contiguous()
     lib = L.lib()
+    for kv in args.tuning:
+        k, v = kv.split("=")
+        L.check(lib.surya_set_tuning(k.encode(), C.c_int(int(v))), f"surya_set_tuning({kv})")
     arms = [int(v) for v in args.fuse.split(",")]
     heats, summary = {}, {}
     for arm in arms:
