@@ -1362,6 +1362,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rank_ms = [round(dt_rank / args.steps * 1e3, 2)]
+    rank_devices = [f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
     gather_ms = round(gather_s[0] / args.steps * 1e3, 3) if dist_on else None
     if dist_on:
         import torch.distributed as dist
@@ -1375,6 +1376,9 @@ def main():
         allr = [torch.empty_like(tr) for _ in range(world)]
         dist.all_gather(allr, tr)
         rank_ms = [round(float(x.item()) / args.steps * 1e3, 2) for x in allr]
+        devs = [None] * world
+        dist.all_gather_object(devs, rank_devices[0])
+        rank_devices = devs
 
     if args.host_profile and rank == 0:
         import cProfile, pstats
@@ -1437,6 +1441,7 @@ def main():
                    "parallelism": (f"dp{world}: {args.lines * world} width-sorted lines dealt round-robin, one all_gather of the outputs per step, "
                                    f"weights broadcast from rank 0 ({args.dist_backend})" if world > 1 else "1 GPU"),
                    "weights": args.weights,
+                   "rccl_world": (world if (dist_on and args.dist_backend == "nccl") else None), "rank_devices": rank_devices,
                    "rank_ms_per_step": rank_ms, "gather_ms_per_step": gather_ms,
                    "gather_pack_unpack_ms_per_step": (round(gather_stats.get("pack_unpack_s", 0.0) / args.steps * 1e3, 3) if dist_on else None),
                    "gather_collective_ms_per_step": (round(gather_stats.get("collective_s", 0.0) / args.steps * 1e3, 3) if dist_on else None),

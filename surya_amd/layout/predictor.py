@@ -120,7 +120,10 @@ class LayoutModelLoader(ModelLoader):
 class LayoutPredictor(BasePredictor):
     model_loader_cls = LayoutModelLoader
     batch_size = None
-    default_batch_sizes = {"cpu": 4, "mps": 4, "cuda": 32, "xla": 16}
+    # "cuda": the reference's 32 (surya/layout/__init__.py:21-26) is sized for consumer cards; on MI355X the engine call is launch-bound at 32
+    # pages (547 us per decode step = 88 launches at M = 32) and 128 pages per call run 2x the pages/s (bench.py layout leg), so a caller who
+    # hands >= 128 pages and no batch_size gets 128-page engine calls; fewer pages -> one call of that many
+    default_batch_sizes = {"cpu": 4, "mps": 4, "cuda": 128, "xla": 16}
 
     # Multi-GPU: when set, ONE call's pages are dealt over the ranks of the initialised process group and the per-page
     # results all-gathered (common/predictor.sharded_over_ranks). Off by default, like DetectionPredictor.shard_pages.

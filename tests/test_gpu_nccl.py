@@ -6,6 +6,7 @@
     HipRecModel(broadcast_weights=True) and RecognitionPredictor.sharded_prediction_loop on REC-TINY == the plain loop.
   * test_two_ranks_nccl_equal_one_rank: TWO ranks, one GPU each (skipped below 2 GPUs; the driver's 8-GPU node runs it): the helpers
     and the product's sharded loop with rank 0's weights broadcast over xGMI == the 1-rank result.
+  Both also run the PAGE-sharded call (RecognitionPredictor.shard_pages: what bench.py's e2e leg does at N > 1) against the plain call.
 """
 import os
 import socket
@@ -91,6 +92,33 @@ def _worker(rank, world, port, q, force):
     assert [list(t) for t in toks_s] == [list(t) for t in toks_p]
     n = min(boxes_s.shape[1], boxes_p.shape[1])
     assert torch.equal(boxes_s[:, :n].float(), boxes_p[:, :n].float())
+    # ---- the e2e call's sharding (RecognitionPredictor.shard_pages, bench.py's configs[3] leg at N > 1): whole pages per rank, each rank
+    # the complete single-rank call on its own pages, one gather of the results == the unsharded call on every rank (VERDICT r05 item 9:
+    # the first multi-GPU node must exercise this path too). The detector is a stand-in with fixed boxes per page (one page blank: a rank
+    # may be dealt only that one).
+    from types import SimpleNamespace
+    from PIL import Image
+
+    class FixedBoxes:
+        def __call__(self, images, batch_size=None):
+            out = []
+            for im in images:
+                wd, ht = im.size
+                k = 0 if wd % 7 == 0 else 2
+                out.append(SimpleNamespace(bboxes=[SimpleNamespace(polygon=[[4, 6 + 40 * j], [wd - 8, 6 + 40 * j], [wd - 8, 34 + 40 * j], [4, 34 + 40 * j]])
+                                                   for j in range(k)]))
+            return out
+
+    rngp = np.random.default_rng(77)
+    pages = [Image.fromarray(rngp.integers(0, 255, size=(96, 140 + 8 * i, 3), dtype=np.uint8)) for i in range(5)]      # widths 140 (blank: 140 % 7 == 0) .. 172
+    det = FixedBoxes()
+    pred.shard_pages = pred.shard_lines = False
+    plain = [r.model_dump() for r in pred(pages, det_predictor=det)]
+    pred.shard_pages, pred.gather_page_results = True, True
+    sharded = [r.model_dump() for r in pred(pages, det_predictor=det)]
+    pred.shard_pages = False
+    assert [len(r["text_lines"]) for r in plain] == [0, 2, 2, 2, 2]
+    assert sharded == plain, "page-sharded call differs from the plain call"
     q.put((rank, gathered, [t.cpu().tolist() for t in w], [list(t) for t in toks_s]))
     dist.barrier()
     dist.destroy_process_group()
