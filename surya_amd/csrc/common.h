@@ -209,6 +209,8 @@ struct Tuning {
                              // launch, bit 2 = z0 inside the head's sum + classify pass, bit 3 = MBConv depthwise 3x3 + projection, bit 4 = FusedMBConv
                              // 3x3 + Hardswish + projection, bit 5 = stem convolutions on the patch-in-LDS kernel; 0 = the op list as written (the checker of
                              // tests/test_gpu_det_fused.py)
+    int fmb_chunk = 64;      // FusedMBConv kernel, Cin = 64 stride 1: mid channels per chunk -- 64 = two workgroups per CU (the chunk epilogue of one beside the
+                             // MFMAs of the other), 128 = one workgroup per CU with twice the accumulators
     int persist = 1;         // 256x256 bf16 GEMMs (>= 4 even K-tiles) as the PERSISTENT 8-phase loop (gemm_nt_p8p_kernel: the half-tile ring runs on across
                              // tiles, wave-private epilogue): 1 = on (round 5: +3...10 % per encoder / prefill shape once the two wave groups were
                              // re-aligned around the epilogue, +0.9 % on the bench's recognition leg); 0 = one tile per workgroup

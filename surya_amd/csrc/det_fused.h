@@ -794,10 +794,264 @@ static inline int launch_stem_conv(const T*, const T*, const T*, const T*, T*, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// FusedMBConv (3x3 expand + Hardswish + 1x1 projection): see below (fmb_*). Shapes the kernel takes:
+// FusedMBConv (encoderdecoder.py:228-270): 3x3 expand (+ folded BN + Hardswish) -> 1x1 projection (+ folded BN, + residual) in ONE kernel: the
+// expanded tensor (256 ... 1024 channels at 256^2 / 128^2, 0.27 - 1.07 GB per 16 pages) never exists. Attention-shaped, as VERDICT r05 drew it:
+//   workgroup = an 8 x 32 pixel tile (8 MFMA row tiles), 4 waves, wave w = pixel rows 2 w, 2 w + 1; persistent over the tile raster;
+//   the tile's input patch ((8 - 1) S + 3 rows x (32 - 1) S + 3 columns x Cin, zero outside the image) sits in LDS for the whole tile: the
+//     3x3's A operand is a 16-byte LDS read at (pixel + tap) -- the stem kernel's im2col without the copy;
+//   the mid channels are walked in chunks of 128: S[64 px x 128] per wave (8 accumulators, 128 registers) = patch . W1_chunk over K = 9 Cin, the
+//     chunk's weights streamed through a two-buffer LDS ring in 64-wide K-tiles (global_load_lds, gemm.h's swizzle; every wave reads all of a
+//     K-tile: 2 + 4 fragment reads per 8 MFMAs);
+//   at the end of a chunk: + bias, Hardswish, round to bf16 (the op list's rounding point), v_permlane32_swap turns the accumulator layout
+//     (4 consecutive channels per lane) into the A-operand layout (8 consecutive), and O[64 px x Cout] += S . W2_chunk with O in accumulators and
+//     the W2 fragments from L2 (requested at the top of the chunk);
+//   epilogue: + bias, round (the GEMM's rounding), + residual, round; 16-byte stores.
+// K order of the 3x3 = the implicit GEMM's ((ky, kx, ci) ascending, 16 per MFMA, one accumulator per output); the projection sums K = mid in the
+// same 16-element steps as the GEMM: with identical S bits the sums are the GEMM's. Built for Cout = 64 (stage 0: the two largest expanded
+// tensors); the Cout = 128 blocks of stage 1 keep the op list (their W2 fragments + 128 more accumulator registers do not fit beside S).
+template <int CIN, int S, int MCH>      // MCH = mid channels per chunk: 128 (one workgroup per CU) or 64 (half the accumulators: two workgroups per CU,
+                                        // one multiplying while the other runs its chunk epilogue on the vector ALU)
+__global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ b1,
+                                                 const bf16_t* __restrict__ w2, const bf16_t* __restrict__ b2, const bf16_t* __restrict__ res,
+                                                 bf16_t* __restrict__ out, int H, int W, int Ho, int Wo, int MID, int Kpad, int tiles_x,
+                                                 int tiles_y, int ntiles) {
+    constexpr int COUT = 64, TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PB = CIN * 2, CPP = CIN / 8;
+    constexpr int SH = CPP == 4 ? 2 : (CPP == 8 ? 1 : 0), KS_TAP = CIN / 16, NKT = (9 * CIN + 63) / 64;
+    constexpr int KPS = MCH == 64 ? 2 : 1;                                  // K-tiles per ring stage (one barrier per stage: at MCH = 64 a single K-tile is only 16 MFMAs per wave)
+    constexpr int NST = (NKT + KPS - 1) / KPS;                               // stages per chunk
+    constexpr int PATCH = (PH * PW * PB + 1023) & ~1023, RB = KPS * MCH * 128;     // bytes: the patch; one ring buffer = KPS K-tiles of MCH W1 rows x 64 k
+    constexpr int NJ = MCH / 32, NI = MCH / 32, NS2 = MCH / 16;             // mid tiles per chunk; request instructions per wave and K-tile; projection K steps per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem + PATCH;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int nchunks = MID / MCH;
+    // request side of the W1 ring: instruction i of wave wv fills rows (wv * 4 + i) * 8 + (lane >> 3) of a K-tile, physical chunk lane & 7
+    unsigned wq[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = (wv * NI + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        wq[i] = (unsigned)(row * Kpad * 2 + c * 16);
+    }
+#define FM_ISSUE(BUF, CH, ST)                                                                                           \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int t_ = 0; t_ < KPS; ++t_) {                                                            \
+            const int kt_ = min((ST) * KPS + t_, NKT - 1);          /* a stage past the last K-tile re-reads it (never multiplied) */ \
+            const unsigned char* b_ = reinterpret_cast<const unsigned char*>(w1) + ((long)(CH) * MCH * Kpad + kt_ * 64) * 2; \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_)                                                           \
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_ + wq[i_]), (lptr_t)(ring + (BUF) * RB + t_ * MCH * 128 + (wv * NI + i_) * 1024), 16, 0, 0); \
+        }                                                                                                               \
+    }
+    // read side
+    int xb[2], swz[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xb[i] = (((wv * 2 + i) * S) * PW + lr * S) * PB;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) swz[kx] = ((lr * S + kx) >> SH) & (CPP - 1);
+    int wl[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wl[kk] = lr * 128 + (((kk * 2 + lh) ^ ((lr >> 1) & 7)) << 4);
+
+    const int xcd = blockIdx.x & 7, gx = (int)gridDim.x >> 3, wx = (int)blockIdx.x >> 3;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int t_begin = xcd * per + min(xcd, rem), t_cnt = per + (xcd < rem ? 1 : 0);
+    for (int tl = wx; tl < t_cnt; tl += gx) {
+        const int bid = t_begin + tl;
+        const int b = bid / (tiles_x * tiles_y), tr = bid - b * tiles_x * tiles_y;
+        const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+        __syncthreads();                                     // the previous tile's patch and ring are done with
+        FM_ISSUE(0, 0, 0);
+        {   // patch
+            const bf16_t* img = in + (long)b * H * W * CIN;
+            const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+            for (int idx = tid; idx < PH * PW * CPP; idx += 256) {
+                const int px = idx / CPP, c = idx % CPP, pr = px / PW, pc = px - pr * PW;
+                const int iy = iy0 + pr, ix = ix0 + pc;
+                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) raw = *reinterpret_cast<const uint4*>(img + ((long)iy * W + ix) * CIN + c * 8);
+                *reinterpret_cast<uint4*>(smem + px * PB + ((c ^ ((pc >> SH) & (CPP - 1))) << 4)) = raw;
+            }
+        }
+        f32x16 oacc[2][2];                                   // [cout tile][row]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[j][i][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // patch + K-tile (chunk 0, 0) landed
+        for (int ch = 0; ch < nchunks; ++ch) {
+            // W2 fragments of this chunk (K = its 128 mid channels, 8 steps x 2 cout tiles) and its bias, requested now, used behind the K loop
+            u32x4 w2f[2][NS2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < NS2; ++s2)
+                    w2f[j][s2] = *reinterpret_cast<const u32x4*>(w2 + (long)(j * 32 + lr) * MID + ch * MCH + s2 * 16 + lh * 8);
+            uint2 b1r[NJ][4];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b1r[j][g] = *reinterpret_cast<const uint2*>(b1 + ch * MCH + j * 32 + g * 8 + lh * 4);
+            f32x16 sacc[NJ][2];                              // [mid tile][row]
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[j][i][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                // stage st of this chunk sits in buffer (ch * NST + st) & 1; the next one of the flat sequence travels into the other
+                const int f = ch * NST + st, buf = f & 1;
+                const bool more = st + 1 < NST || ch + 1 < nchunks;      // uniform
+                if (more) FM_ISSUE(buf ^ 1, st + 1 < NST ? ch : ch + 1, st + 1 < NST ? st + 1 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < KPS; ++t) {
+                const int kt = st * KPS + t;
+                if (kt >= NKT) break;
+                // fragments of K step kk + 1 are read while step kk multiplies (two named register sets, one LDS read placed between each
+                // pair of MFMAs by sched_group_barrier: left to hipcc the stream was read x 6, s_waitcnt lgkmcnt(0), MFMA x 4, read x 2, wait,
+                // MFMA x 4 -- every LDS round trip exposed, the matrix pipe half idle inside the loop)
+#define FM_R(XF, WF, KK)                                                                                                \
+    {                                                                                                                   \
+        const int s_ = kt * 4 + (KK), tap_ = s_ / KS_TAP < 9 ? s_ / KS_TAP : 8, c16_ = s_ % KS_TAP;                     \
+        const int ky_ = tap_ / 3, kx_ = tap_ - ky_ * 3;                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                \
+            XF[i_] = *reinterpret_cast<const u32x4*>(smem + xb[i_] + (ky_ * PW + kx_) * PB + (((c16_ * 2 + lh) ^ swz[kx_]) << 4)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) WF[j_] = *reinterpret_cast<const u32x4*>(ring + buf * RB + t * MCH * 128 + j_ * 4096 + wl[KK]); \
+    }
+#define FM_M(XF, WF)                                                                                                    \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                            \
+                sacc[j_][i_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WF[j_]), __builtin_bit_cast(bf16x8, XF[i_]), sacc[j_][i_], 0, 0, 0); \
+    }
+#define FM_SGB()                                                                                                        \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 + NJ; ++q_) {                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 - NJ, 0);                                                \
+    }
+                {
+                    u32x4 xfa[2], wfa[NJ], xfb[2], wfb[NJ];
+                    FM_R(xfa, wfa, 0);
+                    FM_R(xfb, wfb, 1);
+                    FM_M(xfa, wfa);
+                    FM_R(xfa, wfa, 2);
+                    FM_M(xfb, wfb);
+                    FM_R(xfb, wfb, 3);
+                    FM_M(xfa, wfa);
+                    FM_M(xfb, wfb);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+                    FM_SGB();
+                    FM_SGB();
+                    FM_SGB();
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                }
+#undef FM_R
+#undef FM_M
+#undef FM_SGB
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                             // the next K-tile landed; every wave is done with this one
+            }
+            // ---- S -> bias, Hardswish, bf16, A-operand layout; O += S . W2_chunk
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    uint32_t pk[4][2];                       // quad g: its 4 channels as two packed pairs
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float bq[4];
+                        load4(reinterpret_cast<const bf16_t*>(&b1r[j][g]), bq);
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = hardswish_f(sacc[j][i][4 * g + r] + bq[r]);
+                        pk[g][0] = pack2(v[0], v[1]); pk[g][1] = pack2(v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int p_ = 0; p_ < 2; ++p_) {
+                        // quads 2 p and 2 p + 1: lane l (lh = 0) ends with channels [16 p, + 8), lane l + 32 with [16 p + 8, + 8) of this mid tile
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * p_][0], pk[2 * p_ + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * p_][1], pk[2 * p_ + 1][1], false, false);
+                        const u32x4 x2 = {s0[0], s1[0], s0[1], s1[1]};
+                        const int s2 = j * 2 + p_;
+#pragma unroll
+                        for (int j2 = 0; j2 < 2; ++j2)
+                            oacc[j2][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2f[j2][s2]), __builtin_bit_cast(bf16x8, x2), oacc[j2][i], 0, 0, 0);
+                    }
+                }
+        }
+        // ---- output: + bias, round; + residual, round (the projection GEMM's epilogue); lane ends with channels [8 (2 p + lh), + 8) of a cout tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + wv * 2 + i, ox = ox0 + lr;
+            const bool live = oy < Ho && ox < Wo;
+            const long obase = (((long)b * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * COUT;
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[j2][i][8 * p_ + r]), __float_as_uint(oacc[j2][i][8 * p_ + 4 + r]), false, false);
+                        v[r] = __uint_as_float(sw[0]);
+                        v[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const int c0 = j2 * 32 + 8 * (2 * p_ + lh);
+                    float bv[8];
+                    unpack16(*reinterpret_cast<const uint4*>(b2 + c0), bv, (bf16_t*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = Ty<bf16_t>::rnd(v[e] + bv[e]);
+                    if (res) {
+                        float r8[8];
+                        unpack16(*reinterpret_cast<const uint4*>(res + obase + c0), r8, (bf16_t*)nullptr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    }
+                    if (live)
+                        *reinterpret_cast<uint4*>(out + obase + c0) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                }
+        }
+    }
+#undef FM_ISSUE
+}
+
 static inline bool fmb_shape_ok(int cin, int mid, int cout, int stride, int ho, int wo) {
-    (void)cin; (void)mid; (void)cout; (void)stride; (void)ho; (void)wo;
-    return false;
+    (void)ho; (void)wo;
+    return cout == 64 && mid % 128 == 0 && ((cin == 64 && stride == 1) || (cin == 32 && stride == 2));
+}
+
+static inline int launch_fmb(const bf16_t* in, const bf16_t* w1, const bf16_t* b1, const bf16_t* w2, const bf16_t* b2, const bf16_t* res, bf16_t* out,
+                             const bf16_t* zero, int B, int H, int W, int Cin, int Ho, int Wo, int Mid, int Cout, int stride, int pad, int Kpad,
+                             hipStream_t s) {
+    (void)zero;
+    if (!fmb_shape_ok(Cin, Mid, Cout, stride, Ho, Wo) || pad != 1 || !b1 || !b2) return SA_ERR_SHAPE;
+    const int tx = cdiv(Wo, 32), ty = cdiv(Ho, 8), ntiles = B * tx * ty;
+#define SA_FMB(CI, SS, MC, WGS)                                                                                                 \
+    {                                                                                                                           \
+        constexpr int PH_ = 7 * (SS) + 3, PW_ = 31 * (SS) + 3;                                                                  \
+        constexpr size_t lds = (size_t)((PH_ * PW_ * (CI) * 2 + 1023) & ~1023) + 2 * ((MC) == 64 ? 2 : 1) * (MC) * 128;         \
+        auto kern = fmb_kernel<CI, SS, MC>;                                                                                     \
+        static AttrOnce attr;                                                                                                   \
+        attr.ensure(kern, lds);                                                                                                 \
+        const unsigned g_ = (unsigned)std::max(8, std::min(ntiles, 256 * (WGS)) / 8 * 8);                                       \
+        hipLaunchKernelGGL(kern, dim3(g_), dim3(256), lds, s, in, w1, b1, w2, b2, res, out, H, W, Ho, Wo, Mid, Kpad, tx, ty, ntiles); \
+    }
+    if (Cin == 64) { if (tuning().fmb_chunk == 64) SA_FMB(64, 1, 64, 2) else SA_FMB(64, 1, 128, 1) }
+    else SA_FMB(32, 2, 128, 1)
+#undef SA_FMB
+    return (int)hipGetLastError();
 }
 template <typename T>
 static inline int launch_fmb(const T*, const T*, const T*, const T*, const T*, const T*, T*, const T*, int, int, int, int, int, int, int, int, int, int,

@@ -190,6 +190,7 @@ def test_cond256_bf16_teacher_forced(cond_bf16, bench_inputs):
     worst, mism, checked, positions = teacher_forced(m, g, tiles, grids, seqs, g["bf16_dev"].amax(-1))
     print(f"REC-FULL conditioned, 256 bench crops x {g['tokens'].shape[0]} steps, bf16 teacher-forced: worst logit error {worst:.4f} x max; "
           f"argmax checked at {checked}/{positions} positions, {mism} mismatches")
+    assert worst <= 0.020, worst                                 # measured 0.0160 x max|logit| on HEAD (the reference's own bf16 run: 0.0179): a drift of the kernels' error shows here
     assert checked >= 0.867 * positions, (checked, positions)      # measured 10 781 / 12 288 = 0.877 (a property of the fixture and its tolerance rule); floor = that minus one point
     assert mism == 0, (mism, checked)
 
