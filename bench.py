@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--aux-timeout", type=float, default=None,
                     help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
                          "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
+    ap.add_argument("--no-det-op-list", action="store_true", help="skip the det_fuse = 0 arm of the detection leg (counter passes: tools/profile_round.sh)")
     ap.add_argument("--det-fuse", type=int, default=63, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
     ap.add_argument("--no-slot-sweep", action="store_true", help="skip the e2e leg's 256 / 512 / 1024-slot sweep")
     ap.add_argument("--e2e-slots", type=lambda v: [int(x) for x in v.split(",")], default=[256, 512, 1024], help="slot counts of the e2e sweep")
@@ -477,20 +478,22 @@ def bench_det(args, local_rank, world, rank, barrier):
             if b in ("conv3x3", "conv1x1"):
                 buckets[f"{b}_tflops"] = round(bk[b][1] / bk[b][0] / 1e9, 1) if bk[b][0] else 0.0
             buckets[f"{b}_launches"] = bk[b][2]
-        L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(0)), "surya_set_tuning")
-        try:
-            for _ in range(2):
-                m.forward(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.det_steps):
-                heat0 = m.forward(x)
-            torch.cuda.synchronize()
-            dt0 = (time.perf_counter() - t0) / args.det_steps
-        finally:
-            L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(args.det_fuse)), "surya_set_tuning")
+        heat0, dt0 = heat, None
+        if not args.no_det_op_list:
+            L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(0)), "surya_set_tuning")
+            try:
+                for _ in range(2):
+                    m.forward(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.det_steps):
+                    heat0 = m.forward(x)
+                torch.cuda.synchronize()
+                dt0 = (time.perf_counter() - t0) / args.det_steps
+            finally:
+                L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(args.det_fuse)), "surya_set_tuning")
         dfu = (heat0 - heat).abs()
-        buckets.update({"op_list_ms_per_step": round(dt0 * 1e3, 2), "op_list_pages_per_s": round(args.det_pages / dt0, 1),
+        buckets.update({"op_list_ms_per_step": round(dt0 * 1e3, 2) if dt0 else None, "op_list_pages_per_s": round(args.det_pages / dt0, 1) if dt0 else None,
                         "fused_vs_op_list_max_abs_diff": round(float(dfu.max()), 5), "fused_vs_op_list_mean_abs_diff": round(float(dfu.mean()), 6),
                         "det_fuse": args.det_fuse,
                         "bucket_note": "event-timed per op (min of 3 passes, ~4.5 us of event overhead inside each op's figure); depthwise_ms = MBConv "

@@ -1,10 +1,9 @@
-"""Result objects of the two predictors of the layout model family, field for field what the reference's callers (marker, the
-surya_layout / surya_table CLIs) read:
+"""Result objects of LayoutPredictor, field for field what the reference's callers (marker, the surya_layout CLI) read:
 
   LayoutBox / LayoutResult                      <- surya/layout/schema.py:8-17
-  TableCell / TableRow / TableCol / TableResult <- surya/table_rec/schema.py:8-48
 
-All boxes are common.geometry.PolygonBox (4 corners, derived bbox / width / height, optional confidence)."""
+(TableRecPredictor's are in table_rec/schema.py.) All boxes are common.geometry.PolygonBox (4 corners, derived bbox / width / height,
+optional confidence)."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional
@@ -27,42 +26,3 @@ class LayoutResult(BaseModel):
     bboxes: List[LayoutBox]
     image_bbox: List[float]                  # [0, 0, width, height] of the input page
     sliced: bool = False                     # the page was cut into slices (layout/slicer.py) and its boxes were shifted back
-
-
-# ------------------------------------------------------------------------------------------------------- table recognition
-class _TableBox(PolygonBox):
-    is_header: bool
-
-
-class TableRow(_TableBox):
-    row_id: int
-    label = property(lambda self: f"Row {self.row_id}")
-
-
-class TableCol(_TableBox):
-    col_id: int
-    label = property(lambda self: f"Column {self.col_id}")
-
-
-class TableCell(_TableBox):
-    """A grid cell (row x column intersection) or a spanning cell from the second decoding pass; `merge_up` / `merge_down` are the
-    decoder's vertical-merge votes, `rowspan` grows when TableRecPredictor.decode_batch_predictions acts on them; `text_lines` is
-    filled by callers that run OCR on the table afterwards."""
-    row_id: int
-    cell_id: int
-    within_row_id: int
-    colspan: int
-    rowspan: Optional[int] = None
-    col_id: Optional[int] = None
-    merge_up: bool = False
-    merge_down: bool = False
-    text_lines: Optional[List[dict]] = None
-    label = property(lambda self: f"Cell {self.cell_id} {self.rowspan}/{self.colspan}")
-
-
-class TableResult(BaseModel):
-    cells: List[TableCell]                   # after vertical merges
-    unmerged_cells: List[TableCell]
-    rows: List[TableRow]
-    cols: List[TableCol]
-    image_bbox: List[float]

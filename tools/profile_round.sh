@@ -7,8 +7,8 @@ TAG=${1:-r03k}
 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p1 -- python $R/bench.py --no-cpu-baseline --no-texify --no-layout --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/tmp/e1
 [ -n "$SKIP_REC_PMC" ] || rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/p2 -- python $R/bench.py --no-cpu-baseline --no-det --no-e2e --no-texify --no-layout --steps 1 --warmup 0 > /tmp/o2 2>/tmp/e2
 [ -n "$SKIP_REC_PMC" ] || rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/p3 -- python $R/bench.py --no-cpu-baseline --no-det --no-e2e --no-texify --no-layout --steps 1 --warmup 0 > /tmp/o3 2>/tmp/e3
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/p4 -- python $R/bench.py --det-only --no-cpu-baseline --det-steps 2 > /tmp/o4 2>/tmp/e4
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/p5 -- python $R/bench.py --det-only --no-cpu-baseline --det-steps 2 > /tmp/o5 2>/tmp/e5
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/p4 -- python $R/bench.py --det-only --no-cpu-baseline --no-det-op-list --det-steps 2 > /tmp/o4 2>/tmp/e4
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/p5 -- python $R/bench.py --det-only --no-cpu-baseline --no-det-op-list --det-steps 2 > /tmp/o5 2>/tmp/e5
 cd $R
 db() { find /tmp/$1 -name "*.db" | head -1; }
 python tools/rocpd_stats.py $(db p1) --by-grid > gpurun_out/${TAG}_kernel_stats.md 2>&1

@@ -67,7 +67,7 @@ def det_json(rows):
         if "post_" in name or "rocclr" in name or "prof_null" in name:
             continue
         tot += total * 1024 * (2 if ctr == "FETCH_SIZE" else 1)
-        if ctr == "FETCH_SIZE" and "upsample_planes_kernel" in name:
+        if ctr == "FETCH_SIZE" and "upsample_planes" in name:      # upsample_planes_kernel / upsample_planes4_kernel
             fw += cnt
     print(json.dumps({"detection forward (all kernels)": round(tot / max(fw, 1)), "forwards": fw}, indent=1))
 
