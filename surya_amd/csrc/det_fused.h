@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 // SGPR source, each input vector unpacked once, 86 VGPRs -- runs 79 us against this version's 62: the scalar loads of a rolled row loop sit
 // on the critical path of every filter row.)
 __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
-                                                      bf16_t* __restrict__ out, int H, int W, int C, int tiles_x) {
+                                                      bf16_t* __restrict__ out, const bf16_t* __restrict__ zero, int H, int W, int C, int tiles_x) {
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4;
     __shared__ __attribute__((aligned(16))) unsigned char in_t[PH * PW * 64];
     __shared__ __attribute__((aligned(16))) float wd[25 * 32];
@@ -162,12 +162,23 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
     const int g = blockIdx.y, b = blockIdx.z;
     const int y0 = ((int)blockIdx.x / tiles_x) * TH, x0 = ((int)blockIdx.x % tiles_x) * TW;
     const bf16_t* img = in + (long)b * H * W * C + g * 32;
-    for (int idx = tid; idx < PH * PW * 4; idx += 256) {
-        const int px = idx >> 2, c = idx & 3, ty = px / PW, tx = px - ty * PW;
-        const int gy = y0 - 2 + ty, gx = x0 - 2 + tx;
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) raw = *reinterpret_cast<const uint4*>(img + ((long)gy * W + gx) * C + c * 8);
-        *reinterpret_cast<uint4*>(in_t + px * 64 + c * 16) = raw;
+    {   // patch: direct-to-LDS requests, all in flight at once (16-byte slot = pixel * 4 + chunk, 27 instructions of 64 slots; outside the image
+        // the lane reads the zero page). Staged through registers in a rolled loop it was one global round trip per 16 bytes and thread, 7 in a row.
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int wq = __builtin_amdgcn_readfirstlane(wv);
+        static_assert(PH * PW * 4 % 64 == 0, "whole instructions");
+#pragma unroll
+        for (int k = 0; k < (PH * PW * 4 / 64 + 3) / 4; ++k) {
+            const int q = k * 4 + wq;
+            if (q < PH * PW * 4 / 64) {
+                const int idx = q * 64 + lane, px = idx >> 2, c = idx & 3, ty = px / PW, tx = px - ty * PW;
+                const int gy = y0 - 2 + ty, gx = x0 - 2 + tx;
+                const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const bf16_t* gp = inb ? img + ((long)gy * W + gx) * C + c * 8 : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(in_t + q * 1024), 16, 0, 0);
+            }
+        }
     }
     if (tid < 100) {
         const int tap = tid >> 2, c = tid & 3;
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) wd[tap * 32 + c * 8 + e] = t[e];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
         const int chunk = tid & 3, x = (tid >> 2) & 31, yg = tid >> 7;
@@ -239,13 +251,14 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
     }
 }
 
-static inline int launch_dw5_g1x1(const bf16_t* in, const bf16_t* wdw, const bf16_t* wg, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
+static inline int launch_dw5_g1x1(const bf16_t* in, const bf16_t* wdw, const bf16_t* wg, bf16_t* out, const bf16_t* zero, int B, int H, int W, int C,
+                                  hipStream_t s) {
     const int tx = cdiv(W, 32), ty = cdiv(H, 8);
-    hipLaunchKernelGGL(dw5_g1x1_kernel, dim3(tx * ty, C / 32, B), dim3(256), 0, s, in, wdw, wg, out, H, W, C, tx);
+    hipLaunchKernelGGL(dw5_g1x1_kernel, dim3(tx * ty, C / 32, B), dim3(256), 0, s, in, wdw, wg, out, zero, H, W, C, tx);
     return (int)hipGetLastError();
 }
 template <typename T>
-static inline int launch_dw5_g1x1(const T*, const T*, const T*, T*, int, int, int, int, hipStream_t) { return SA_ERR_UNSUPPORTED; }
+static inline int launch_dw5_g1x1(const T*, const T*, const T*, T*, const T*, int, int, int, int, hipStream_t) { return SA_ERR_UNSUPPORTED; }
 
 // ---------------------------------------------------------------------------------------------------
 // Decode head with z0 inside (SA_DET_UPSUM_CLASSIFY + the stage-0 1x1 convolution that feeds it). head_upsum_classify_blk_kernel read
@@ -809,17 +822,44 @@ static inline int launch_stem_conv(const T*, const T*, const T*, const T*, T*, i
 // K order of the 3x3 = the implicit GEMM's ((ky, kx, ci) ascending, 16 per MFMA, one accumulator per output); the projection sums K = mid in the
 // same 16-element steps as the GEMM: with identical S bits the sums are the GEMM's. Built for Cout = 64 (stage 0: the two largest expanded
 // tensors); the Cout = 128 blocks of stage 1 keep the op list (their W2 fragments + 128 more accumulator registers do not fit beside S).
+// Build-time A/B switches of fmb_kernel (tools/microbench/fmb_variants.sh; gpurun r06ab, op 4 = the Cin 32 stride-2 block, op 6 = the Cin 64 block):
+//   SA_FMB_PK    chunk epilogue on fp32 pairs:        op 4 621 -> 579 us, op 6 374 -> 384 (256-register variant: more spills)  => on at MCH = 128 only
+//   SA_FMB_NB3   three ring buffers at MCH = 128:     op 4 621 -> 639                                                             => off
+//   SA_FMB_OVL   next tile's patch under the tail:    op 4 621 -> 631                                                             => off
+// (the timing ablations that pointed at the ring and the patch -- 33 and 65 us of op 4 -- measured the BURST of 256 synchronised workgroups
+// asking for 18 MB at once, not a latency a deeper ring or a 3 us earlier request could hide)
+#ifndef SA_FMB_NB3
+#define SA_FMB_NB3 0
+#endif
+#ifndef SA_FMB_OVL
+#define SA_FMB_OVL 0
+#endif
+#ifndef SA_FMB_PK
+#define SA_FMB_PK 1
+#endif
+#ifndef SA_FMB_LATEW
+#define SA_FMB_LATEW 1
+#endif
+#ifndef SA_FMB_ABL
+#define SA_FMB_ABL 0                     // timing ablations (tools/microbench/fmb_ablate.sh; results are wrong with any bit set): 1 chunk epilogue without
+#endif                                   // bias + Hardswish, 2 no W1 ring requests after a tile's first, 4 no patch requests, 8 one K stage per chunk
 template <int CIN, int S, int MCH>      // MCH = mid channels per chunk: 128 (one workgroup per CU) or 64 (half the accumulators: two workgroups per CU,
                                         // one multiplying while the other runs its chunk epilogue on the vector ALU)
 __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ b1,
                                                  const bf16_t* __restrict__ w2, const bf16_t* __restrict__ b2, const bf16_t* __restrict__ res,
-                                                 bf16_t* __restrict__ out, int H, int W, int Ho, int Wo, int MID, int Kpad, int tiles_x,
-                                                 int tiles_y, int ntiles) {
+                                                 bf16_t* __restrict__ out, const bf16_t* __restrict__ zero, int H, int W, int Ho, int Wo, int MID,
+                                                 int Kpad, int tiles_x, int tiles_y, int ntiles) {
     constexpr int COUT = 64, TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PB = CIN * 2, CPP = CIN / 8;
     constexpr int SH = CPP == 4 ? 2 : (CPP == 8 ? 1 : 0), KS_TAP = CIN / 16, NKT = (9 * CIN + 63) / 64;
     constexpr int KPS = MCH == 64 ? 2 : 1;                                  // K-tiles per ring stage (one barrier per stage: at MCH = 64 a single K-tile is only 16 MFMAs per wave)
     constexpr int NST = (NKT + KPS - 1) / KPS;                               // stages per chunk
     constexpr int PATCH = (PH * PW * PB + 1023) & ~1023, RB = KPS * MCH * 128;     // bytes: the patch; one ring buffer = KPS K-tiles of MCH W1 rows x 64 k
+    // One workgroup per CU (MCH = 128): nothing else hides a stall, so the ring has THREE buffers (a stage's requests are issued two stages
+    // = ~2000 cycles ahead; one stage ahead left 33 us of op 4 waiting on L2, SA_FMB_ABL = 2) and the NEXT tile's patch and first two stages are
+    // requested behind the tile's last K stage, under its last chunk epilogue and output epilogue (patch round trip: 65 us of op 4, SA_FMB_ABL = 4).
+    // Two workgroups per CU (MCH = 64): two buffers (LDS), the other workgroup covers.
+    constexpr int NB = (MCH == 128 && SA_FMB_NB3) ? 3 : 2, PD = NB - 1;
+    constexpr bool OVL = MCH == 128 && SA_FMB_OVL;
     constexpr int NJ = MCH / 32, NI = MCH / 32, NS2 = MCH / 16;             // mid tiles per chunk; request instructions per wave and K-tile; projection K steps per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem + PATCH;
@@ -843,6 +883,38 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                 __builtin_amdgcn_global_load_lds((gptr_t)(b_ + wq[i_]), (lptr_t)(ring + (BUF) * RB + t_ * MCH * 128 + (wv * NI + i_) * 1024), 16, 0, 0); \
         }                                                                                                               \
     }
+    // patch requests of tile (BB, OY0, OX0): direct to LDS, all in flight at once. 16-byte slot = pixel * CPP + physical chunk, instruction q fills
+    // slots [64 q, + 64) = 64 / CPP pixels (they wrap over at most one patch row end: no division); a lane outside the image writes zeros itself.
+    // The first version staged the patch through registers in a rolled loop -- one global round trip per 16 bytes and thread, 17 in a row at
+    // S = 2: ~25 of a tile's 45 us (ISA: load, vmcnt(0), ds_write).
+#define FM_PATCH(BB, OY0, OX0)                                                                                          \
+    {                                                                                                                   \
+        const unsigned char* img_ = reinterpret_cast<const unsigned char*>(in + (long)(BB) * H * W * CIN);              \
+        const int iy0_ = (OY0) * S - 1, ix0_ = (OX0) * S - 1;                                                           \
+        int ln_ = lane;                                                                                                 \
+        asm volatile("" : "+v"(ln_));       /* opaque per tile: visible, hipcc hoists every slot's (row, column) out of the tile loop and spills */ \
+        const int lp_ = ln_ / CPP, lc_ = ln_ % CPP;                                                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < (PATCH / 1024 + 3) / 4; ++k_) {                                         \
+            const int q_ = k_ * 4 + wv;                              /* wave-uniform */                               \
+            if (q_ < PATCH / 1024 && !(SA_FMB_ABL & 4)) {                                                               \
+                const int p0_ = q_ * (64 / CPP), r0_ = p0_ / PW, c0_ = p0_ - r0_ * PW;     /* scalar */                 \
+                int pc_ = c0_ + lp_;                                                                                    \
+                const bool wrap_ = pc_ >= PW;                                                                           \
+                pc_ -= wrap_ ? PW : 0;                                                                                  \
+                const int iy_ = iy0_ + r0_ + (wrap_ ? 1 : 0), ix_ = ix0_ + pc_;                                         \
+                const bool inb_ = p0_ + lp_ < PH * PW && (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;    \
+                const unsigned off_ = (unsigned)(((iy_ * W + ix_) * CIN + ((lc_ ^ ((pc_ >> SH) & (CPP - 1))) << 3)) * 2); \
+                if (inb_) __builtin_amdgcn_global_load_lds((gptr_t)(img_ + off_), (lptr_t)(smem + q_ * 1024), 16, 0, 0); \
+                else *reinterpret_cast<uint4*>(smem + q_ * 1024 + ln_ * 16) = make_uint4(0u, 0u, 0u, 0u);               \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+    // a tile's first PD ring stages + its patch
+#define FM_HEAD(BB, OY0, OX0)                                                                                           \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < PD; ++s_) FM_ISSUE(s_, s_ / NST, s_ % NST);                             \
+        FM_PATCH(BB, OY0, OX0);                                                                                         \
+    }
     // read side
     int xb[2], swz[3];
 #pragma unroll
@@ -860,18 +932,9 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
         const int bid = t_begin + tl;
         const int b = bid / (tiles_x * tiles_y), tr = bid - b * tiles_x * tiles_y;
         const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
-        __syncthreads();                                     // the previous tile's patch and ring are done with
-        FM_ISSUE(0, 0, 0);
-        {   // patch
-            const bf16_t* img = in + (long)b * H * W * CIN;
-            const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-            for (int idx = tid; idx < PH * PW * CPP; idx += 256) {
-                const int px = idx / CPP, c = idx % CPP, pr = px / PW, pc = px - pr * PW;
-                const int iy = iy0 + pr, ix = ix0 + pc;
-                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) raw = *reinterpret_cast<const uint4*>(img + ((long)iy * W + ix) * CIN + c * 8);
-                *reinterpret_cast<uint4*>(smem + px * PB + ((c ^ ((pc >> SH) & (CPP - 1))) << 4)) = raw;
-            }
+        if (!OVL || tl == wx) {
+            __syncthreads();                                 // the previous tile's patch and ring are done with
+            FM_HEAD(b, oy0, ox0);
         }
         f32x16 oacc[2][2];                                   // [cout tile][row]
 #pragma unroll
@@ -882,19 +945,23 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                 for (int r = 0; r < 16; ++r) oacc[j][i][r] = 0.f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // patch + K-tile (chunk 0, 0) landed
+        int fb = 0;                                          // buffer of the chunk's stage 0
         for (int ch = 0; ch < nchunks; ++ch) {
-            // W2 fragments of this chunk (K = its 128 mid channels, 8 steps x 2 cout tiles) and its bias, requested now, used behind the K loop
+            // W2 fragments of this chunk (K = its MCH mid channels, NS2 steps x 2 cout tiles) and its bias: requested at the top of the chunk and used
+            // behind the K loop (MCH = 128, one workgroup per CU), or requested behind the K loop (MCH = 64 with SA_FMB_LATEW: 48 registers fewer
+            // across the loop -- at 256 registers the early request spilled 38 -- and the second workgroup covers the round trip)
             u32x4 w2f[2][NS2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int s2 = 0; s2 < NS2; ++s2)
-                    w2f[j][s2] = *reinterpret_cast<const u32x4*>(w2 + (long)(j * 32 + lr) * MID + ch * MCH + s2 * 16 + lh * 8);
             uint2 b1r[NJ][4];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) b1r[j][g] = *reinterpret_cast<const uint2*>(b1 + ch * MCH + j * 32 + g * 8 + lh * 4);
+#define FM_LOADW()                                                                                                      \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
+            _Pragma("unroll") for (int s2_ = 0; s2_ < NS2; ++s2_)                                                       \
+                w2f[j_][s2_] = *reinterpret_cast<const u32x4*>(w2 + (long)(j_ * 32 + lr) * MID + ch * MCH + s2_ * 16 + lh * 8); \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                               \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) b1r[j_][g_] = *reinterpret_cast<const uint2*>(b1 + ch * MCH + j_ * 32 + g_ * 8 + lh * 4); \
+    }
+            constexpr bool LATEW = MCH == 64 && SA_FMB_LATEW;
+            if (!LATEW) FM_LOADW();
             f32x16 sacc[NJ][2];                              // [mid tile][row]
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -904,10 +971,12 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                     for (int r = 0; r < 16; ++r) sacc[j][i][r] = 0.f;
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                // stage st of this chunk sits in buffer (ch * NST + st) & 1; the next one of the flat sequence travels into the other
-                const int f = ch * NST + st, buf = f & 1;
-                const bool more = st + 1 < NST || ch + 1 < nchunks;      // uniform
-                if (more) FM_ISSUE(buf ^ 1, st + 1 < NST ? ch : ch + 1, st + 1 < NST ? st + 1 : 0);
+                // stage st of this chunk sits in buffer (ch * NST + st) % NB; the one PD stages on in the tile's flat sequence is requested now,
+                // into the buffer every wave left at the last barrier
+                const int buf = (fb + st) % NB;
+                const bool more = st + PD < NST || ch + 1 < nchunks;     // uniform
+                if (more && !(SA_FMB_ABL & 2)) FM_ISSUE((fb + st + PD) % NB, st + PD < NST ? ch : ch + 1, (st + PD) % NST);
+                if ((SA_FMB_ABL & 8) && st > 0) continue;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < KPS; ++t) {
@@ -960,8 +1029,18 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
 #undef FM_M
 #undef FM_SGB
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                             // the next K-tile landed; every wave is done with this one
+                // the next stage landed (everything but the requests just issued -- in-order return among loads; no store is in flight here)
+                if (NB == 3 && more && !(SA_FMB_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPS * NI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                             // ... and every wave is done with this one
+            }
+            fb = (fb + NST) % NB;
+            if (LATEW) FM_LOADW();
+#undef FM_LOADW
+            if (OVL && ch + 1 == nchunks && tl + gx < t_cnt) {   // the next tile's patch and first stages travel under this chunk's epilogue and the stores
+                const int bidn = t_begin + tl + gx;
+                const int bn = bidn / (tiles_x * tiles_y), trn = bidn - bn * tiles_x * tiles_y;
+                FM_HEAD(bn, (trn / tiles_x) * TH, (trn % tiles_x) * TW);
             }
             // ---- S -> bias, Hardswish, bf16, A-operand layout; O += S . W2_chunk
 #pragma unroll
@@ -971,12 +1050,32 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                     uint32_t pk[4][2];                       // quad g: its 4 channels as two packed pairs
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
+                        // on fp32 PAIRS (v_pk_add_f32 / v_pk_mul_f32; the clamp stays one v_med3 per value): the scalar form was ~8 vector
+                        // instructions per value at one wave per SIMD (107 of op 4's 589 us, SA_FMB_ABL = 1). Same operations in the same order
+                        // as hardswish_f(s + b): (x * clamp(x + 3, 0, 6)) * (1 / 6), every step one fp32 rounding.
                         float bq[4];
                         load4(reinterpret_cast<const bf16_t*>(&b1r[j][g]), bq);
+#if SA_FMB_PK
+                      if (MCH == 128) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 x = f32x2{sacc[j][i][4 * g + 2 * h], sacc[j][i][4 * g + 2 * h + 1]};
+                            if (!(SA_FMB_ABL & 1)) {
+                                x = x + f32x2{bq[2 * h], bq[2 * h + 1]};
+                                f32x2 t = x + f32x2{3.0f, 3.0f};
+                                t = f32x2{__builtin_amdgcn_fmed3f(t.x, 0.0f, 6.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 6.0f)};
+                                x = (x * t) * f32x2{1.0f / 6.0f, 1.0f / 6.0f};
+                            }
+                            pk[g][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+                        }
+                      } else
+#endif
+                      {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = hardswish_f(sacc[j][i][4 * g + r] + bq[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = (SA_FMB_ABL & 1) ? sacc[j][i][4 * g + r] : hardswish_f(sacc[j][i][4 * g + r] + bq[r]);
                         pk[g][0] = pack2(v[0], v[1]); pk[g][1] = pack2(v[2], v[3]);
+                      }
                     }
 #pragma unroll
                     for (int p_ = 0; p_ < 2; ++p_) {
@@ -1025,6 +1124,8 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
         }
     }
 #undef FM_ISSUE
+#undef FM_PATCH
+#undef FM_HEAD
 }
 
 static inline bool fmb_shape_ok(int cin, int mid, int cout, int stride, int ho, int wo) {
@@ -1035,18 +1136,17 @@ static inline bool fmb_shape_ok(int cin, int mid, int cout, int stride, int ho, 
 static inline int launch_fmb(const bf16_t* in, const bf16_t* w1, const bf16_t* b1, const bf16_t* w2, const bf16_t* b2, const bf16_t* res, bf16_t* out,
                              const bf16_t* zero, int B, int H, int W, int Cin, int Ho, int Wo, int Mid, int Cout, int stride, int pad, int Kpad,
                              hipStream_t s) {
-    (void)zero;
     if (!fmb_shape_ok(Cin, Mid, Cout, stride, Ho, Wo) || pad != 1 || !b1 || !b2) return SA_ERR_SHAPE;
     const int tx = cdiv(Wo, 32), ty = cdiv(Ho, 8), ntiles = B * tx * ty;
 #define SA_FMB(CI, SS, MC, WGS)                                                                                                 \
     {                                                                                                                           \
         constexpr int PH_ = 7 * (SS) + 3, PW_ = 31 * (SS) + 3;                                                                  \
-        constexpr size_t lds = (size_t)((PH_ * PW_ * (CI) * 2 + 1023) & ~1023) + 2 * ((MC) == 64 ? 2 : 1) * (MC) * 128;         \
+        constexpr size_t lds = (size_t)((PH_ * PW_ * (CI) * 2 + 1023) & ~1023) + ((MC) == 64 ? 2 * 2 : (SA_FMB_NB3 ? 3 : 2)) * (MC) * 128; \
         auto kern = fmb_kernel<CI, SS, MC>;                                                                                     \
         static AttrOnce attr;                                                                                                   \
         attr.ensure(kern, lds);                                                                                                 \
         const unsigned g_ = (unsigned)std::max(8, std::min(ntiles, 256 * (WGS)) / 8 * 8);                                       \
-        hipLaunchKernelGGL(kern, dim3(g_), dim3(256), lds, s, in, w1, b1, w2, b2, res, out, H, W, Ho, Wo, Mid, Kpad, tx, ty, ntiles); \
+        hipLaunchKernelGGL(kern, dim3(g_), dim3(256), lds, s, in, w1, b1, w2, b2, res, out, zero, H, W, Ho, Wo, Mid, Kpad, tx, ty, ntiles); \
     }
     if (Cin == 64) { if (tuning().fmb_chunk == 64) SA_FMB(64, 1, 64, 2) else SA_FMB(64, 1, 128, 1) }
     else SA_FMB(32, 2, 128, 1)

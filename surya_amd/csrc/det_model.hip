@@ -245,7 +245,7 @@ struct DetModel : DetBase {
                     if constexpr (std::is_same<T, bf16_t>::value) {
                         if (fk == FUSE_MLA_AGG) {
                             const surya_det_op& gp = ops[fuse_with[oi]];
-                            if ((rc = launch_dw5_g1x1(bufs[op.in0], WT(op.w_idx), WT(gp.w_idx), bufs[gp.out], B, op.hin, op.win, op.cin, s))) return rc;
+                            if ((rc = launch_dw5_g1x1(bufs[op.in0], WT(op.w_idx), WT(gp.w_idx), bufs[gp.out], zero_page, B, op.hin, op.win, op.cin, s))) return rc;
                             break;
                         }
                         if (fk == FUSE_DWPROJ) {
