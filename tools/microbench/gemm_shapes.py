@@ -12,6 +12,8 @@ shapes = [(46460, 6912, 1280, 3, "enc gate|up"), (46460, 3840, 1280, 0, "enc qkv
 import os
 if os.environ.get("ONLY_DECODE"):
     shapes = [s for s in shapes if s[0] == 256]
+if os.environ.get("ONLY_SHAPE"):                    # counter passes: one launch shape per run (tools/profile_bigtile_pmc.sh)
+    shapes = [s for s in shapes if s[4] == os.environ["ONLY_SHAPE"]]
 for M, N, K, epi, name in shapes:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     b = torch.randn(N, device="cuda").bfloat16()
