@@ -186,6 +186,10 @@ struct Tuning {
     int split_max = 8;       // slice cap (the reduce kernels keep <= 8 slabs in flight)
     int bigtile = 3;         // 256x256 tiles for large bf16 GEMMs: 3 = the 8-phase schedule (round 5; even K-tile counts, else the 2-stage loop), 1 = 2-stage loop, 2 = 2-stage on 4 waves, 0 = 128x128 only
     int bigtile_any = 0;     // 1: every M > 256 bf16 GEMM takes the 256x256 tile whatever its round count (tests / race screens of the tile on small shapes)
+    int big_m_split = -1;    // decode projections above 256 rows (round 6): split-K tile -- -1 = by workgroup count (128x128 once it fills half the chip, else 128x64 within one round; 4-stage ring),
+                             // 0 = the 64x64 tile of the <= 256-row regime, 2 = 128x128, 3 = 128x64 (slice count unchanged: same bits in every arm)
+    int big_m_gateup = -1;   // decode gate|up above 256 rows: -1 = by rows (8-phase 256x256 tile at 4-6 row blocks, else the generic choice), 0 = generic,
+                             // 1 = persistent 8-phase loop, 2 = 8-phase tile per workgroup
     int gateup_ring = 2;     // decode gate|up (64x64 tiles, M in (128, 256]): LDS stages of its direct-to-LDS loop (2 = unrolled pair, 3 / 4 = ring with counted vmcnt)
     int conv_persist = 3;    // 3 x 3 / 5 x 5 convolutions on 256x256 tiles on the persistent 8-phase loop with the gather in its request stream: bit 0 = Cin % 64 == 0 (a K-tile is one tap), bit 1 = Cin == 32 (two taps per K-tile); 0 = one-tile 2-stage kernel
     int dwconv_pipe = 2;     // depthwise convolutions: 2 = round-3 kernel with its index split by host-made reciprocals (64-bit % and / were ~700 instructions per thread; +1 % on the forward), 1 = all loads unconditional (hipcc hoists them all: 2 waves per SIMD, -4.5 %), 0 = round-3 kernel

@@ -1606,6 +1606,18 @@ static inline int launch_gemm(const GemmArgs<TI, TO>& a, hipStream_t s) {
             return rc;
         }
     }
+    if constexpr (EPI == EPI_SWIGLU && sizeof(TI) == 2 && sizeof(TO) == 2) {
+        // decode (and small-prefill) gate|up above 256 rows (round 6): 4-6 row blocks x 40 column tiles of 256 x 256 are 160-240 workgroups -- too few for the cost model
+        // below, but the 8-phase tile at 0.62-0.94 of the chip still beats 128 x 128 tiles (1024 rows: 47.7 -> 30 us per layer, 280 us per step;
+        // at 768 rows = 120 tiles it loses 90 us per step). Same K order: tokens identical.
+        const int mode = tuning().big_m_gateup;             // -1 = by rows, 0 = never, 1 = persistent loop, 2 = one tile per workgroup
+        const int rb = cdiv(a.M, 256), t256 = rb * cdiv(a.N, 256);
+        const int pick = mode >= 0 ? mode : ((rb >= 4 && t256 >= 160 && t256 < 256) ? 2 : 0);     // (256 tiles and more: the cost model below)
+        if (pick && (a.K / Ty<TI>::KE) % 2 == 0 && a.K / Ty<TI>::KE >= 4 && a.N % 8 == 0) {
+            if (pick == 1) return launch_gemm_persist<TI, TO, EPI>(a, s);
+            return launch_gemm_cfg<TI, TO, 256, 256, 4, 2, EPI, false, 8>(a, s);
+        }
+    }
     if (a.N <= 64 && a.M >= 128 * 256) return launch_gemm_cfg<TI, TO, 128, 64, 4, 1, EPI>(a, s);   // narrow outputs (1x1 convs to 64 ch)
     const long big = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const int glds = tuning().glds;
@@ -1673,6 +1685,21 @@ static inline int launch_gemm_splitk(GemmArgs<TI, TI>& a, hipStream_t s) {
     // 64x64 tiles with a 4-stage direct-to-LDS ring and ~256 workgroups. 128x64 / 128x128 split-K tiles (fewer L2->CU requests per
     // MAC, more slices) were measured in r02 and lose by 70-180 us per decode step (profiles/r02_decode_sweeps.md).
     a.splitk = pick_splitk(cdiv(a.N, 64), nk);
+    // above 256 rows (round 6) the 64 x 64 tile re-reads every W slice once per 64 rows and every X row block once per 64 columns: the slice
+    // count stays a function of (N, K) -- same K grouping, same bits -- and only the tile grows
+    // (tools/microbench/decode_sweep.py --configs bigm, gpurun r06ad: at 1024 rows 128 x 128 tiles with the 4-stage ring take 290 us off the
+    // 2772 us step -- 8 x 14 x 2 / 8 x 10 x 3 workgroups = one round of the chip; at 768 rows 160 us; at 384 / 512 rows they fill half the chip and
+    // lose, and 128 x 64 tiles take 60-70 us off. Tokens identical in every arm.)
+    if constexpr (sizeof(TI) == 2) {
+        const int mode = tuning().big_m_split;              // -1 = by rows, 0 = 64 x 64 always, 2 / 3 = force
+        // by workgroup count (one workgroup per CU for both larger tiles): 128 x 128 once it fills more than half the chip (640 rows: 140-150
+        // workgroups, 1784 against 1890 us per step; 512 rows: 112-120, loses), else 128 x 64 while it stays within one round (384 / 512 rows:
+        // 168-240 workgroups, 60-70 us per step; at 640 rows it needs 280-300 and loses)
+        const int w128 = cdiv(a.M, 128) * cdiv(a.N, 128) * a.splitk, w12864 = cdiv(a.M, 128) * cdiv(a.N, 64) * a.splitk;
+        const int pick = a.M <= 256 ? 0 : (mode >= 0 ? mode : (w128 >= 136 ? 2 : (w12864 <= 256 ? 3 : 0)));
+        if (pick == 2) return launch_gemm_cfg<TI, TI, 128, 128, 2, 2, EPI_BIAS, true, 4>(a, s);
+        if (pick == 3) return launch_gemm_cfg<TI, TI, 128, 64, 4, 1, EPI_BIAS, true, 4>(a, s);
+    }
     return launch_gemm_cfg<TI, TI, 64, 64, 2, 2, EPI_BIAS, true, 4>(a, s);
 }
 

@@ -210,12 +210,14 @@ def test_streamed_detect_recognise_equals_the_serial_call(hip_lib, slots, det_ba
     assert rec(only_blank, det_predictor=det3) == s3
 
 
-@pytest.mark.parametrize("cfg_name,dtype,n_lines,max_slots", [("REC-TINY", torch.bfloat16, 400, 512), ("REC-FULL", torch.bfloat16, 330, 384)])
+@pytest.mark.parametrize("cfg_name,dtype,n_lines,max_slots", [("REC-TINY", torch.bfloat16, 400, 512), ("REC-FULL", torch.bfloat16, 330, 384),
+                                                                  ("REC-FULL", torch.bfloat16, 960, 1024)])
 def test_ocr_results_identical_across_slot_counts(hip_lib, cfg_name, dtype, n_lines, max_slots):
     """the decode regime above 256 slots. One predictor with max_slots > 256, the same images + boxes through
     RecognitionPredictor.__call__ at recognition_batch_size = 64, 256 and max_slots: the OCRResults must be identical field for field -- a
     line's stream does not depend on how many lines decode beside it (split-K counts are a function of (N, K) only, every tile shape walks K
-    in the same order), including the M > 256 tile choices of the gate|up and lm_head GEMMs."""
+    in the same order), including the M > 256 tile choices of the gate|up and lm_head GEMMs. 330 / 384 rows take the 128 x 64 split-K tile, 960 / 1024
+    rows the 128 x 128 split-K tile and the 8-phase 256 x 256 gate|up tile (csrc/gemm.h, sa::Tuning big_m_split / big_m_gateup)."""
     from surya_amd.recognition.predictor import RecognitionPredictor, RecognitionModelLoader
     cfg = rec_config(cfg_name)
     sd = make_rec_weights(cfg, 0, recipe="conditioned") if cfg_name == "REC-FULL" else make_rec_weights(cfg, 0)

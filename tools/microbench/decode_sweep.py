@@ -57,7 +57,7 @@ def main():
         for k, v in kw.items():
             L.check(lib.surya_set_tuning(k.encode(), C.c_int(v)), f"surya_set_tuning({k})")
 
-    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8, dattn=4, rnorm=2, ghead=2, fuse_embed=1, lmhead=1, kvprefetch=0, gateup_ring=2)
+    base = dict(graph=0, split_target=256, split_min_kt=4, split_max=8, dattn=4, rnorm=2, ghead=2, fuse_embed=1, lmhead=1, kvprefetch=0, gateup_ring=2, big_m_split=-1, big_m_gateup=-1)
     if args.configs == "base":
         variants = [dict()]
     elif args.configs == "fewer":        # fewer, longer split-K slices for the bf16 path
@@ -68,6 +68,10 @@ def main():
                     dict(dattn=3, rnorm=1, ghead=1, fuse_embed=0, lmhead=0), dict(graph=1), dict()]
     elif args.configs == "r5":           # round 5: LDS stages of the decode gate|up loop (2 = unrolled pair, 3 / 4 = ring with counted vmcnt), interleaved
         variants = [dict(), dict(gateup_ring=3), dict(gateup_ring=4), dict(), dict(gateup_ring=3), dict(gateup_ring=4)]
+    elif args.configs == "bigm":         # round 6: tiles of the decode projections above 256 rows (run with --slots 512 / 1024), interleaved
+        variants = [dict(big_m_split=0, big_m_gateup=0), dict(), dict(big_m_split=2, big_m_gateup=0), dict(big_m_split=3, big_m_gateup=0),
+                    dict(big_m_split=0, big_m_gateup=2), dict(big_m_split=2, big_m_gateup=2), dict(big_m_split=2, big_m_gateup=1),
+                    dict(big_m_split=0, big_m_gateup=0), dict()]
     elif args.configs == "pf":           # K/V prefetch workgroups in the reduce kernels, on / off, interleaved
         variants = [dict(kvprefetch=1), dict(), dict(kvprefetch=1), dict(), dict(lmhead=2, kvprefetch=1), dict(lmhead=2)]
     elif args.configs == "fp8only":
