@@ -84,7 +84,7 @@ def parse():
                     help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
                          "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
     ap.add_argument("--no-det-op-list", action="store_true", help="skip the det_fuse = 0 arm of the detection leg (counter passes: tools/profile_round.sh)")
-    ap.add_argument("--det-fuse", type=int, default=63, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
+    ap.add_argument("--det-fuse", type=int, default=127, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
     ap.add_argument("--no-slot-sweep", action="store_true", help="skip the e2e leg's 256 / 512 / 1024-slot sweep")
     ap.add_argument("--e2e-slots", type=lambda v: [int(x) for x in v.split(",")], default=[256, 512, 1024], help="slot counts of the e2e sweep")
     ap.add_argument("--no-predictor-call", action="store_true", help="skip the predictor_call object (RecognitionPredictor.__call__ wall clock + CPU oracle through the same call shape)")
@@ -467,15 +467,15 @@ def bench_det(args, local_rank, world, rank, barrier):
             _, rows = m.forward_timed(x)
             ms = [r[1] for r in rows]
             best = ms if best is None else [min(a, b) for a, b in zip(best, ms)]
+        from surya_amd.detection.buckets import launch_rows
         bk = {b: [0.0, 0.0, 0] for b in BUCKETS}
-        for (o, _), t in zip(rows, best):
-            if t > 0:
-                e = bk[bucket_of(o)]
-                e[0] += t; e[1] += op_flops(o) * args.det_pages; e[2] += 1
+        for _, b, t, fl, _ in launch_rows([r[0] for r in rows], best):
+            e = bk[b]
+            e[0] += t; e[1] += fl * args.det_pages; e[2] += 1
         buckets = {}
         for b in BUCKETS:
             buckets[f"{b}_ms"] = round(bk[b][0], 3)
-            if b in ("conv3x3", "conv1x1"):
+            if b in ("conv3x3", "conv1x1", "mbconv"):
                 buckets[f"{b}_tflops"] = round(bk[b][1] / bk[b][0] / 1e9, 1) if bk[b][0] else 0.0
             buckets[f"{b}_launches"] = bk[b][2]
         heat0, dt0 = heat, None
@@ -497,7 +497,8 @@ def bench_det(args, local_rank, world, rank, barrier):
                         "fused_vs_op_list_max_abs_diff": round(float(dfu.max()), 5), "fused_vs_op_list_mean_abs_diff": round(float(dfu.mean()), 6),
                         "det_fuse": args.det_fuse,
                         "bucket_note": "event-timed per op (min of 3 passes, ~4.5 us of event overhead inside each op's figure); depthwise_ms = MBConv "
-                                       "depthwise 3x3 launches INCLUDING the projection 1x1 folded into them (dwproj_kernel), conv1x1 = the remaining 1x1 "
+                                       "depthwise 3x3 launches INCLUDING the projection 1x1 folded into them (dwproj_kernel), mbconv = whole MBConv blocks in one launch (expand + "
+                                       "depthwise + projection, det_mbconv.h: the two stride-2 transitions), conv1x1 = the remaining 1x1 "
                                        "GEMMs (expand, FusedMBConv projection, LiteMLA qkv / proj), litemla = depthwise 5x5 + grouped 1x1 and kv + out, "
                                        "head = the three coarse z convolutions, z0 + sum + classify, output upsample; op_list_* = the same forward with "
                                        "every fused form off (det_fuse = 0), same process"})

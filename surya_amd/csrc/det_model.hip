@@ -10,6 +10,7 @@
 #include "../../include/surya_amd.h"
 #include "det_kernels.h"
 #include "det_fused.h"
+#include "det_mbconv.h"
 #include "det_post.h"
 #include "resample.h"
 
@@ -63,10 +64,11 @@ struct DetModel : DetBase {
         planes = reinterpret_cast<float*>(arena + planes_off);
         kvp = reinterpret_cast<float*>(arena + kvp_off);
         find_fusions();
-        return SA_OK;
+        return prepare_fused_weights();
     }
     ~DetModel() override {
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        for (T* p : mb_w2f) if (p) (void)hipFree(p);
         if (arena) (void)hipFree(arena);
     }
 
@@ -83,13 +85,26 @@ struct DetModel : DetBase {
     //   bit 3  MBConv's depthwise 3x3 + projection 1x1 in one kernel (the depthwise result is the projection's A operand, in LDS only)
     //   bit 4  FusedMBConv's 3x3 expand + Hardswish + 1x1 projection in one kernel (the expanded tensor exists per 64-channel chunk, in registers / LDS only)
     //   bit 5  (not a fusion: a kernel choice) the three 32-channel stem convolutions on the patch-in-LDS kernel instead of the implicit GEMM
-    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32 };
+    //   bit 6  MBConv's expand 1x1 + depthwise 3x3 + projection 1x1 in one kernel (det_mbconv.h: the expanded tensor exists per 64-channel chunk, in LDS
+    //          only); takes the stride-2 transitions, where bit 3 alone leaves the 2048- / 6144-channel tensor written and read back once
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64 };
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
+    std::vector<char> mb_start;        // per op: an expand 1x1 whose depthwise (op + 1) and projection (op + 2) the MBConv kernel takes with it
+    std::vector<T*> mb_w2f;            // per op: that block's projection weight, fragment-major (det_mbconv.h), made once at init; owned
+
+    // an op that does not run under the fused forms switched on by `fuse`
+    bool folded(int oi, int fuse) const {
+        const int n = (int)ops.size();
+        if ((fuse & FUSE_MBCONV) && ((oi >= 1 && mb_start[oi - 1]) || (oi >= 2 && mb_start[oi - 2]))) return true;
+        if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) return true;
+        for (int j = oi + 1; j < n; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) return true;
+        return false;
+    }
 
     void find_fusions() {
         const int n = (int)ops.size();
-        fuse_kind.assign(n, 0); fuse_with.assign(n, -1);
+        fuse_kind.assign(n, 0); fuse_with.assign(n, -1); mb_start.assign(n, 0);
         constexpr bool BF = std::is_same<T, bf16_t>::value;
         for (int i = 0; i < n; ++i) {
             const surya_det_op& a = ops[i];
@@ -103,6 +118,17 @@ struct DetModel : DetBase {
                 a.b_idx >= 0 && a.act == SA_ACT_HSWISH) { fuse_kind[i] = FUSE_DWPROJ; fuse_with[i] = i + 1; }
             if (a.type == SA_DET_CONV && a.k == 3 && a.act == SA_ACT_HSWISH && a.res < 0 && b.type == SA_DET_CONV && b.k == 1 && b.stride == 1 &&
                 b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && fmb_supported(a, b)) { fuse_kind[i] = FUSE_FMB; fuse_with[i] = i + 1; }
+        }
+        // whole MBConv blocks: expand 1x1 (+ Hardswish) whose only reader is the depthwise of a depthwise + projection pair found above
+        for (int i = 0; i + 2 < n && BF; ++i) {
+            const surya_det_op& a = ops[i];
+            const surya_det_op& dw = ops[i + 1];
+            const surya_det_op& pj = ops[i + 2];
+            if (fuse_kind[i + 1] != FUSE_DWPROJ || a.type != SA_DET_CONV || a.k != 1 || a.stride != 1 || a.act != SA_ACT_HSWISH || a.res >= 0 ||
+                a.p1 != a.cin || a.b_idx < 0 || dw.in0 != a.out || !mbconv_shape_ok(a.cin, a.cout, pj.cout, dw.stride)) continue;
+            bool only_reader = true;
+            for (int k = 0; k < n; ++k) if (k != i + 1 && (ops[k].in0 == a.out || ops[k].in1 == a.out || ops[k].res == a.out)) only_reader = false;
+            if (only_reader) mb_start[i] = 1;
         }
         // the folded head: UPSUM_CLASSIFY whose full-resolution operand comes from a plain 1x1 convolution
         for (int j = 0; j < n && BF; ++j) {
@@ -122,6 +148,20 @@ struct DetModel : DetBase {
                 ops[j].cout <= 2 && ops[j].hin % 8 == 0 && ops[j].win % 8 == 0 && only_reader) { fuse_kind[j] = FUSE_HEAD_Z0; fuse_with[j] = prod; }
         }
     }
+    int prepare_fused_weights() {
+        mb_w2f.assign(ops.size(), nullptr);
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            for (size_t i = 0; i + 2 < ops.size(); ++i) {
+                if (!mb_start[i]) continue;
+                const surya_det_op& pj = ops[i + 2];
+                SA_HIP(hipMalloc((void**)&mb_w2f[i], (size_t)pj.cout * pj.cin * sizeof(T)));
+                int rc = mbconv_w2_fragments(WT(pj.w_idx), mb_w2f[i], pj.cout, pj.cin, nullptr);
+                if (rc) return rc;
+            }
+            SA_HIP(hipDeviceSynchronize());
+        }
+        return SA_OK;
+    }
     static bool fmb_supported(const surya_det_op& a, const surya_det_op& b) { return fmb_shape_ok(a.cin, a.cout, b.cout, a.stride, a.hout, a.wout); }
 
     int forward(const float* pixels, const unsigned char* pixels_u8, const float* ms, int B, float* heat, float* lowres,
@@ -140,10 +180,7 @@ struct DetModel : DetBase {
             const surya_det_op& op = ops[oi];
             if (op_ms) SA_HIP(hipEventRecord(evs[oi], s));
             // an op folded into a fused form that is switched on does not run
-            bool skip = false;
-            if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) skip = true;
-            for (int j = oi + 1; j < n && !skip; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) skip = true;
-            if (skip) continue;
+            if (folded(oi, fuse)) continue;
             const int fk = fuse_kind[oi] & fuse;
             switch (op.type) {
                 case SA_DET_UPSUM_SRC: {
@@ -207,6 +244,14 @@ struct DetModel : DetBase {
                 }
                 case SA_DET_CONV: {
                     if constexpr (std::is_same<T, bf16_t>::value) {
+                        if (mb_start[oi] && (fuse & FUSE_MBCONV)) {
+                            const surya_det_op& dw = ops[oi + 1];
+                            const surya_det_op& pj = ops[oi + 2];
+                            if ((rc = launch_mbconv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(dw.w_idx), WT(dw.b_idx), mb_w2f[oi], WT(pj.b_idx),
+                                                    pj.res >= 0 ? bufs[pj.res] : nullptr, bufs[pj.out], B, op.hin, op.win, op.cin, op.cout, dw.hout,
+                                                    dw.wout, pj.cout, dw.stride, s))) return rc;
+                            break;
+                        }
                         if (fk == FUSE_FMB) {
                             const surya_det_op& pj = ops[fuse_with[oi]];
                             if ((rc = launch_fmb(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(pj.w_idx), WT(pj.b_idx), pj.res >= 0 ? bufs[pj.res] : nullptr,
@@ -341,11 +386,8 @@ struct DetModel : DetBase {
             SA_HIP(hipEventSynchronize(evs[n]));
             std::vector<int> ran;
             for (int oi = 0; oi < n; ++oi) {
-                bool skip = false;
-                if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) skip = true;
-                for (int j = oi + 1; j < n && !skip; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) skip = true;
                 op_ms[oi] = 0.f;
-                if (!skip) ran.push_back(oi);
+                if (!folded(oi, fuse)) ran.push_back(oi);
             }
             for (size_t k = 0; k < ran.size(); ++k) {
                 float ms_ = 0.f;

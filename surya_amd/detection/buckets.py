@@ -9,7 +9,7 @@ from __future__ import annotations
 from .plan import (OP_CLASSIFY, OP_CONV, OP_DWCONV, OP_GROUPED1X1, OP_INPUT, OP_LITEMLA, OP_UPCAT, OP_UPSAMPLE_OUT, OP_UPSUM_CLASSIFY,
                    OP_UPSUM_SRC)
 
-BUCKETS = ("conv3x3", "conv1x1", "depthwise", "litemla", "head", "other")
+BUCKETS = ("conv3x3", "conv1x1", "depthwise", "mbconv", "litemla", "head", "other")
 
 _TAG_BUCKET = {"stem": "conv3x3", "fmb_3x3": "conv3x3", "fmb_proj": "conv1x1", "mb_expand": "conv1x1", "mb_proj": "conv1x1",
                "mla_qkv": "conv1x1", "mla_proj": "conv1x1", "mb_dw": "depthwise", "mla_dw5": "litemla", "mla_g1x1": "litemla",
@@ -60,3 +60,25 @@ def op_bytes(op: dict, elem: int = 2) -> float:
     if t == OP_UPSUM_SRC:
         return 0.0
     return 0.0
+
+
+def launch_rows(ops, times_ms):
+    """One row per op that RAN: (index, bucket, ms, flops per image, bytes per image).
+
+    A whole-MBConv launch (csrc/det_mbconv.h, det_fuse bit 6) shows as an mb_expand op with a time whose depthwise and projection both report
+    0: it goes to the `mbconv` bucket with the FLOPs of all three ops and the block's boundary tensors only (the expanded tensor is neither
+    written nor read). Every other fused pair stays under its first op's bucket, as before, with that op's own figures."""
+    out = []
+    n = len(ops)
+    for i, (o, t) in enumerate(zip(ops, times_ms)):
+        if t <= 0:
+            continue
+        if (o.get("tag") == "mb_expand" and i + 2 < n and ops[i + 1].get("tag") == "mb_dw" and ops[i + 2].get("tag") == "mb_proj"
+                and times_ms[i + 1] <= 0 and times_ms[i + 2] <= 0):
+            pj = ops[i + 2]
+            fl = op_flops(o) + op_flops(ops[i + 1]) + op_flops(pj)
+            by = (o["hin"] * o["win"] * o["cin"] + pj["hout"] * pj["wout"] * pj["cout"] * (2 if pj["res"] >= 0 else 1)) * 2.0
+            out.append((i, "mbconv", t, fl, by))
+        else:
+            out.append((i, bucket_of(o), t, op_flops(o), op_bytes(o)))
+    return out

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--pages", type=int, default=16)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--config", default="DET-DEFAULT")
-    ap.add_argument("--fuse", default="0,63")
+    ap.add_argument("--fuse", default="0,127")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--json", action="store_true")
@@ -36,7 +36,7 @@ def main():
     args = ap.parse_args()
     from surya_amd import _lib as L
     from surya_amd.config import det_config
-    from surya_amd.detection.buckets import bucket_of, op_bytes, op_flops
+    from surya_amd.detection.buckets import bucket_of, launch_rows, op_bytes, op_flops
     from surya_amd.detection.model import HipDetModel
     from surya_amd.synth import make_det_weights, make_pages
     from oracle import det_oracle as do
@@ -65,17 +65,17 @@ def main():
         ops = [r[0] for r in rows]
         buckets = {}
         print(f"\n=== det_fuse = {arm}: {args.pages} pages {args.size}^2, {args.config}, bf16; per-op min of {args.reps} event-timed forwards ===")
+        ran = {r[0]: r for r in launch_rows(ops, best)}
         for i, (o, t) in enumerate(zip(ops, best)):
-            bk = bucket_of(o)
-            fl, by = op_flops(o) * args.pages, op_bytes(o) * args.pages
+            _, bk, _, fl, by = ran.get(i, (i, bucket_of(o), 0.0, op_flops(o), op_bytes(o)))
+            fl, by = fl * args.pages, by * args.pages
             if t > 0:
                 b = buckets.setdefault(bk, [0.0, 0.0, 0.0, 0])
                 b[0] += t; b[1] += fl; b[2] += by; b[3] += 1
-            if args.rows or arm == arms[0] or True:
-                shape = f"{o['cin']:>5}->{o['cout']:<5} k{o['k']} s{o['stride']} {o['hin']}x{o['win']}->{o['hout']}x{o['wout']}"
-                tf = fl / t / 1e9 if t > 0 else 0.0
-                gb = by / t / 1e6 if t > 0 else 0.0
-                print(f"{i:3d} {bk:10s} type {o['type']:2d} {shape:42s} {t*1e3:9.1f} us  {tf:8.1f} TF/s  {gb:8.0f} GB/s")
+            shape = f"{o['cin']:>5}->{o['cout']:<5} k{o['k']} s{o['stride']} {o['hin']}x{o['win']}->{o['hout']}x{o['wout']}"
+            tf = fl / t / 1e9 if t > 0 else 0.0
+            gb = by / t / 1e6 if t > 0 else 0.0
+            print(f"{i:3d} {bk:10s} type {o['type']:2d} {shape:42s} {t*1e3:9.1f} us  {tf:8.1f} TF/s  {gb:8.0f} GB/s")
         tot = sum(best)
         print(f"--- buckets (sum of op times {tot:.3f} ms)")
         for bk, (t, fl, by, n) in sorted(buckets.items(), key=lambda kv: -kv[1][0]):
@@ -95,7 +95,7 @@ def main():
         d = (heats[arm] - base).abs()
         print(f"heat maps det_fuse={arm} vs {arms[0]}: max abs diff {d.max().item():.3e}, mean {d.mean().item():.3e}, "
               f"bit-identical: {bool(torch.equal(heats[arm].view(torch.int32), base.view(torch.int32)))}")
-    L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(63)), "surya_set_tuning")
+    L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(127)), "surya_set_tuning")
     if args.json:
         print(json.dumps(summary))
 
