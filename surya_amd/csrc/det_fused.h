@@ -267,6 +267,8 @@ static inline int launch_dw5_g1x1(const T*, const T*, const T*, T*, const T*, in
 // from global memory, loaded once: K = 64; A0 fragments from L2), add the bias in fp32, round to bf16 -- the GEMM epilogue's arithmetic, bit
 // for bit -- and hand the slab over in 32 KiB of LDS ([128 px][128 ch], 16-byte chunks XOR-swizzled by the pixel row); from there on the
 // pass is head_upsum_classify_blk_kernel's: 16 lanes per block, lane `sub` takes channels [slab + 8 sub, + 8), same tap tiles, same sums.
+// A0 comes FRAGMENT-MAJOR ([C / 32][4 K steps][64 lanes][8], det_mbconv.h's mbconv_w2_fragments at engine init): a fragment load is one contiguous KiB
+// (from the row-major [C][64] weight it touched 32 cache lines, 16 such loads per slab at one wave per SIMD).
 template <int R1, int R2, int R3, int BH>
 __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ A0, const bf16_t* __restrict__ zb,
                                                       const bf16_t* __restrict__ z1, const bf16_t* __restrict__ z2, const bf16_t* __restrict__ z3,
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void head_z0_kernel(const bf16_t* __restrict__
     {                                                                                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
             _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                         \
-                wf[j_][ks_] = *reinterpret_cast<const u32x4*>(A0 + (long)((N0) + j_ * 32 + lr) * K + (ks_ * 2 + lh) * 8); \
+                wf[j_][ks_] = *reinterpret_cast<const u32x4*>(A0 + ((long)(((N0) >> 5) + j_) * 4 + ks_) * 512 + lane * 8); \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) braw[j_][q_] = *reinterpret_cast<const uint2*>(zb + (N0) + j_ * 32 + q_ * 8 + lh * 4); \
     }
@@ -546,7 +548,10 @@ __global__ __launch_bounds__(512) void dwproj_kernel(const bf16_t* __restrict__ 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-        const bf16_t* w2p = w2 + (long)(n0 + wv * 64 + lr) * Cm + lh * 8;
+        // w2 comes FRAGMENT-MAJOR ([Cm / 64][Cout / 32][4 K steps][64 lanes][8]: det_mbconv.h's mbconv_w2_fragments at engine init): a fragment load is
+        // one contiguous KiB instead of 32 cache lines of the row-major [Cout][Cm] weight
+        const bf16_t* w2p = w2 + ((long)((n0 + wv * 64) >> 5) * 4 * 64 + lane) * 8;
+        const long w2cs = (long)(Cout >> 5) * 4 * 64 * 8;     // elements per 64-channel chunk
         // W fragments: two named sets; all eight 16-byte loads of the NEXT chunk are issued in one burst at the top of a chunk (the four
         // loads of a 128-byte weight row then meet in L1; spread over the chunk, one per kk, every one of them went to L2 again)
         u32x4 wa[2][4], wb[2][4];
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(512) void dwproj_kernel(const bf16_t* __restrict__ 
     {                                                                                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
             _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                         \
-                WF[j_][kk_] = *reinterpret_cast<const u32x4*>(w2p + (long)j_ * 32 * Cm + (C0) + kk_ * 16);              \
+                WF[j_][kk_] = *reinterpret_cast<const u32x4*>(w2p + ((C0) >> 6) * w2cs + (j_ * 4 + kk_) * 512);         \
     }
 #define DP_MM(WF, BUF)                                                                                                  \
     {                                                                                                                   \

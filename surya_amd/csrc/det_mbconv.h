@@ -27,6 +27,9 @@ namespace sa {
 #ifndef SA_MBC_DREQ
 #define SA_MBC_DREQ 1
 #endif
+#ifndef SA_MBC_W2SPREAD
+#define SA_MBC_W2SPREAD 0
+#endif
 #ifndef SA_MBC_TIMING
 #define SA_MBC_TIMING 0   // tools/microbench/mbconv_timing.hip: s_memtime stamps of waves 0 (X) and 4 (D) per chunk iteration into `dbg`
 #endif
@@ -293,11 +296,11 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
                     wld = *reinterpret_cast<const u32x4*>(wsrc + min(it + 1, nch - 1) * MCH);
                 }
                 // W2 fragments of chunk it - 2 (used behind the depthwise arithmetic below)
-                {
-                    const long c2 = (long)min(max(it - 2, 0), nch - 1) * (COUT / 32) * 4 * 64 * 8;
-    #pragma unroll
+                const long c2 = (long)min(max(it - 2, 0), nch - 1) * (COUT / 32) * 4 * 64 * 8;
+                if constexpr (!SA_MBC_W2SPREAD) {
+#pragma unroll
                     for (int j = 0; j < NJ; ++j)
-    #pragma unroll
+#pragma unroll
                         for (int kk = 0; kk < 4; ++kk) w2f[j][kk] = *reinterpret_cast<const u32x4*>(w2p + c2 + (j * 4 + kk) * 64 * 8);
                 }
                 if (wv == 4) MBC_STAMP(1, it, 4);
@@ -309,6 +312,12 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {                // (ky, kx) ascending: dwconv_tx_kernel's order
                     if (t + NS - 1 < 9) MB_LE((t + NS - 1) % NS, t + NS - 1);
+                    if constexpr (SA_MBC_W2SPREAD) {             // the W2 requests ride between the taps: NJ * 4 of them over the first eight steps
+#pragma unroll
+                        for (int q = t * (NJ / 2); q < (t + 1) * (NJ / 2) && t < 8; ++q)
+#pragma unroll
+                            for (int h = 0; h < 1; ++h) w2f[q / 4][q % 4] = *reinterpret_cast<const u32x4*>(w2p + c2 + q * 64 * 8);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (!(SA_MBC_ABL & 4)) {
                         const f32x4 t0 = __builtin_bit_cast(f32x4, tw[t % NS][0]), t1 = __builtin_bit_cast(f32x4, tw[t % NS][1]);

@@ -69,6 +69,7 @@ struct DetModel : DetBase {
     ~DetModel() override {
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
         for (T* p : mb_w2f) if (p) (void)hipFree(p);
+        for (T* p : head_a0f) if (p) (void)hipFree(p);
         if (arena) (void)hipFree(arena);
     }
 
@@ -91,7 +92,8 @@ struct DetModel : DetBase {
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
     std::vector<char> mb_start;        // per op: an expand 1x1 whose depthwise (op + 1) and projection (op + 2) the MBConv kernel takes with it
-    std::vector<T*> mb_w2f;            // per op: that block's projection weight, fragment-major (det_mbconv.h), made once at init; owned
+    std::vector<T*> mb_w2f;            // per DEPTHWISE op of a depthwise + projection pair: the projection weight, fragment-major (det_mbconv.h), made once at init; owned
+    std::vector<T*> head_a0f;          // per op (FUSE_HEAD_Z0): the folded z0 convolution's weight A0, fragment-major; owned
 
     // an op that does not run under the fused forms switched on by `fuse`
     bool folded(int oi, int fuse) const {
@@ -150,10 +152,20 @@ struct DetModel : DetBase {
     }
     int prepare_fused_weights() {
         mb_w2f.assign(ops.size(), nullptr);
+        head_a0f.assign(ops.size(), nullptr);
         if constexpr (std::is_same<T, bf16_t>::value) {
-            for (size_t i = 0; i + 2 < ops.size(); ++i) {
-                if (!mb_start[i]) continue;
-                const surya_det_op& pj = ops[i + 2];
+            for (size_t j = 0; j < ops.size(); ++j) {
+                if (fuse_kind[j] != FUSE_HEAD_Z0) continue;
+                const surya_det_op& zc = ops[fuse_with[j]];
+                SA_HIP(hipMalloc((void**)&head_a0f[j], (size_t)zc.cout * zc.cin * sizeof(T)));
+                int rc = mbconv_w2_fragments(WT(zc.w_idx), head_a0f[j], zc.cout, zc.cin, nullptr);
+                if (rc) return rc;
+            }
+            // every depthwise + projection pair (dwproj_kernel and mbconv_kernel read the projection weight as MFMA fragments straight from L2):
+            // indexed by the DEPTHWISE op
+            for (size_t i = 0; i + 1 < ops.size(); ++i) {
+                if (fuse_kind[i] != FUSE_DWPROJ) continue;
+                const surya_det_op& pj = ops[i + 1];
                 SA_HIP(hipMalloc((void**)&mb_w2f[i], (size_t)pj.cout * pj.cin * sizeof(T)));
                 int rc = mbconv_w2_fragments(WT(pj.w_idx), mb_w2f[i], pj.cout, pj.cin, nullptr);
                 if (rc) return rc;
@@ -195,7 +207,7 @@ struct DetModel : DetBase {
                     if constexpr (std::is_same<T, bf16_t>::value) {
                         if (fk == FUSE_HEAD_Z0 && upsum.n == 3) {
                             const surya_det_op& zc = ops[fuse_with[oi]];
-                            if ((rc = launch_head_z0(bufs[zc.in0], WT(zc.w_idx), WT(zc.b_idx), reinterpret_cast<const T*>(upsum.p[0]),
+                            if ((rc = launch_head_z0(bufs[zc.in0], head_a0f[oi], WT(zc.b_idx), reinterpret_cast<const T*>(upsum.p[0]),
                                                      reinterpret_cast<const T*>(upsum.p[1]), reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx),
                                                      WT(op.b_idx), planes, B, op.hin, op.win, zc.cin, op.cin, op.cout, s))) return rc;
                             upsum.n = 0;
@@ -247,7 +259,7 @@ struct DetModel : DetBase {
                         if (mb_start[oi] && (fuse & FUSE_MBCONV)) {
                             const surya_det_op& dw = ops[oi + 1];
                             const surya_det_op& pj = ops[oi + 2];
-                            if ((rc = launch_mbconv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(dw.w_idx), WT(dw.b_idx), mb_w2f[oi], WT(pj.b_idx),
+                            if ((rc = launch_mbconv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(dw.w_idx), WT(dw.b_idx), mb_w2f[oi + 1], WT(pj.b_idx),
                                                     pj.res >= 0 ? bufs[pj.res] : nullptr, bufs[pj.out], B, op.hin, op.win, op.cin, op.cout, dw.hout,
                                                     dw.wout, pj.cout, dw.stride, s))) return rc;
                             break;
@@ -295,7 +307,7 @@ struct DetModel : DetBase {
                         }
                         if (fk == FUSE_DWPROJ) {
                             const surya_det_op& pj = ops[fuse_with[oi]];
-                            if ((rc = launch_dwproj(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), op.act, WT(pj.w_idx), WT(pj.b_idx),
+                            if ((rc = launch_dwproj(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), op.act, mb_w2f[oi], WT(pj.b_idx),
                                                     pj.res >= 0 ? bufs[pj.res] : nullptr, bufs[pj.out], B, op.hin, op.win, op.cin, op.hout, op.wout,
                                                     pj.cout, op.stride, s))) return rc;
                             break;
