@@ -822,7 +822,8 @@ static inline int launch_stem_conv(const T*, const T*, const T*, const T*, T*, i
 //     K-tile: 2 + 4 fragment reads per 8 MFMAs);
 //   at the end of a chunk: + bias, Hardswish, round to bf16 (the op list's rounding point), v_permlane32_swap turns the accumulator layout
 //     (4 consecutive channels per lane) into the A-operand layout (8 consecutive), and O[64 px x Cout] += S . W2_chunk with O in accumulators and
-//     the W2 fragments from L2 (requested at the top of the chunk);
+//     the W2 fragments from L2 (requested at the top of the chunk; W2 comes fragment-major, [MID / 64][2 cout tiles][4 K steps][64 lanes][8], made at
+//     engine init by det_mbconv.h's mbconv_w2_fragments: one contiguous KiB per load);
 //   epilogue: + bias, round (the GEMM's rounding), + residual, round; 16-byte stores.
 // K order of the 3x3 = the implicit GEMM's ((ky, kx, ci) ascending, 16 per MFMA, one accumulator per output); the projection sums K = mid in the
 // same 16-element steps as the GEMM: with identical S bits the sums are the GEMM's. Built for Cout = 64 (stage 0: the two largest expanded
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
     {                                                                                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
             _Pragma("unroll") for (int s2_ = 0; s2_ < NS2; ++s2_)                                                       \
-                w2f[j_][s2_] = *reinterpret_cast<const u32x4*>(w2 + (long)(j_ * 32 + lr) * MID + ch * MCH + s2_ * 16 + lh * 8); \
+                w2f[j_][s2_] = *reinterpret_cast<const u32x4*>(w2 + ((long)((ch * MCH >> 6) + (s2_ >> 2)) * 2 + j_) * 2048 + (s2_ & 3) * 512 + lane * 8); \
         _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                               \
             _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) b1r[j_][g_] = *reinterpret_cast<const uint2*>(b1 + ch * MCH + j_ * 32 + g_ * 8 + lh * 4); \
     }

@@ -164,7 +164,7 @@ struct DetModel : DetBase {
             // every depthwise + projection pair (dwproj_kernel and mbconv_kernel read the projection weight as MFMA fragments straight from L2):
             // indexed by the DEPTHWISE op
             for (size_t i = 0; i + 1 < ops.size(); ++i) {
-                if (fuse_kind[i] != FUSE_DWPROJ) continue;
+                if (fuse_kind[i] != FUSE_DWPROJ && fuse_kind[i] != FUSE_FMB) continue;      // (FusedMBConv: indexed by the 3x3 op)
                 const surya_det_op& pj = ops[i + 1];
                 SA_HIP(hipMalloc((void**)&mb_w2f[i], (size_t)pj.cout * pj.cin * sizeof(T)));
                 int rc = mbconv_w2_fragments(WT(pj.w_idx), mb_w2f[i], pj.cout, pj.cin, nullptr);
@@ -266,7 +266,7 @@ struct DetModel : DetBase {
                         }
                         if (fk == FUSE_FMB) {
                             const surya_det_op& pj = ops[fuse_with[oi]];
-                            if ((rc = launch_fmb(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(pj.w_idx), WT(pj.b_idx), pj.res >= 0 ? bufs[pj.res] : nullptr,
+                            if ((rc = launch_fmb(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), mb_w2f[oi], WT(pj.b_idx), pj.res >= 0 ? bufs[pj.res] : nullptr,
                                                  bufs[pj.out], zero_page, B, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, pj.cout, op.stride, op.p0,
                                                  op.p1, s))) return rc;
                             break;
