@@ -51,3 +51,34 @@ def test_folded_head_algebra_and_accounting():
     assert b.reference_flops_per_image == b.flops_per_image
     assert a.flops_per_image < b.flops_per_image                           # the fold executes less
     assert len(a.buf_elems) < len(b.buf_elems) + 4 and max(a.buf_elems) <= max(b.buf_elems)   # no 4 x 128-channel concat buffer
+
+
+def test_bucket_rows_credit_a_whole_mbconv_launch_with_its_three_ops():
+    """detection/buckets.py::launch_rows (bench.py's detection.roofline keys, tools/det_op_times.py): an MBConv block run as ONE launch
+    (csrc/det_mbconv.h) shows as an expand op with a time and a depthwise + projection with 0 -- it must land in the `mbconv` bucket with
+    the FLOPs of all three ops and the block's boundary tensors only; with the pair form (depthwise + projection in one launch) the
+    expand stays a conv1x1 row and the depthwise row keeps its own figures."""
+    from surya_amd.detection.buckets import BUCKETS, launch_rows, op_bytes, op_flops
+    cfg = det_config("DET-DEFAULT")
+    pl = P.build_det_plan(cfg, make_det_weights(cfg, 0), 256, 256)
+    ops = pl.ops
+    idx = [i for i, o in enumerate(ops) if o["tag"] == "mb_expand" and ops[i + 1]["stride"] == 2]
+    assert len(idx) == 2 and "mbconv" in BUCKETS
+    times = [1.0] * len(ops)
+    for i in idx:                                            # whole-block form on the two stride-2 transitions
+        times[i + 1] = times[i + 2] = 0.0
+    rows = {r[0]: r for r in launch_rows(ops, times)}
+    for i in idx:
+        _, b, t, fl, by = rows[i]
+        assert b == "mbconv" and t == 1.0
+        assert fl == op_flops(ops[i]) + op_flops(ops[i + 1]) + op_flops(ops[i + 2])
+        pj = ops[i + 2]
+        assert by == (ops[i]["hin"] * ops[i]["win"] * ops[i]["cin"] + pj["hout"] * pj["wout"] * pj["cout"]) * 2.0
+        assert by < op_bytes(ops[i]) and i + 1 not in rows and i + 2 not in rows
+    # pair form: depthwise + projection folded, expand on its own
+    j = [i for i, o in enumerate(ops) if o["tag"] == "mb_expand" and ops[i + 1]["stride"] == 1][0]
+    times = [1.0] * len(ops)
+    times[j + 2] = 0.0
+    rows = {r[0]: r for r in launch_rows(ops, times)}
+    assert rows[j][1] == "conv1x1" and rows[j + 1][1] == "depthwise" and j + 2 not in rows
+    assert sum(1 for r in rows.values() if r[1] == "mbconv") == 0
