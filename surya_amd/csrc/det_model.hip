@@ -11,6 +11,7 @@
 #include "det_kernels.h"
 #include "det_fused.h"
 #include "det_mbconv.h"
+#include "det_head.h"
 #include "det_post.h"
 #include "resample.h"
 
@@ -86,9 +87,11 @@ struct DetModel : DetBase {
     //   bit 3  MBConv's depthwise 3x3 + projection 1x1 in one kernel (the depthwise result is the projection's A operand, in LDS only)
     //   bit 4  FusedMBConv's 3x3 expand + Hardswish + 1x1 projection in one kernel (the expanded tensor exists per 64-channel chunk, in registers / LDS only)
     //   bit 5  (not a fusion: a kernel choice) the three 32-channel stem convolutions on the patch-in-LDS kernel instead of the implicit GEMM
+    //   bit 7  (with bit 2) the folded head entirely on the matrix cores: the three bilinear up-samplings as a constant K = 96 map on z0's accumulators
+    //          (det_head.h); re-associates fp32 sums, not bit-identical to the op list
     //   bit 6  MBConv's expand 1x1 + depthwise 3x3 + projection 1x1 in one kernel (det_mbconv.h: the expanded tensor exists per 64-channel chunk, in LDS
     //          only); takes the stride-2 transitions, where bit 3 alone leaves the 2048- / 6144-channel tensor written and read back once
-    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64 };
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64, FUSE_HEAD_MFMA = 128 };
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
     std::vector<char> mb_start;        // per op: an expand 1x1 whose depthwise (op + 1) and projection (op + 2) the MBConv kernel takes with it
@@ -207,6 +210,15 @@ struct DetModel : DetBase {
                     if constexpr (std::is_same<T, bf16_t>::value) {
                         if (fk == FUSE_HEAD_Z0 && upsum.n == 3) {
                             const surya_det_op& zc = ops[fuse_with[oi]];
+                            if ((fuse & FUSE_HEAD_MFMA) && head_mfma_shape_ok(op.hin, op.win, zc.cin, op.cin, op.cout)) {
+                                if ((rc = launch_head_mfma(bufs[zc.in0], head_a0f[oi], WT(zc.b_idx), reinterpret_cast<const T*>(upsum.p[0]),
+                                                           reinterpret_cast<const T*>(upsum.p[1]), reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx),
+                                                           WT(op.b_idx), planes, B, op.hin, op.win, zc.cin, op.cin, op.cout, s))) return rc;
+                                upsum.n = 0;
+                                if (lowres)
+                                    SA_HIP(hipMemcpyAsync(lowres, planes, (size_t)P * op.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                                break;
+                            }
                             if ((rc = launch_head_z0(bufs[zc.in0], head_a0f[oi], WT(zc.b_idx), reinterpret_cast<const T*>(upsum.p[0]),
                                                      reinterpret_cast<const T*>(upsum.p[1]), reinterpret_cast<const T*>(upsum.p[2]), WT(op.w_idx),
                                                      WT(op.b_idx), planes, B, op.hin, op.win, zc.cin, op.cin, op.cout, s))) return rc;
