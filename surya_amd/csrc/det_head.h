@@ -21,6 +21,10 @@
 
 namespace sa {
 
+#ifndef SA_HEAD_ASM_DMA
+#define SA_HEAD_ASM_DMA 1
+#endif
+
 __device__ __forceinline__ void head_axis_weights(int p, int R, int& i0, float& f) {
     // fine pixel p of the tile (tile origin aligned to R): source coordinate relative to the tile's first coarse cell
     const float src = ((float)p + 0.5f) / (float)R - 0.5f;
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const bf16_t* __restr
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
     const int nslab = C / 128;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     for (int i = tid; i < C / 8; i += 256) {
         *reinterpret_cast<uint4*>(smem + OFF_TAB + i * 16) = *reinterpret_cast<const uint4*>(zb + i * 8);
         *reinterpret_cast<uint4*>(smem + OFF_TAB + C * 2 + i * 16) = *reinterpret_cast<const uint4*>(w + i * 8);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const bf16_t* __restr
     }
     // ---- tap requests: request i of this wave fills LDS rows (wv * 6 + i) * 4 + (lane >> 4), physical chunk lane & 15 <- logical chunk (lane & 15) ^ ((row & 3) << 1)
     const int h1 = H0 / 2, w1 = W0 / 2, h2 = H0 / 4, w2 = W0 / 4, h3 = H0 / 8, w3 = W0 / 8;
-    const int tiles_x = W0 / TW, tiles_y = H0 / TH;
+    const int tiles_x = (W0 + TW - 1) / TW, tiles_y = H0 / TH;      // W0 is a multiple of 8: the last tile of a row may be half outside (clamped loads, no stores)
     // (a request = 4 tap rows never straddles a scale: 60 and 84 are multiples of 4 -- its source tensor is wave-uniform, a scalar pointer)
     const bf16_t* zsrc[6];
     int zrow[6];                                             // element offset of the tap pixel inside its tensor, set per tile
@@ -121,14 +126,28 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const bf16_t* __restr
             zrow[i_] = (((IMG) * hs_ + cy_) * ws_ + cx_) * C + zchunk;                                                  \
         }                                                                                                               \
     }
+    // SA_HEAD_ASM_DMA: the requests as inline asm. Behind the builtin hipcc orders EVERY later LDS read of the step behind the pending LDS-DMA
+    // (s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16: the taps' round trip and the A0 fragments' exposed once per slab) -- it cannot see
+    // that the request fills the OTHER buffer. The asm form is invisible to that bookkeeping; the wait at the top of the next step is explicit anyway.
+#if SA_HEAD_ASM_DMA
+#define HM_ISSUE(BUF, SLAB)                                                                                             \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                              \
+            const bf16_t* g_ = zsrc[i_] + zrow[i_] + (SLAB) * 128;                                                      \
+            const unsigned l_ = lds0 + (unsigned)((BUF) * ZB + (wv * 6 + i_) * 1024);                                   \
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_), "s"(l_) : "memory", "m0"); \
+        }                                                                                                               \
+    }
+#else
 #define HM_ISSUE(BUF, SLAB)                                                                                             \
     {                                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_)                                                                \
             __builtin_amdgcn_global_load_lds((gptr_t)(zsrc[i_] + zrow[i_] + (SLAB) * 128), (lptr_t)(smem + (BUF) * ZB + (wv * 6 + i_) * 1024), 16, 0, 0); \
     }
+#endif
 #define HM_LOADX(XF, IMG, Y0, X0)                                                                                       \
     {                                                                                                                   \
-        const bf16_t* xp_ = x0 + (((long)(IMG) * H0 + (Y0) + py) * W0 + (X0) + px) * K0 + lh * 8;                        \
+        const bf16_t* xp_ = x0 + (((long)(IMG) * H0 + (Y0) + py) * W0 + min((X0) + px, W0 - 1)) * K0 + lh * 8;           \
         _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) XF[ks_] = *reinterpret_cast<const u32x4*>(xp_ + ks_ * 16);  \
     }
 #define HM_LOADA(SLAB)                                                                                                  \
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const bf16_t* __restr
         // ---- the two channel halves of the pixel meet; + b_l, round, sigmoid, round; lane half l writes label l
         p0 += __shfl_xor(p0, 32, 64);
         p1 += __shfl_xor(p1, 32, 64);
-        if (lh < L) {
+        if (lh < L && x0c + px < W0) {
             const float z = Ty<bf16_t>::rnd((lh ? p1 : p0) + blv[lh]);
             out[((long)img * L + lh) * HW + (long)(y0 + py) * W0 + x0c + px] = Ty<bf16_t>::rnd(1.0f / (1.0f + expf(-z)));
         }
@@ -250,13 +269,13 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const bf16_t* __restr
 }
 
 static inline bool head_mfma_shape_ok(int H0, int W0, int K, int C, int L) {
-    return K == 64 && C % 128 == 0 && C <= 1024 && L >= 1 && L <= 2 && H0 % 8 == 0 && W0 % 16 == 0 && H0 >= 16 && W0 >= 32;
+    return K == 64 && C % 128 == 0 && C <= 1024 && L >= 1 && L <= 2 && H0 % 8 == 0 && W0 % 8 == 0 && H0 >= 16 && W0 >= 32;
 }
 
 static inline int launch_head_mfma(const bf16_t* x0, const bf16_t* A0f, const bf16_t* zb, const bf16_t* z1, const bf16_t* z2, const bf16_t* z3,
                                    const bf16_t* w, const bf16_t* bias, float* planes, int B, int H0, int W0, int K, int C, int L, hipStream_t s) {
     if (!head_mfma_shape_ok(H0, W0, K, C, L) || !zb || (long)B * (H0 / 2) * (W0 / 2) * C >= (1L << 31)) return SA_ERR_SHAPE;
-    const int ntiles = B * (H0 / 8) * (W0 / 16);
+    const int ntiles = B * (H0 / 8) * ((W0 + 15) / 16);
     const size_t lds = 2 * 96 * 256 + (size_t)C * 6;
     auto kern = head_mfma_kernel;
     static AttrOnce attr;
