@@ -161,20 +161,19 @@ def get_detected_boxes(textmap, text_threshold=None, low_text=None) -> List[Poly
 
 
 def clean_boxes(boxes: List[PolygonBox]) -> List[PolygonBox]:
-    """Drop degenerate boxes and boxes fully contained in another one (surya/common/util.py:9-36)."""
+    """Drop degenerate boxes and boxes fully contained in another one (surya/common/util.py:9-36). Same decisions as the reference's double
+    loop; every box's bbox is formed once (the property rebuilds it from the polygon on each access: 26 evaluations per box and page inside
+    the detector thread of the streamed call, while the decode loop waits for the interpreter)."""
+    bbs = [bo.bbox for bo in boxes]
     kept = []
-    for bo in boxes:
-        xs = [p[0] for p in bo.polygon]
-        ys = [p[1] for p in bo.polygon]
-        if max(xs) == min(xs) or max(ys) == min(ys):
+    for i, bo in enumerate(boxes):
+        b = bbs[i]
+        if b[2] == b[0] or b[3] == b[1]:
             continue
-        b = bo.bbox
         inside = False
-        for other in boxes:
-            if other.polygon == bo.polygon:
-                continue
-            o = other.bbox
-            if b == o:
+        for j, other in enumerate(boxes):
+            o = bbs[j]
+            if b == o:                                       # (covers `other.polygon == bo.polygon`: equal polygons have equal bboxes)
                 continue
             if b[0] >= o[0] and b[1] >= o[1] and b[2] <= o[2] and b[3] <= o[3]:
                 inside = True

@@ -1164,6 +1164,18 @@ class RecognitionPredictor(BasePredictor):
         # whole default switch interval (5 ms = a decode call of 4 steps)
         old_switch = sys.getswitchinterval()
         sys.setswitchinterval(min(old_switch, 5e-4))
+        if os.environ.get("SURYA_AMD_PROFILE_PRODUCER"):     # debugging aid: cProfile of the detector thread's Python work, to stderr
+            import cProfile, pstats
+            _inner = produce
+
+            def produce():                                   # noqa: F811
+                pr = cProfile.Profile()
+                pr.enable()
+                try:
+                    _inner()
+                finally:
+                    pr.disable()
+                    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(22)
         producer = threading.Thread(target=produce, name="surya-amd-detect", daemon=True)
         try:
             with ThreadPoolExecutor(1) as pool:
