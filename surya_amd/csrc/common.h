@@ -172,7 +172,22 @@ __device__ __forceinline__ float gelu_epi(float x) {
 // GELU, tanh approximation (torch gelu(approximate="tanh") / transformers gelu_pytorch_tanh)
 __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+// Hardswish x . relu6(x + 3) / 6 as x . clamp(x / 6 + 0.5, 0, 1): ONE v_fma_f32 with the clamp output modifier + one multiply (the literal form is add, max,
+// min, multiply, multiply -- and its epilogues are where the detector's kernels are vector-ALU-bound). Two fp32 roundings instead of three; differs from
+// the literal form by <= 1 ulp of fp32 before any bf16 rounding (fp32 mode stays <= 1e-4 from the oracle, tests/test_gpu_det.py). EVERY kernel takes its
+// Hardswish from here or from hardswish_pk below, so the fused forms keep repeating the op list's bits.
+__device__ __forceinline__ float hardswish_f(float x) {
+    float t;
+    asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(t) : "v"(x), "s"(1.0f / 6.0f));
+    return x * t;
+}
+typedef float f32x2_hs __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_hs hardswish_pk(f32x2_hs x) {      // the same two operations on an fp32 pair (v_pk_fma_f32 ... clamp, v_pk_mul_f32)
+    f32x2_hs t;
+    const f32x2_hs c = {1.0f / 6.0f, 1.0f / 6.0f};
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,0,0] clamp" : "=v"(t) : "v"(x), "s"(c));
+    return x * t;
+}
 
 // Launch-policy knobs, in ONE place. Defaults are the measured best; surya_set_tuning(key, value) changes
 // them at run time for A/B sweeps inside one process (tools/microbench/decode_sweep.py). Nothing in a launch path reads the

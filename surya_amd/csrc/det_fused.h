@@ -1056,9 +1056,9 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                     uint32_t pk[4][2];                       // quad g: its 4 channels as two packed pairs
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        // on fp32 PAIRS (v_pk_add_f32 / v_pk_mul_f32; the clamp stays one v_med3 per value): the scalar form was ~8 vector
-                        // instructions per value at one wave per SIMD (107 of op 4's 589 us, SA_FMB_ABL = 1). Same operations in the same order
-                        // as hardswish_f(s + b): (x * clamp(x + 3, 0, 6)) * (1 / 6), every step one fp32 rounding.
+                        // on fp32 PAIRS: v_pk_add_f32 (bias), then common.h's hardswish_pk (v_pk_fma_f32 ... clamp, v_pk_mul_f32) -- the scalar literal
+                        // form was ~8 vector instructions per value at one wave per SIMD (107 of op 4's 589 us, SA_FMB_ABL = 1). Same operations as
+                        // hardswish_f(s + b), every step one fp32 rounding.
                         float bq[4];
                         load4(reinterpret_cast<const bf16_t*>(&b1r[j][g]), bq);
 #if SA_FMB_PK
@@ -1067,10 +1067,7 @@ __global__ __launch_bounds__(256, MCH == 64 ? 2 : 1) void fmb_kernel(const bf16_
                         for (int h = 0; h < 2; ++h) {
                             f32x2 x = f32x2{sacc[j][i][4 * g + 2 * h], sacc[j][i][4 * g + 2 * h + 1]};
                             if (!(SA_FMB_ABL & 1)) {
-                                x = x + f32x2{bq[2 * h], bq[2 * h + 1]};
-                                f32x2 t = x + f32x2{3.0f, 3.0f};
-                                t = f32x2{__builtin_amdgcn_fmed3f(t.x, 0.0f, 6.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 6.0f)};
-                                x = (x * t) * f32x2{1.0f / 6.0f, 1.0f / 6.0f};
+                                x = hardswish_pk(x + f32x2{bq[2 * h], bq[2 * h + 1]});
                             }
                             pk[g][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
                         }

@@ -202,11 +202,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
                         for (int h = 0; h < 2; ++h) {
                             f32x2 x = f32x2{acc[u][4 * g + 2 * h], acc[u][4 * g + 2 * h + 1]};
                             if constexpr (!(SA_MBC_ABL & 2)) {
-                                // hardswish_f(s + b) on an fp32 pair: (x * clamp(x + 3, 0, 6)) * (1 / 6), every step one fp32 rounding
-                                x = x + f32x2{bq[2 * h], bq[2 * h + 1]};
-                                f32x2 tt = x + f32x2{3.0f, 3.0f};
-                                tt = f32x2{__builtin_amdgcn_fmed3f(tt.x, 0.0f, 6.0f), __builtin_amdgcn_fmed3f(tt.y, 0.0f, 6.0f)};
-                                x = (x * tt) * f32x2{1.0f / 6.0f, 1.0f / 6.0f};
+                                x = hardswish_pk(x + f32x2{bq[2 * h], bq[2 * h + 1]});      // common.h: the op list's Hardswish on an fp32 pair
                             }
                             pk[h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t)) & emask[t];
                         }
