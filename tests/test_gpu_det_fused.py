@@ -123,3 +123,30 @@ def test_forward_timed_reports_every_op(hip_lib):
     heat, rows = m.forward_timed(x)
     assert torch.equal(heat, ref)
     assert len(rows) == len(m.plan_ops) and all(ms >= 0 for _, ms in rows) and sum(ms for _, ms in rows) > 0
+
+
+@pytest.mark.parametrize("h,w,pages_n", [(384, 672, 2), (736, 288, 3)])
+def test_fused_forms_non_square_pages(hip_lib, h, w, pages_n):
+    """Non-square pages (tile rasters with tiles_x != tiles_y; 672 / 4 = 168 and 288 / 4 = 72 are odd multiples of 8: the head kernel's half-outside
+    last tile): the bit-identical forms repeat the op list's bits, the re-associating ones stay inside their bound."""
+    from surya_amd.detection.model import HipDetModel
+    cfg = det_config("DET-DEFAULT")
+    sd = make_det_weights(cfg, 0)
+    m = HipDetModel(cfg, sd, height=h, width=w, dtype=torch.bfloat16, max_batch=pages_n)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(pages_n, 3, h, w, generator=g) * 0.8).cuda().contiguous()
+    try:
+        _set(hip_lib, 0)
+        base = m.forward(x).clone()
+        assert torch.isfinite(base).all() and base.std().item() > 0.01
+        for bit in (8, 16, 32, 64, 72, 132, ALL):
+            _set(hip_lib, bit)
+            hm = m.forward(x).clone()
+            d = (hm - base).abs()
+            print(f"{h}x{w} x {pages_n}: det_fuse={bit:3d} vs op list: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+            if bit in (8, 16, 32, 64, 72):
+                assert torch.equal(hm.view(torch.int32), base.view(torch.int32)), f"det_fuse={bit} must repeat the op list's bits"
+            else:
+                assert d.max().item() <= 2e-2 and d.mean().item() <= 2e-3, (bit, d.max().item())
+    finally:
+        _default(hip_lib)
