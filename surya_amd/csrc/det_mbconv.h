@@ -49,6 +49,9 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
 #endif
                                                      ) {
     constexpr int MCH = 64, KK1 = CIN / 16;
+    // the W1 ring's LDS-DMA requests are issued by the D waves at Cin = 128 and by the X waves at Cin = 256, where the D waves already carry 16 W2
+    // fragment requests per chunk and the X waves have the slack (one gpurun A/B of all four combinations: 403 / 522 us with D, 406 / 513 with X)
+    constexpr bool DREQ = SA_MBC_DREQ && CIN == 128;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, NROW = PH * PW, RT = (NROW + 31) / 32;
     constexpr int NPX = TH * TW, PT = NPX / 32, NJ = COUT / 128;       // output pixel tiles; cout tiles per D wave
     static_assert(NPX % 32 == 0 && (TW & (TW - 1)) == 0 && COUT % 128 == 0 && CIN % 64 == 0, "tile shape");
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
             ft[0] = wv == 0 ? 0 : wv + 1; hf = wv < 2 ? 1 : -1; hct = wv & 1;
         }
         const bool has_half = hf >= 0;                       // wave-uniform
-        if constexpr (!SA_MBC_DREQ) MB_ISSUE(0, 0);
+        if constexpr (!DREQ) MB_ISSUE(0, 0);
         // the patch: B fragments of this wave's row tiles, straight from global memory (clamped addresses; pixels outside the image are zeroed at the E store)
         u32x4 pf[NF + 1][KK1];
         unsigned emask[NF + 1];
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
             if (wv == 0) MBC_STAMP(0, it, 0);
             if (it < nch) {
                 const int buf = it & 1;
-                if constexpr (!SA_MBC_DREQ) MB_ISSUE(buf ^ 1, min(it + 1, nch - 1));     // unconditional (clamped): the buffer every X wave left at the last barrier
+                if constexpr (!DREQ) MB_ISSUE(buf ^ 1, min(it + 1, nch - 1));     // unconditional (clamped): the buffer every X wave left at the last barrier
                 f32x16 acc[2 * NF + 1];
 #pragma unroll
                 for (int u = 0; u < 2 * NF + 1; ++u)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
                     }
                 }
                 if (wv == 0) MBC_STAMP(0, it, 2);
-                if constexpr (!SA_MBC_DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W1 chunk it + 1 landed
+                if constexpr (!DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W1 chunk it + 1 landed
             }
             if (wv == 0) MBC_STAMP(0, it, 3);
             __syncthreads();                                 // (B_it)
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
         const bool wl = pt_ < 80;
         const bf16_t* wsrc = (pt_ >> 3) < 9 ? wd + (long)(pt_ >> 3) * Cm + (pt_ & 7) * 8 : bd + (pt_ & 7) * 8;
         u32x4 wld = {0u, 0u, 0u, 0u};
-        if constexpr (SA_MBC_DREQ) MB_ISSUE(0, 0);
+        if constexpr (DREQ) MB_ISSUE(0, 0);
         if (wl) wld = *reinterpret_cast<const u32x4*>(wsrc);
         f32x16 acc[NJ][PT];
 #pragma unroll
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
         // contiguous = 8 cache lines. From the row-major [Cout][Cm] weight a load touched 32 lines (one per output channel, 32 bytes used of each): 1024 /
         // 2048 line requests per chunk and CU, and the D waves' iteration was bound by them (4449 / 5544 cycles against ~1700 of arithmetic).
         const bf16_t* w2p = w2 + ((long)(d * NJ) * 4 * 64 + lane) * 8;
-        if constexpr (SA_MBC_DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // (P0)
         for (int it = 0; it < nch + 2; ++it) {
             if (wv == 4) MBC_STAMP(1, it, 0);
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < NS - 1; ++t) MB_LE(t, t);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (SA_MBC_DREQ) { if (it < nch) MB_ISSUE((it & 1) ^ 1, min(it + 1, nch - 1)); }     // the ring buffer every X wave left at the last barrier
+                if constexpr (DREQ) { if (it < nch) MB_ISSUE((it & 1) ^ 1, min(it + 1, nch - 1)); }     // the ring buffer every X wave left at the last barrier
                 // taps of chunk `it` into slot it & 1 (read by the depthwise of the NEXT iteration); chunk it + 1's requested
                 if (wl) {
                     unsigned char* dst = smem + OFF_TAP + (it & 1) * TAPB + pt_ * 32;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512) void mbconv_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(w2f[j][kk]));
             if (wv == 4) MBC_STAMP(1, it, 2);
-            if constexpr (SA_MBC_DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W1 chunk it + 1 landed (the W2 fragments were waited for above)
+            if constexpr (DREQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W1 chunk it + 1 landed (the W2 fragments were waited for above)
             __syncthreads();                                 // (B_it)
             if (wv == 4) MBC_STAMP(1, it, 3);
         }
