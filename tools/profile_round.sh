@@ -4,6 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03k}
+rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5     # a box can be handed out twice in a session: `find | head -1` below must not pick up the previous call's database
 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/p1 -- python $R/bench.py --no-cpu-baseline --no-texify --no-layout --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/tmp/e1
 [ -n "$SKIP_REC_PMC" ] || rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/p2 -- python $R/bench.py --no-cpu-baseline --no-det --no-e2e --no-texify --no-layout --steps 1 --warmup 0 > /tmp/o2 2>/tmp/e2
 [ -n "$SKIP_REC_PMC" ] || rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/p3 -- python $R/bench.py --no-cpu-baseline --no-det --no-e2e --no-texify --no-layout --steps 1 --warmup 0 > /tmp/o3 2>/tmp/e3
