@@ -667,10 +667,28 @@ static inline int launch_dwproj(const T*, const T*, const T*, int, const T*, con
 //   Cin = 8 : K step s = taps 2 s + (lane >> 5) (tap 9 = zero weights, reads tap 8's pixel), LDS pixel = 16 bytes
 // The 32 x 32 result D[cout][px] leaves a lane with 4 consecutive channels per group; v_permlane32_swap between lane l and l + 32 (same pixel)
 // makes that 8 consecutive channels, so the stores are 16 bytes.
-template <int CIN, int S, int EPI>      // EPI: 0 = bias + Hardswish, 1 = bias + residual
-__global__ __launch_bounds__(256, CIN == 32 ? 2 : 4) void stem_conv_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+// SRC (Cin = 8 only): where the patch comes from. 0 = the NHWC bf16 activation buffer; 1 = the caller's fp32 NCHW pixel_values (3 planes), 2 = uint8
+// NHWC pages with SegformerImageProcessor's rescale + normalise -- the input-layout kernels' conversions (nchw_to_nhwc_kernel / u8_to_nhwc_kernel,
+// bit for bit) done in the patch loader, so the 8-channel copy of the page (16 bytes per pixel written and read back: 0.54 GB per 16 pages) never exists.
+struct StemSrc { const float* planes; const unsigned char* u8; float m0, m1, m2, s0, s1, s2; int pix; };
+template <int SRC>
+__device__ __forceinline__ uint4 stem_pixel(const StemSrc& s, int b, long hw, long p) {
+    if constexpr (SRC == 1) {
+        const float* q = s.planes + (long)b * 3 * hw + p;
+        return make_uint4(pack2(q[0], q[hw]), pack2(q[2 * hw], 0.f), 0u, 0u);                 // nchw_to_nhwc_kernel's pixel
+    } else {
+#pragma clang fp contract(off)
+        const unsigned char* px = s.u8 + ((long)b * hw + p) * s.pix;                          // u8_to_nhwc_kernel's pixel (float64 rescale rounded once)
+        const double k = 1.0 / 255.0;
+        const float v0 = ((float)((double)px[0] * k) - s.m0) / s.s0, v1 = ((float)((double)px[1] * k) - s.m1) / s.s1, v2 = ((float)((double)px[2] * k) - s.m2) / s.s2;
+        return make_uint4(pack2(v0, v1), pack2(v2, 0.f), 0u, 0u);
+    }
+}
+template <int CIN, int S, int EPI, int SRC = 0>      // EPI: 0 = bias + Hardswish, 1 = bias + residual
+__global__ __launch_bounds__(256, CIN == 32 ? 2 : (SRC ? 3 : 4)) void stem_conv_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
                                                        const bf16_t* __restrict__ res, bf16_t* __restrict__ out, int H, int W, int Ho, int Wo, int Kpad,
-                                                       int tiles_x, int tiles_y, int ntiles) {
+                                                       int tiles_x, int tiles_y, int ntiles, StemSrc src = StemSrc()) {
+    static_assert(SRC == 0 || CIN == 8, "pixel sources feed the first convolution only");
     constexpr int TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PB = CIN * 2, CPP = PB / 16;
     constexpr int NSTEP = CIN == 32 ? 18 : 5;
     static_assert((CIN == 32 || CIN == 8), "stem shapes");
@@ -698,7 +716,10 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 4) void stem_conv_kernel(const
             const int idx_ = min(tid + i_ * 256, PH * PW * CPP - 1), px_ = idx_ / CPP, c_ = idx_ % CPP, pr_ = px_ / PW, pc_ = px_ - pr_ * PW; \
             const int iy_ = iy0_ + pr_, ix_ = ix0_ + pc_;                                                               \
             const bool ok_ = (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                                \
-            const uint4 v_ = *reinterpret_cast<const uint4*>(img_ + ((long)min(max(iy_, 0), H - 1) * W + min(max(ix_, 0), W - 1)) * CIN + c_ * 8); \
+            const long pp_ = (long)min(max(iy_, 0), H - 1) * W + min(max(ix_, 0), W - 1);                               \
+            uint4 v_;                                                                                                   \
+            if constexpr (SRC == 0) v_ = *reinterpret_cast<const uint4*>(img_ + pp_ * CIN + c_ * 8);                    \
+            else v_ = stem_pixel<SRC>(src, b_, (long)H * W, pp_);                                                       \
             const unsigned m_ = ok_ ? 0xffffffffu : 0u;      /* unconditional load, masked: no branch between a load and its use */ \
             pre[i_] = make_uint4(v_.x & m_, v_.y & m_, v_.z & m_, v_.w & m_);                                           \
         }                                                                                                               \
@@ -809,6 +830,18 @@ static inline int launch_stem_conv(const bf16_t* in, const bf16_t* w, const bf16
 template <typename T>
 static inline int launch_stem_conv(const T*, const T*, const T*, const T*, T*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t) {
     return SA_ERR_UNSUPPORTED;
+}
+// The first convolution straight from the caller's pixels (SRC 1 / 2 above)
+static inline int launch_stem_conv_pixels(const StemSrc& src, const bf16_t* w, const bf16_t* bias, bf16_t* out, int B, int H, int W, int Ho, int Wo,
+                                          int Cout, int k, int stride, int pad, int Kpad, int act, hipStream_t s) {
+    if (Cout != 32 || k != 3 || pad != 1 || !bias || stride != 2 || act != ACT_HSWISH || (!src.planes && !src.u8)) return SA_ERR_UNSUPPORTED;
+    const int tx = cdiv(Wo, 32), ty = cdiv(Ho, 8), ntiles = B * tx * ty;
+    const unsigned g0 = (unsigned)std::min(ntiles, 256 * 3) / 8 * 8, grid = g0 ? g0 : 8u;
+    if (src.planes)
+        hipLaunchKernelGGL((stem_conv_kernel<8, 2, 0, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)nullptr, w, bias, (const bf16_t*)nullptr, out, H, W, Ho, Wo, Kpad, tx, ty, ntiles, src);
+    else
+        hipLaunchKernelGGL((stem_conv_kernel<8, 2, 0, 2>), dim3(grid), dim3(256), 0, s, (const bf16_t*)nullptr, w, bias, (const bf16_t*)nullptr, out, H, W, Ho, Wo, Kpad, tx, ty, ntiles, src);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

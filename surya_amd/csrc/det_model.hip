@@ -87,13 +87,16 @@ struct DetModel : DetBase {
     //   bit 3  MBConv's depthwise 3x3 + projection 1x1 in one kernel (the depthwise result is the projection's A operand, in LDS only)
     //   bit 4  FusedMBConv's 3x3 expand + Hardswish + 1x1 projection in one kernel (the expanded tensor exists per 64-channel chunk, in registers / LDS only)
     //   bit 5  (not a fusion: a kernel choice) the three 32-channel stem convolutions on the patch-in-LDS kernel instead of the implicit GEMM
+    //   bit 8  (with bit 5) the first convolution reads the caller's pixels itself (fp32 planes or uint8 pages): the input-layout launch and its
+    //          8-channel copy of the page are gone; same conversions, same bits
     //   bit 7  (with bit 2) the folded head entirely on the matrix cores: the three bilinear up-samplings as a constant K = 96 map on z0's accumulators
     //          (det_head.h); re-associates fp32 sums, not bit-identical to the op list
     //   bit 6  MBConv's expand 1x1 + depthwise 3x3 + projection 1x1 in one kernel (det_mbconv.h: the expanded tensor exists per 64-channel chunk, in LDS
     //          only); takes the stride-2 transitions, where bit 3 alone leaves the 2048- / 6144-channel tensor written and read back once
-    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64, FUSE_HEAD_MFMA = 128 };
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64, FUSE_HEAD_MFMA = 128, FUSE_INPUT = 256 };
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
+    int input_fold = -1;               // the SA_DET_INPUT op whose only reader is the first stem convolution (that convolution is op input_fold + 1)
     std::vector<char> mb_start;        // per op: an expand 1x1 whose depthwise (op + 1) and projection (op + 2) the MBConv kernel takes with it
     std::vector<T*> mb_w2f;            // per DEPTHWISE op of a depthwise + projection pair: the projection weight, fragment-major (det_mbconv.h), made once at init; owned
     std::vector<T*> head_a0f;          // per op (FUSE_HEAD_Z0): the folded z0 convolution's weight A0, fragment-major; owned
@@ -101,6 +104,7 @@ struct DetModel : DetBase {
     // an op that does not run under the fused forms switched on by `fuse`
     bool folded(int oi, int fuse) const {
         const int n = (int)ops.size();
+        if (oi == input_fold && (fuse & FUSE_INPUT) && (fuse & FUSE_STEM)) return true;
         if ((fuse & FUSE_MBCONV) && ((oi >= 1 && mb_start[oi - 1]) || (oi >= 2 && mb_start[oi - 2]))) return true;
         if (oi > 0 && fuse_with[oi - 1] == oi && (fuse & fuse_kind[oi - 1])) return true;
         for (int j = oi + 1; j < n; ++j) if (fuse_kind[j] == FUSE_HEAD_Z0 && fuse_with[j] == oi && (fuse & FUSE_HEAD_Z0)) return true;
@@ -123,6 +127,15 @@ struct DetModel : DetBase {
                 a.b_idx >= 0 && a.act == SA_ACT_HSWISH) { fuse_kind[i] = FUSE_DWPROJ; fuse_with[i] = i + 1; }
             if (a.type == SA_DET_CONV && a.k == 3 && a.act == SA_ACT_HSWISH && a.res < 0 && b.type == SA_DET_CONV && b.k == 1 && b.stride == 1 &&
                 b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && fmb_supported(a, b)) { fuse_kind[i] = FUSE_FMB; fuse_with[i] = i + 1; }
+        }
+        // the input-layout op feeding ONLY the first stem convolution (3 -> 8 padded channels, 3x3 stride 2, 32 outputs)
+        input_fold = -1;
+        if (BF && n >= 2 && ops[0].type == SA_DET_INPUT && ops[1].type == SA_DET_CONV && ops[1].in0 == ops[0].out && ops[0].cin == 3 && ops[0].cout == 8 &&
+            ops[1].cin == 8 && ops[1].cout == 32 && ops[1].k == 3 && ops[1].stride == 2 && ops[1].p0 == 1 && ops[1].act == SA_ACT_HSWISH && ops[1].res < 0 &&
+            ops[1].b_idx >= 0) {
+            bool only = true;
+            for (int k2 = 2; k2 < n; ++k2) if (ops[k2].in0 == ops[0].out || ops[k2].in1 == ops[0].out || ops[k2].res == ops[0].out) only = false;
+            if (only) input_fold = 0;
         }
         // whole MBConv blocks: expand 1x1 (+ Hardswish) whose only reader is the depthwise of a depthwise + projection pair found above
         for (int i = 0; i + 2 < n && BF; ++i) {
@@ -285,6 +298,13 @@ struct DetModel : DetBase {
                         }
                     }
                     if constexpr (std::is_same<T, bf16_t>::value) {
+                        if (input_fold >= 0 && oi == input_fold + 1 && (fuse & FUSE_INPUT) && (fuse & FUSE_STEM)) {
+                            StemSrc src{pixels_u8 ? nullptr : pixels, pixels_u8, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pix};
+                            if (pixels_u8) { src.m0 = ms[0]; src.m1 = ms[1]; src.m2 = ms[2]; src.s0 = ms[3]; src.s1 = ms[4]; src.s2 = ms[5]; }
+                            if ((rc = launch_stem_conv_pixels(src, WT(op.w_idx), WT(op.b_idx), bufs[op.out], B, op.hin, op.win, op.hout, op.wout, op.cout,
+                                                              op.k, op.stride, op.p0, op.p1, op.act, s))) return rc;
+                            break;
+                        }
                         // the 32-channel stem convolutions: patch-in-LDS kernel (det_fuse bit 5; the implicit-GEMM path below is the checker)
                         if ((fuse & FUSE_STEM) && op.cout == 32 && op.k == 3) {
                             rc = launch_stem_conv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), op.res >= 0 ? bufs[op.res] : nullptr, bufs[op.out], B, op.hin,

@@ -6,9 +6,10 @@ det_fuse = 0 runs detection/plan.py's op list as written (round 5's path: every 
   8  MBConv depthwise 3x3 + projection        16 FusedMBConv 3x3 + Hardswish + projection (the two Cout = 64 blocks of stage 0)
   32 the three 32-channel stem convolutions on the patch-in-LDS kernel (a kernel choice, not a fusion)
   64 whole MBConv blocks (expand 1x1 + depthwise 3x3 + projection 1x1; csrc/det_mbconv.h) -- the two stride-2 transitions
+  256 (with 32) the first convolution reads the caller's pixels itself: no input-layout launch (same conversions: bit-identical)
   128 (with 4) the folded head entirely on the matrix cores: bilinear up-samplings as a constant K = 96 map on z0's accumulators (csrc/det_head.h)
 Expectations written into the asserts:
-  * bits 4, 8, 16, 32 and 64 repeat the op list's arithmetic exactly (same MFMA, same K order, same rounding points): heat maps bit-identical;
+  * bits 4, 8, 16, 32, 64 and 256 repeat the op list's arithmetic exactly (same MFMA, same K order, same rounding points): heat maps bit-identical;
   * bit 1 runs the grouped 1x1 on the bf16 MFMA instead of an fp32 fma chain, bit 2 sums tokens on the fp32 MFMA in another order and bit 128
     interpolates on the MFMA (and does not round z0 to bf16 on its own):
     fp32-accumulation re-association only, but a bf16 rounding step of an intermediate may flip and the flips travel through the six
@@ -26,7 +27,7 @@ from surya_amd.synth import make_det_weights, make_pages
 
 pytestmark = pytest.mark.gpu
 
-ALL = 255
+ALL = 511
 
 
 def _set(lib, v):
@@ -38,7 +39,7 @@ def _default(lib):
     _set(lib, DEFAULT)
 
 
-DEFAULT = 255
+DEFAULT = 511
 
 
 def build(name, size, dtype, max_batch):
@@ -61,7 +62,7 @@ def test_fused_forms_vs_op_list_bf16(hip_lib, pages_n, size):
         again = m.forward(x).clone()
         assert torch.equal(base, again)
         assert torch.isfinite(base).all() and base.std().item() > 0.02
-        for bit in (1, 2, 4, 8, 16, 32, 64, 72, 127, 132, ALL):
+        for bit in (1, 2, 4, 8, 16, 32, 64, 72, 127, 132, 288, ALL):
             _set(hip_lib, bit)
             h = m.forward(x).clone()
             h2 = m.forward(x).clone()
@@ -69,7 +70,7 @@ def test_fused_forms_vs_op_list_bf16(hip_lib, pages_n, size):
             d = (h - base).abs().max().item()
             print(f"{size}^2 x {pages_n}: det_fuse={bit:2d} vs op list: max abs diff {d:.3e}, identical {torch.equal(h, base)}")
             assert torch.isfinite(h).all()
-            if bit in (4, 8, 16, 32, 64, 72):
+            if bit in (4, 8, 16, 32, 64, 72, 288):
                 assert torch.equal(h.view(torch.int32), base.view(torch.int32)), f"det_fuse={bit} must repeat the op list's bits"
             else:
                 assert d <= 2e-2 and (h - base).abs().mean().item() <= 2e-3, (bit, d)
@@ -139,14 +140,43 @@ def test_fused_forms_non_square_pages(hip_lib, h, w, pages_n):
         _set(hip_lib, 0)
         base = m.forward(x).clone()
         assert torch.isfinite(base).all() and base.std().item() > 0.01
-        for bit in (8, 16, 32, 64, 72, 132, ALL):
+        for bit in (8, 16, 32, 64, 72, 288, 132, ALL):
             _set(hip_lib, bit)
             hm = m.forward(x).clone()
             d = (hm - base).abs()
             print(f"{h}x{w} x {pages_n}: det_fuse={bit:3d} vs op list: max {d.max().item():.3e} mean {d.mean().item():.3e}")
-            if bit in (8, 16, 32, 64, 72):
+            if bit in (8, 16, 32, 64, 72, 288):
                 assert torch.equal(hm.view(torch.int32), base.view(torch.int32)), f"det_fuse={bit} must repeat the op list's bits"
             else:
                 assert d.max().item() <= 2e-2 and d.mean().item() <= 2e-3, (bit, d.max().item())
+    finally:
+        _default(hip_lib)
+
+
+@pytest.mark.parametrize("pix", [3, 4])
+def test_input_fused_stem_u8_pages(hip_lib, pix):
+    """surya_det_forward_u8 with the first convolution reading the uint8 pages itself (bits 32 + 256: rescale + normalise in the patch loader, RGB
+    and RGBX) against the op list (input-layout launch + implicit-GEMM convolution): the same conversions, bit-identical maps; 672 x 416 page."""
+    import numpy as np
+    from surya_amd.detection.model import HipDetModel
+    cfg = det_config("DET-DEFAULT")
+    sd = make_det_weights(cfg, 0)
+    h, w, n = 416, 672, 3
+    m = HipDetModel(cfg, sd, height=h, width=w, dtype=torch.bfloat16, max_batch=n)
+    rng = np.random.default_rng(11)
+    u8 = torch.from_numpy(rng.integers(0, 256, size=(n, h, w, pix), dtype=np.uint8)).cuda().contiguous()
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    try:
+        _set(hip_lib, 0)
+        base = m.forward_u8(u8, mean, std).clone()
+        for bit in (32, 288, ALL):
+            _set(hip_lib, bit)
+            hm = m.forward_u8(u8, mean, std).clone()
+            d = (hm - base).abs().max().item()
+            print(f"u8 pix={pix}: det_fuse={bit} vs op list: max abs diff {d:.3e}")
+            if bit != ALL:
+                assert torch.equal(hm.view(torch.int32), base.view(torch.int32)), bit
+            else:
+                assert d <= 2e-2
     finally:
         _default(hip_lib)
