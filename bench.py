@@ -84,7 +84,7 @@ def parse():
                     help="seconds the auxiliary legs (cpu baseline, detection, e2e, texify) may take after the timed main leg before "
                          "the JSON line is printed without the unfinished ones (default 900 at N = 1, 240 at N > 1)")
     ap.add_argument("--no-det-op-list", action="store_true", help="skip the det_fuse = 0 arm of the detection leg (counter passes: tools/profile_round.sh)")
-    ap.add_argument("--det-fuse", type=int, default=511, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
+    ap.add_argument("--det-fuse", type=int, default=1023, help="sa::Tuning det_fuse for the detection leg (csrc/det_model.hip; 0 = the op list as written)")
     ap.add_argument("--no-slot-sweep", action="store_true", help="skip the e2e leg's 256 / 512 / 1024-slot sweep")
     ap.add_argument("--e2e-slots", type=lambda v: [int(x) for x in v.split(",")], default=[256, 512, 1024], help="slot counts of the e2e sweep")
     ap.add_argument("--no-predictor-call", action="store_true", help="skip the predictor_call object (RecognitionPredictor.__call__ wall clock + CPU oracle through the same call shape)")

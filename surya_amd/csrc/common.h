@@ -224,11 +224,12 @@ struct Tuning {
                              // compute): 0 = when some active slot's context exceeds one 128-key tile (host bound; eager launches only -- under graph replay, `graph` = 1, the single-buffer kernel runs and the bound is not advanced), 1 = always, -1 = never
     int lay_ln = 1;          // layout / table encoder LayerNorm (bf16): 1 = rows held in registers by C / 8 lanes (layernorm_rows_bf16_kernel), 0 = a wave per row
     int det_head_blk = 1;    // detector's folded decode head: 1 = register-blocked sum + classify (4 x 2 pixel blocks), 0 = per-pixel kernel
-    int det_fuse = 511;      // detector's fused forms (det_model.hip find_fusions; bf16): bit 0 = LiteMLA depthwise 5x5 + grouped 1x1, bit 1 = LiteMLA kv + out in one
+    int det_fuse = 1023;     // detector's fused forms (det_model.hip find_fusions; bf16): bit 0 = LiteMLA depthwise 5x5 + grouped 1x1, bit 1 = LiteMLA kv + out in one
                              // launch, bit 2 = z0 inside the head's sum + classify pass, bit 3 = MBConv depthwise 3x3 + projection, bit 4 = FusedMBConv
                              // 3x3 + Hardswish + projection, bit 5 = stem convolutions on the patch-in-LDS kernel, bit 6 = whole MBConv blocks (expand + depthwise +
                              // projection) in one launch at the stride-2 transitions (det_mbconv.h), bit 7 = (with bit 2) the folded head entirely on the matrix cores
-                             // (det_head.h), bit 8 = (with bit 5) the first convolution reads the caller's pixels itself (no input-layout launch); 0 = the op list as written (the checker of
+                             // (det_head.h), bit 8 = (with bit 5) the first convolution reads the caller's pixels itself (no input-layout launch), bit 9 = the stem's residual block (two 3x3
+                             // convolutions) in one launch with the tensor between them in LDS; 0 = the op list as written (the checker of
                              // tests/test_gpu_det_fused.py)
     int fmb_chunk = 64;      // FusedMBConv kernel, Cin = 64 stride 1: mid channels per chunk -- 64 = two workgroups per CU (the chunk epilogue of one beside the
                              // MFMAs of the other), 128 = one workgroup per CU with twice the accumulators

@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, 3) void head_mfma_kernel(const bf16_t* __restr
         if (more_tiles) HM_TILE(tl + gx, nimg, ny0, nx0);
         for (int sl = 0; sl < nslab; ++sl, ++step) {
             const int buf = step & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this step's taps and A0 fragments (and x0 fragments) have landed
+            // this step's taps and A0 fragments (and x0 fragments) have landed. The BUILTIN (not asm): hipcc's own counter bookkeeping then knows the x0
+            // fragments' loads are complete. With an asm wait it kept them pending and put s_waitcnt vmcnt(0) in front of the step's first MFMA -- behind
+            // the five LDS-DMA requests just issued for the NEXT step (invisible to it), every step: the ring never ran ahead
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();                                 // ... for every wave, and every wave is done with the other buffers
             const bool last = sl + 1 == nslab;
             if (last) HM_ROWS(nimg, ny0, nx0);               // the next step belongs to the next tile (re-reads this tile at the very end: harmless)

@@ -89,11 +89,13 @@ struct DetModel : DetBase {
     //   bit 5  (not a fusion: a kernel choice) the three 32-channel stem convolutions on the patch-in-LDS kernel instead of the implicit GEMM
     //   bit 8  (with bit 5) the first convolution reads the caller's pixels itself (fp32 planes or uint8 pages): the input-layout launch and its
     //          8-channel copy of the page are gone; same conversions, same bits
+    //   bit 9  the stem's residual block (two 32 -> 32 3x3 convolutions, x + conv2(hswish(conv1(x)))) in one kernel: the tensor between them lives in
+    //          LDS (det_fused.h stem_res_kernel); the two launches' K orders and rounding points: bit-identical
     //   bit 7  (with bit 2) the folded head entirely on the matrix cores: the three bilinear up-samplings as a constant K = 96 map on z0's accumulators
     //          (det_head.h); re-associates fp32 sums, not bit-identical to the op list
     //   bit 6  MBConv's expand 1x1 + depthwise 3x3 + projection 1x1 in one kernel (det_mbconv.h: the expanded tensor exists per 64-channel chunk, in LDS
     //          only); takes the stride-2 transitions, where bit 3 alone leaves the 2048- / 6144-channel tensor written and read back once
-    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64, FUSE_HEAD_MFMA = 128, FUSE_INPUT = 256 };
+    enum { FUSE_MLA_AGG = 1, FUSE_MLA_ATTN = 2, FUSE_HEAD_Z0 = 4, FUSE_DWPROJ = 8, FUSE_FMB = 16, FUSE_STEM = 32, FUSE_MBCONV = 64, FUSE_HEAD_MFMA = 128, FUSE_INPUT = 256, FUSE_STEM_RES = 512 };
     std::vector<int> fuse_kind;        // per op: the fused form that STARTS here (0 = none)
     std::vector<int> fuse_with;        // per op: index of the partner op (the one skipped / the producer folded in), -1 = none
     int input_fold = -1;               // the SA_DET_INPUT op whose only reader is the first stem convolution (that convolution is op input_fold + 1)
@@ -127,6 +129,14 @@ struct DetModel : DetBase {
                 a.b_idx >= 0 && a.act == SA_ACT_HSWISH) { fuse_kind[i] = FUSE_DWPROJ; fuse_with[i] = i + 1; }
             if (a.type == SA_DET_CONV && a.k == 3 && a.act == SA_ACT_HSWISH && a.res < 0 && b.type == SA_DET_CONV && b.k == 1 && b.stride == 1 &&
                 b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && fmb_supported(a, b)) { fuse_kind[i] = FUSE_FMB; fuse_with[i] = i + 1; }
+            if (a.type == SA_DET_CONV && a.k == 3 && a.stride == 1 && a.p0 == 1 && a.cin == 32 && a.cout == 32 && a.act == SA_ACT_HSWISH && a.res < 0 &&
+                a.b_idx >= 0 && b.type == SA_DET_CONV && b.k == 3 && b.stride == 1 && b.p0 == 1 && b.cin == 32 && b.cout == 32 && b.act == SA_ACT_NONE &&
+                b.b_idx >= 0 && b.in0 == a.out && b.res == a.in0 && b.p1 == a.p1) {
+                bool only_reader = true;
+                for (int k2 = 0; k2 < n; ++k2)
+                    if (k2 != i + 1 && (ops[k2].in0 == a.out || ops[k2].in1 == a.out || ops[k2].res == a.out)) only_reader = false;
+                if (only_reader) { fuse_kind[i] = FUSE_STEM_RES; fuse_with[i] = i + 1; }
+            }
         }
         // the input-layout op feeding ONLY the first stem convolution (3 -> 8 padded channels, 3x3 stride 2, 32 outputs)
         input_fold = -1;
@@ -287,6 +297,12 @@ struct DetModel : DetBase {
                             if ((rc = launch_mbconv(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(dw.w_idx), WT(dw.b_idx), mb_w2f[oi + 1], WT(pj.b_idx),
                                                     pj.res >= 0 ? bufs[pj.res] : nullptr, bufs[pj.out], B, op.hin, op.win, op.cin, op.cout, dw.hout,
                                                     dw.wout, pj.cout, dw.stride, s))) return rc;
+                            break;
+                        }
+                        if (fk == FUSE_STEM_RES) {
+                            const surya_det_op& c2 = ops[fuse_with[oi]];
+                            if ((rc = launch_stem_res(bufs[op.in0], WT(op.w_idx), WT(op.b_idx), WT(c2.w_idx), WT(c2.b_idx), bufs[c2.out], B, op.hin, op.win,
+                                                      op.p1, s))) return rc;
                             break;
                         }
                         if (fk == FUSE_FMB) {

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--pages", type=int, default=16)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--config", default="DET-DEFAULT")
-    ap.add_argument("--fuse", default="0,511")
+    ap.add_argument("--fuse", default="0,1023")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--json", action="store_true")
@@ -95,7 +95,7 @@ def main():
         d = (heats[arm] - base).abs()
         print(f"heat maps det_fuse={arm} vs {arms[0]}: max abs diff {d.max().item():.3e}, mean {d.mean().item():.3e}, "
               f"bit-identical: {bool(torch.equal(heats[arm].view(torch.int32), base.view(torch.int32)))}")
-    L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(511)), "surya_set_tuning")
+    L.check(lib.surya_set_tuning(b"det_fuse", C.c_int(1023)), "surya_set_tuning")
     if args.json:
         print(json.dumps(summary))
 
