@@ -852,7 +852,8 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, PH = TH + 4, PW = TW + 4, NI = IH * IW, NIT = (NI + 31) / 32, NSTEP = 18;
     constexpr int PATCHB = PH * PW * 64, INTERB = NIT * 32 * 64;
     static_assert(NIT == 11, "three row tiles for conv1 waves 0-2, two for wave 3");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                    // 2 * PATCHB + 2 * INTERB = 100352 bytes
+    static_assert(PH * PW / 16 == 27, "7 / 7 / 7 / 6 requests per wave: the counted waits below");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                    // 3 * PATCHB + 2 * INTERB = 128000 bytes
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wv8 = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
         if (pc >= PW) { pc -= PW; ++prw; }
         poff[k] = (prw * W + pc) * 64 + (((lane & 3) ^ ((pc >> 2) & 3)) << 4);
     }
-    auto request_patch = [&](int j, int buf) {
+    auto request_patch = [&](int j, int buf) -> int {    // returns this wave's request count on an interior tile, -1 on an edge tile (lanes outside the image skip theirs)
         const int bid = t_begin + wx + j * gx;
         const int b = bid / tpp, tr = bid - b * tpp;
         const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_), "s"(l_) : "memory", "m0");
                 }
             }
-            return;
+            return wv < (PH * PW / 16) % 4 ? (PH * PW / 16 + 3) / 4 : PH * PW / 16 / 4;
         }
         unsigned char* patch = smem + buf * PATCHB;
         int ln = lane;
@@ -949,23 +950,29 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
                 }
             }
         }
+        return -1;
     };
+    // THREE patch buffers, requests two tiles ahead: with one tile's patch (27 KB) in flight per CU the iteration could not be shorter than the loaded
+    // memory round trip (ablation: no requests = -47 of 229 us). The end-of-iteration wait is counted: the newest tile's requests stay in flight
     if (conv1) {
         request_patch(0, 0);
+        if (nloc > 1) request_patch(1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     // one tile loop per role (the same number of barriers in each): in ONE loop hipcc's counter bookkeeping merged the conv2 waves' loads and stores into
     // the conv1 path and put s_waitcnt vmcnt(0) in front of conv1's first MFMA -- behind the patch requests just issued
     if (conv1) {
+        int pb = 0;                                          // j % 3
         for (int j = 0; j <= nloc; ++j) {
+            int nreq = 0;
             if (j < nloc) {
-                if (j + 1 < nloc && !(SA_SR_ABL & 4)) request_patch(j + 1, (j + 1) & 1);
+                if (j + 2 < nloc && !(SA_SR_ABL & 4)) nreq = request_patch(j + 2, pb == 0 ? 2 : pb - 1);
                 const int bid = t_begin + wx + j * gx;
                 const int b = bid / tpp, tr = bid - b * tpp;
                 const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
-                const unsigned char* patch = smem + (j & 1) * PATCHB;
-                unsigned char* inter = smem + 2 * PATCHB + (j & 1) * INTERB;
+                const unsigned char* patch = smem + pb * PATCHB;
+                unsigned char* inter = smem + 3 * PATCHB + (j & 1) * INTERB;
                 f32x16 acc[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
@@ -1006,8 +1013,13 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
                     }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): tile j + 1's patch has landed (this wave's share); the builtin, so that hipcc's own bookkeeping sees a clean state too
-            __syncthreads();                                 // inter[j & 1] is complete, patch[(j + 1) & 1] has landed, inter[(j - 1) & 1] and patch[j & 1] are free
+            // tile j + 1's patch has landed (this wave's share), tile j + 2's requests stay in flight. The builtin, so that hipcc's own bookkeeping sees
+            // a clean state too (vmcnt(N) = 0x0F70 | N)
+            if (nreq == 7) __builtin_amdgcn_s_waitcnt(0x0F77);
+            else if (nreq == 6) __builtin_amdgcn_s_waitcnt(0x0F76);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            pb = pb == 2 ? 0 : pb + 1;
+            __syncthreads();                                 // inter[j & 1] is complete, patch[(j + 1) % 3] has landed, inter[(j - 1) & 1] and patch[j % 3] are free
         }
     } else {
         // conv2's bias, this lane's two 8-channel groups, once (a load in the tile's epilogue waits vmcnt(0) behind the output store in front of it)
@@ -1022,7 +1034,7 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
             const int bid = t_begin + wx + (j - 1) * gx;
             const int b = bid / tpp, tr = bid - b * tpp;
             const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
-            const unsigned char* inter = smem + 2 * PATCHB + ((j - 1) & 1) * INTERB;
+            const unsigned char* inter = smem + 3 * PATCHB + ((j - 1) & 1) * INTERB;
             // residual rows of this tile (the block's input, L2-hot: the conv1 waves pulled it one iteration ago), requested before the MFMAs
             uint4 rraw[2][2];
             long obase[2];
@@ -1098,7 +1110,7 @@ static inline int launch_stem_res(const bf16_t* in, const bf16_t* w1, const bf16
     if (!b1 || !b2 || (long)B * H * W * 32 >= (1L << 31)) return SA_ERR_UNSUPPORTED;
     const int tx = cdiv(W, 32), ty = cdiv(H, 8), ntiles = B * tx * ty;
     const unsigned g0 = (unsigned)std::min(ntiles, 256) / 8 * 8, grid = g0 ? g0 : 8u;      // persistent: one workgroup per CU, whole XCD rounds
-    const size_t lds = 2 * (12 * 36 * 64) + 2 * (11 * 32 * 64);
+    const size_t lds = 3 * (12 * 36 * 64) + 2 * (11 * 32 * 64);
     auto kern = stem_res_kernel;
     static AttrOnce attr;
     attr.ensure(kern, lds);
