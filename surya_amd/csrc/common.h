@@ -231,6 +231,7 @@ struct Tuning {
                              // (det_head.h), bit 8 = (with bit 5) the first convolution reads the caller's pixels itself (no input-layout launch), bit 9 = the stem's residual block (two 3x3
                              // convolutions) in one launch with the tensor between them in LDS; 0 = the op list as written (the checker of
                              // tests/test_gpu_det_fused.py)
+    int det_up4 = 1;         // detector's x4 output up-sampling: 1 = a 4 x 4 output block per thread from its 3 x 3 source neighbourhood (upsample_planes_x4_kernel), 0 = upsample_planes4_kernel (the checker: same bits)
     int fmb_chunk = 64;      // FusedMBConv kernel, Cin = 64 stride 1: mid channels per chunk -- 64 = two workgroups per CU (the chunk epilogue of one beside the
                              // MFMAs of the other), 128 = one workgroup per CU with twice the accumulators
     int persist = 1;         // 256x256 bf16 GEMMs (>= 4 even K-tiles) as the PERSISTENT 8-phase loop (gemm_nt_p8p_kernel: the half-tile ring runs on across

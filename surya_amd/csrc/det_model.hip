@@ -428,7 +428,10 @@ struct DetModel : DetBase {
                 case SA_DET_UPSAMPLE_OUT: {
                     if (!heat) break;
                     const long n = (long)B * op.cout * op.hout * op.wout;
-                    if (op.wout % 4 == 0)
+                    if (op.hout == 4 * op.hin && op.wout == 4 * op.win && B * op.cout <= 65535 && cdiv(op.hin, 4) <= 65535 && tuning().det_up4)
+                        hipLaunchKernelGGL(upsample_planes_x4_kernel, dim3((unsigned)cdiv(op.win, 64), (unsigned)cdiv(op.hin, 4), (unsigned)(B * op.cout)),
+                                           dim3(64, 4), 0, s, planes, heat, op.hin, op.win);
+                    else if (op.wout % 4 == 0)
                         hipLaunchKernelGGL(upsample_planes4_kernel, dim3((unsigned)cdivl(n / 4, 256)), dim3(256), 0, s, planes, heat,
                                            B * op.cout, op.hin, op.win, op.hout, op.wout);
                     else

@@ -1459,7 +1459,7 @@ int surya_set_tuning(const char* key, int value) {
         {"graph", &t.graph}, {"split_target", &t.split_target}, {"split_min_kt", &t.split_min_kt}, {"split_max", &t.split_max},
         {"bigtile", &t.bigtile}, {"bigtile_any", &t.bigtile_any}, {"conv_lean", &t.conv_lean}, {"conv_persist", &t.conv_persist}, {"dwconv_pipe", &t.dwconv_pipe}, {"bigtile_ratio_pct", &t.bigtile_ratio_pct}, {"gateup_ring", &t.gateup_ring}, {"big_m_split", &t.big_m_split}, {"big_m_gateup", &t.big_m_gateup}, {"glds", &t.glds}, {"bigtile_min_k", &t.bigtile_min_k}, {"dattn", &t.dattn}, {"rnorm", &t.rnorm},
         {"ghead", &t.ghead}, {"fuse_embed", &t.fuse_embed}, {"persist", &t.persist}, {"lmhead", &t.lmhead}, {"kvprefetch", &t.kvprefetch},
-        {"dattn_db", &t.dattn_db}, {"lay_ln", &t.lay_ln}, {"det_head_blk", &t.det_head_blk}, {"det_fuse", &t.det_fuse}, {"fmb_chunk", &t.fmb_chunk}};
+        {"dattn_db", &t.dattn_db}, {"lay_ln", &t.lay_ln}, {"det_head_blk", &t.det_head_blk}, {"det_fuse", &t.det_fuse}, {"det_up4", &t.det_up4}, {"fmb_chunk", &t.fmb_chunk}};
     for (auto& e : tab)
         if (!strcmp(e.k, key)) {
             if (*e.v != value) ++tuning_epoch();        // captured decode graphs are stale (RecModel::decode_steps drops them)

@@ -181,3 +181,26 @@ def test_input_fused_stem_u8_pages(hip_lib, pix):
                 assert d <= 2e-2
     finally:
         _default(hip_lib)
+
+
+@pytest.mark.parametrize("h,w,pages_n", [(1024, 1024, 2), (416, 672, 3)])
+def test_x4_output_upsample_repeats_the_generic_kernel(hip_lib, h, w, pages_n):
+    """sa::Tuning det_up4: the x4 output up-sampling with a 4 x 4 output block per thread (upsample_planes_x4_kernel) against the generic float4 kernel
+    (det_up4 = 0): same coefficients, same operands, same expression -- bit-identical heat maps, also on a page whose quarter-resolution map is not a
+    multiple of the 64 x 4 thread block."""
+    from surya_amd import _lib as L
+    from surya_amd.detection.model import HipDetModel
+    cfg = det_config("DET-DEFAULT")
+    sd = make_det_weights(cfg, 0)
+    m = HipDetModel(cfg, sd, height=h, width=w, dtype=torch.bfloat16, max_batch=pages_n)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(pages_n, 3, h, w, generator=g).cuda().contiguous()
+    try:
+        L.check(hip_lib.surya_set_tuning(b"det_up4", C.c_int(0)), "surya_set_tuning")
+        base = m.forward(x).clone()
+        L.check(hip_lib.surya_set_tuning(b"det_up4", C.c_int(1)), "surya_set_tuning")
+        got = m.forward(x).clone()
+        assert base.std().item() > 0.01
+        assert torch.equal(got.view(torch.int32), base.view(torch.int32))
+    finally:
+        L.check(hip_lib.surya_set_tuning(b"det_up4", C.c_int(1)), "surya_set_tuning")
