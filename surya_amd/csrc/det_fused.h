@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) void stem_res_kernel(const bf16_t* __restri
 
 static inline int launch_stem_res(const bf16_t* in, const bf16_t* w1, const bf16_t* b1, const bf16_t* w2, const bf16_t* b2, bf16_t* out, int B, int H,
                                   int W, int Kpad, hipStream_t s) {
-    if (!b1 || !b2 || (long)B * H * W * 32 >= (1L << 31)) return SA_ERR_UNSUPPORTED;
+    if (!b1 || !b2 || (long)H * W * 64 >= (1L << 31) || (long)B * cdiv(W, 32) * cdiv(H, 8) >= (1L << 31)) return SA_ERR_UNSUPPORTED;   // (per-image byte offsets are 32-bit; find_fusions checks the same)
     const int tx = cdiv(W, 32), ty = cdiv(H, 8), ntiles = B * tx * ty;
     const unsigned g0 = (unsigned)std::min(ntiles, 256) / 8 * 8, grid = g0 ? g0 : 8u;      // persistent: one workgroup per CU, whole XCD rounds
     const size_t lds = 3 * (12 * 36 * 64) + 2 * (11 * 32 * 64);

@@ -131,7 +131,8 @@ struct DetModel : DetBase {
                 b.in0 == a.out && b.act == SA_ACT_NONE && b.p1 == b.cin && fmb_supported(a, b)) { fuse_kind[i] = FUSE_FMB; fuse_with[i] = i + 1; }
             if (a.type == SA_DET_CONV && a.k == 3 && a.stride == 1 && a.p0 == 1 && a.cin == 32 && a.cout == 32 && a.act == SA_ACT_HSWISH && a.res < 0 &&
                 a.b_idx >= 0 && b.type == SA_DET_CONV && b.k == 3 && b.stride == 1 && b.p0 == 1 && b.cin == 32 && b.cout == 32 && b.act == SA_ACT_NONE &&
-                b.b_idx >= 0 && b.in0 == a.out && b.res == a.in0 && b.p1 == a.p1) {
+                b.b_idx >= 0 && b.in0 == a.out && b.res == a.in0 && b.p1 == a.p1 && (long)a.hin * a.win * 64 < (1L << 31) &&
+                (long)max_batch * cdiv(a.win, 32) * cdiv(a.hin, 8) < (1L << 31)) {
                 bool only_reader = true;
                 for (int k2 = 0; k2 < n; ++k2)
                     if (k2 != i + 1 && (ops[k2].in0 == a.out || ops[k2].in1 == a.out || ops[k2].res == a.out)) only_reader = false;
