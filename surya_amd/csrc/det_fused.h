@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 // (Tried and not kept, gpurun r06n: a wave per 8-channel chunk with the tap weights as SCALAR operands -- s_load + SALU unpack, v_fmac with an
 // SGPR source, each input vector unpacked once, 86 VGPRs -- runs 79 us against this version's 62: the scalar loads of a rolled row loop sit
 // on the critical path of every filter row.)
+#ifndef SA_DW5_ORDER
+#define SA_DW5_ORDER 0      // 0 = a filter column per iteration (input rows shared by the output rows), 1 = the first version: a filter row per iteration, taps in dwconv_tx_kernel's order
+#endif
 __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
                                                       bf16_t* __restrict__ out, const bf16_t* __restrict__ zero, int H, int W, int C, int tiles_x) {
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4;
@@ -196,6 +199,39 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
         for (int o = 0; o < 4; ++o)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#if SA_DW5_ORDER == 0
+#pragma unroll 1
+        for (int kx = 0; kx < 5; ++kx) {                    // (rolled: unrolled, hipcc hoists all the LDS reads and spills)
+            // one filter COLUMN at a time: the thread's eight input rows at column x + kx are read and unpacked once and feed all (output row, ky)
+            // pairs -- 40 LDS reads and 320 unpack operations per thread where the row-at-a-time loop below spends 100 and 800 (62 -> 47 us). An
+            // accumulator sees its taps in (kx, ky) order instead of dwconv_tx_kernel's (ky, kx): an fp32 re-association, the class this form is in
+            float wc[5][8];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wd + (ky * 5 + kx) * 32 + chunk * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wd + (ky * 5 + kx) * 32 + chunk * 8 + 4);
+                wc[ky][0] = w0.x; wc[ky][1] = w0.y; wc[ky][2] = w0.z; wc[ky][3] = w0.w;
+                wc[ky][4] = w1.x; wc[ky][5] = w1.y; wc[ky][6] = w1.z; wc[ky][7] = w1.w;
+            }
+            uint4 raw[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[r] = *reinterpret_cast<const uint4*>(in_t + ((yg * 4 + r) * PW + x + kx) * 64 + chunk * 16);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float xv[8];
+                unpack16(raw[r], xv, (bf16_t*)nullptr);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int ky = r - o;
+                    if (ky >= 0 && ky < 5) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[o][e] += xv[e] * wc[ky][e];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll 1
         for (int ky = 0; ky < 5; ++ky) {                    // (rolled, and one output row at a time below: unrolled, hipcc hoists all 150 LDS reads and spills)
             float wr[5][8];
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int px = (yg * 4 + o) * TW + x;
