@@ -152,15 +152,19 @@ __global__ __launch_bounds__(256) void litemla_fused_kernel(const T* __restrict_
 // (Tried and not kept, gpurun r06n: a wave per 8-channel chunk with the tap weights as SCALAR operands -- s_load + SALU unpack, v_fmac with an
 // SGPR source, each input vector unpacked once, 86 VGPRs -- runs 79 us against this version's 62: the scalar loads of a rolled row loop sit
 // on the critical path of every filter row.)
+#ifndef SA_DW5_WG
+#define SA_DW5_WG 4
+#endif
 #ifndef SA_DW5_ORDER
 #define SA_DW5_ORDER 0      // 0 = a filter column per iteration (input rows shared by the output rows), 1 = the first version: a filter row per iteration, taps in dwconv_tx_kernel's order
 #endif
-__global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
+__global__ __launch_bounds__(256, SA_DW5_WG) void dw5_g1x1_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wdw, const bf16_t* __restrict__ wg,
                                                       bf16_t* __restrict__ out, const bf16_t* __restrict__ zero, int H, int W, int C, int tiles_x) {
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4;
     __shared__ __attribute__((aligned(16))) unsigned char in_t[PH * PW * 64];
     __shared__ __attribute__((aligned(16))) float wd[25 * 32];
-    __shared__ __attribute__((aligned(16))) unsigned char a_t[TH * TW * 64];
+    unsigned char* a_t = in_t;                               // the A tile [256 px][32 ch] takes the patch's place once every thread is done reading it: 31 KB, four workgroups per CU
+    static_assert(TH * TW * 64 <= PH * PW * 64, "A tile inside the patch");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = blockIdx.y, b = blockIdx.z;
     const int y0 = ((int)blockIdx.x / tiles_x) * TH, x0 = ((int)blockIdx.x % tiles_x) * TW;
@@ -213,23 +217,27 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
                 wc[ky][0] = w0.x; wc[ky][1] = w0.y; wc[ky][2] = w0.z; wc[ky][3] = w0.w;
                 wc[ky][4] = w1.x; wc[ky][5] = w1.y; wc[ky][6] = w1.z; wc[ky][7] = w1.w;
             }
-            uint4 raw[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) raw[r] = *reinterpret_cast<const uint4*>(in_t + ((yg * 4 + r) * PW + x + kx) * 64 + chunk * 16);
+            for (int hr = 0; hr < 2; ++hr) {                 // four rows at a time: 16 instead of 32 registers of raw rows (four workgroups per CU)
+                uint4 raw[4];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float xv[8];
-                unpack16(raw[r], xv, (bf16_t*)nullptr);
+                for (int r = 0; r < 4; ++r) raw[r] = *reinterpret_cast<const uint4*>(in_t + ((yg * 4 + hr * 4 + r) * PW + x + kx) * 64 + chunk * 16);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int ky = r - o;
-                    if (ky >= 0 && ky < 5) {
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = hr * 4 + r4;
+                    float xv[8];
+                    unpack16(raw[r4], xv, (bf16_t*)nullptr);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[o][e] += xv[e] * wc[ky][e];
+                    for (int o = 0; o < 4; ++o) {
+                        const int ky = r - o;
+                        if (ky >= 0 && ky < 5) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[o][e] += xv[e] * wc[ky][e];
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
 #else
 #pragma unroll 1
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(256, 3) void dw5_g1x1_kernel(const bf16_t* __restri
             }
         }
 #endif
+        __syncthreads();                                     // every thread is done with the patch: the A tile may overwrite it
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int px = (yg * 4 + o) * TW + x;
