@@ -661,20 +661,37 @@ __global__ __launch_bounds__(512) void dwproj_kernel(const bf16_t* __restrict__ 
         }
     }
     __syncthreads();                                         // (E2)
-    for (int id = tid; id < 128 * CPR; id += 512) {
-        const int row = id / CPR, cc = id % CPR;
-        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-        if (oy >= Ho || ox >= Wo) continue;
-        const uint4 rawo = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((cc ^ (row & 31)) << 4));
-        const long off = (((long)b * Ho + oy) * Wo + ox) * Cout + n0 + cc * 8;
-        if (res) {
-            float a[8], r8[8];
-            unpack16(rawo, a, (bf16_t*)nullptr);
-            unpack16(*reinterpret_cast<const uint4*>(res + off), r8, (bf16_t*)nullptr);
-            store4(out + off, a[0] + r8[0], a[1] + r8[1], a[2] + r8[2], a[3] + r8[3]);
-            store4(out + off + 4, a[4] + r8[4], a[5] + r8[5], a[6] + r8[6], a[7] + r8[7]);
-        } else {
-            *reinterpret_cast<uint4*>(out + off) = rawo;
+    // whole rows out: this thread's eight 16-byte pieces. All eight residual requests first (rolled, the loop was load -> vmcnt(0) -> add -> store per
+    // piece: eight memory round trips in a row at the end of every workgroup), then the adds and stores; rows outside the image load a clamped address and store nothing
+    {
+        constexpr int NP = 128 * CPR / 512;
+        static_assert(128 * CPR % 512 == 0, "whole pieces per thread");
+        long offs[NP];
+        bool ok[NP];
+        uint4 rr[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int id = tid + it * 512, row = id / CPR, cc = id % CPR;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            ok[it] = oy < Ho && ox < Wo;
+            offs[it] = (((long)b * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * Cout + n0 + cc * 8;
+            if (res) rr[it] = *reinterpret_cast<const uint4*>(res + offs[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int id = tid + it * 512, row = id / CPR, cc = id % CPR;
+            const uint4 rawo = *reinterpret_cast<const uint4*>(smem + row * ROWB + ((cc ^ (row & 31)) << 4));
+            if (res) {
+                float a[8], r8[8];
+                unpack16(rawo, a, (bf16_t*)nullptr);
+                unpack16(rr[it], r8, (bf16_t*)nullptr);
+                if (ok[it]) {
+                    store4(out + offs[it], a[0] + r8[0], a[1] + r8[1], a[2] + r8[2], a[3] + r8[3]);
+                    store4(out + offs[it] + 4, a[4] + r8[4], a[5] + r8[5], a[6] + r8[6], a[7] + r8[7]);
+                }
+            } else if (ok[it]) {
+                *reinterpret_cast<uint4*>(out + offs[it]) = rawo;
+            }
         }
     }
 }
